@@ -1,0 +1,208 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import glob
+import os
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolo_oracle as yo
+from oracle import rektnet_oracle as ro
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+T = torch.from_numpy
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(G, "bt_*.npz"))), ids=os.path.basename)
+def test_build_targets_bit_exact(path):
+    z = np.load(path)
+    tgt = T(z["target"])
+    keep = tgt.clone()
+    out = yo.build_targets(tgt, T(z["anchors"]), z["anchors"].shape[0], int(z["C"]), int(z["Gh"]), int(z["Gw"]), float(z["thr"]))
+    assert torch.equal(tgt, keep)                                  # input not mutated
+    for k, v in zip(("mask", "conf_mask", "tx", "ty", "tw", "th", "tconf", "tcls"), out):
+        assert v.dtype == T(z[k]).dtype, k
+        assert np.array_equal(v.numpy(), z[k]), k                  # 0 ulp, masks/indices exact
+
+
+def test_build_targets_quirks():
+    z = load("bt_leak.npz")
+    cm = z["conf_mask"]
+    # Q1: the ignore cell of image 0 is zeroed in image 1 as well (all anchors not holding a positive)
+    zero_cells = np.argwhere(cm[1] == 0)
+    assert len(zero_cells) > 0
+    z = load("bt_empty.npz")                                      # Q3 phantom positive at [0, a, 0, 0]
+    assert z["mask"][0].sum() == 1 and z["mask"][0][:, 0, 0].sum() == 1
+    assert np.isclose(z["tw"][0].min(), np.log(np.float32(1e-16)), rtol=1e-6)
+
+
+def test_bbox_iou():
+    z = load("bbox_iou.npz")
+    assert np.array_equal(yo.corner_iou_plus1(T(z["c1"]), T(z["c2"])).numpy(), z["iou_corner"])
+    assert np.array_equal(yo.center_iou_plus1(T(z["b1"]), T(z["b2"])).numpy(), z["iou_center"])
+
+
+@pytest.mark.parametrize("name", ["yolo_layer_c1_g13.npz", "yolo_layer_c80_g13.npz", "yolo_layer_c1_g26.npz"])
+def test_yolo_layer(name):
+    z = load(name)
+    s = T(z["sample"]).clone().requires_grad_(True)
+    anchors = [tuple(a) for a in z["anchors_px"].tolist()]
+    loss, parts = yo.yolo_layer(s, anchors, int(z["C"]), int(z["cfg_h"]), T(z["targets"]))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), z["loss"], rtol=1e-6)
+    np.testing.assert_allclose(parts.numpy(), z["parts"], rtol=1e-6)
+    np.testing.assert_allclose(s.grad.numpy(), z["dsample"], rtol=1e-5, atol=1e-9)
+    ev = yo.yolo_layer(s.detach(), anchors, int(z["C"]), int(z["cfg_h"]))
+    np.testing.assert_allclose(ev.numpy(), z["eval_out"], rtol=1e-6, atol=1e-7)
+
+
+def ref_key_to_oracle(k):
+    # module_list.3.conv_3.weight -> conv3.weight ; module_list.3.batch_norm_3.running_mean -> bn3.running_mean
+    _, i, mod, leaf = k.split(".")
+    return ("conv" if mod.startswith("conv") else "bn") + f"{i}.{leaf}"
+
+
+@pytest.fixture(scope="module")
+def mini():
+    cwd = os.getcwd()
+    os.chdir(os.path.join(G, "mini"))
+    try:
+        anchors = yo.read_anchor_row("dataset/train.csv")
+        net = yo.DarknetOracle("mini.cfg", anchors=anchors)
+        net.load_weights("mini.weights", [18, 18])
+    finally:
+        os.chdir(cwd)
+    return net
+
+
+def test_mini_darknet_loss_grads_running(mini):
+    z = load("mini_darknet.npz")
+    net = mini
+    base = {k: v.clone() for k, v in net.params.items()}
+    for k in net.trainable():
+        net.params[k] = base[k].clone().requires_grad_(True)
+    losses = net.forward(T(z["x"]), T(z["targets"]), bn_train=True)
+    losses[0].sum().backward()
+    np.testing.assert_allclose(torch.stack([l.detach() for l in losses]).numpy(), z["losses"], rtol=2e-5)
+    names = [str(n) for n in z["grad_names"]]
+    for n, gn in zip(names, z["grad_norm"]):
+        g = net.params[ref_key_to_oracle(n)].grad
+        np.testing.assert_allclose(float(g.double().norm()), gn, rtol=2e-4, atol=1e-7, err_msg=n)
+    for k in z.files:
+        if k.startswith("grad::"):
+            g = net.params[ref_key_to_oracle(k[6:])].grad
+            np.testing.assert_allclose(g.numpy(), z[k], rtol=1e-3, atol=2e-6, err_msg=k)
+        if k.startswith("run::"):
+            np.testing.assert_allclose(net.params[ref_key_to_oracle(k[5:])].detach().numpy(), z[k], rtol=1e-5, atol=1e-7, err_msg=k)
+    # the fixture's eval pass ran AFTER the train step, i.e. with the updated running stats
+    for k, v in base.items():
+        if "running" not in k:
+            net.params[k] = v
+    with torch.no_grad():
+        ev = net.forward(T(z["x"]), None, bn_train=False)
+    np.testing.assert_allclose(ev.numpy(), z["eval_out"], rtol=1e-4, atol=1e-5)
+    for k, v in base.items():
+        net.params[k] = v
+
+
+def test_mini_weights_roundtrip(mini, tmp_path):
+    p = tmp_path / "rt.weights"
+    mini.save_weights(str(p))
+    assert open(p, "rb").read() == open(os.path.join(G, "mini", "mini.weights"), "rb").read()
+
+
+def test_mini_dp_semantics(mini):
+    """rank r's loss == oracle on shard r alone; all-reduced grad == sum of per-shard grads."""
+    z = load("mini_darknet_dp.npz")
+    base = {k: v.clone() for k, v in mini.params.items()}
+    x, tg = T(z["x"]), T(z["targets"])
+    for nsh in (2, 4):
+        per = 8 // nsh
+        tot = None
+        for r in range(nsh):
+            for k, v in base.items():
+                mini.params[k] = v.clone().requires_grad_("running" not in k)
+            ls = mini.forward(x[r * per:(r + 1) * per], tg[r * per:(r + 1) * per])
+            ls[0].sum().backward()
+            np.testing.assert_allclose(torch.stack([l.detach() for l in ls]).numpy(), z[f"losses_{nsh}"][r], rtol=5e-5)
+            g0 = mini.params["conv0.weight"].grad
+            tot = g0 if tot is None else tot + g0
+        np.testing.assert_allclose(tot.numpy(), z[f"g0_{nsh}"], rtol=2e-3, atol=1e-5)
+    for k, v in base.items():
+        mini.params[k] = v
+
+
+def test_yolo_baseline_structure():
+    z = load("yolo_baseline_structure.npz")
+    v = {(int(r[0]), int(r[1])): r for r in z["variants"]}
+    assert v[(80, 416)][2] == 61949149 and v[(1, 416)][2] == 61523734
+    assert v[(80, 416)][3] == 10647 and v[(80, 608)][3] == 22743 and v[(80, 416)][4] == 85
+    assert z["conv_table"].shape[0] == 75
+
+
+# ----------------------------------------------------------------------------- RektNet
+def test_rektnet_forward_backward():
+    z = load("rektnet_net.npz")
+    sd0 = {k[4:]: T(z[k]) for k in z.files if k.startswith("sd::")}
+    assert sum(v.numel() for k, v in sd0.items() if "running" not in k and "num_batches" not in k) == 311383
+    x, thm, tpts = T(z["x"]), T(z["thm"]), T(z["tpts"])
+    for lt, geo in (("l1_softargmax", True), ("l2_heatmap", False)):
+        tag = f"{lt}:{int(geo)}"
+        sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd0.items()}
+        hm, pts = ro.keypoint_forward(x, sd, train=True)
+        loc, gl, tot = ro.cross_ratio_loss(hm, pts, thm, tpts, lt, geo, 0.05, 0.05)
+        tot.backward()
+        np.testing.assert_allclose(pts.detach().numpy(), z[f"pts::{tag}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose([float(loc), float(gl), float(tot)], z[f"loss::{tag}"], rtol=1e-5, atol=1e-7)
+        names = [str(n) for n in z["gnames"]]
+        for n, gn in zip(names, z[f"gnorm::{tag}"]):
+            # conv biases in front of a BN have mathematically-zero grads (Q17): pure round-off, compare loosely
+            noise = n.endswith(".bias") and "bn" not in n and n != "out.bias"
+            np.testing.assert_allclose(float(sd[n].grad.double().norm()), gn, rtol=5e-3, atol=1e-3 if noise else 1e-6, err_msg=n)
+        for k in z.files:
+            if k.startswith(f"grad::{tag}::"):
+                n = k.split("::")[2]
+                ref = z[k]
+                if n.endswith("conv1.bias"):
+                    assert np.abs(sd[n].grad.numpy()).max() < 1e-3
+                    continue
+                np.testing.assert_allclose(sd[n].grad.numpy(), ref, rtol=5e-3, atol=1e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+        if lt == "l1_softargmax":
+            np.testing.assert_allclose(hm.detach().numpy(), z[f"hm::{tag}"], rtol=1e-3, atol=1e-8)
+            for k in z.files:
+                if k.startswith("run::"):
+                    np.testing.assert_allclose(sd[k[5:]].numpy(), z[k], rtol=1e-5, atol=1e-7, err_msg=k)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    with torch.no_grad():
+        _, pts = ro.keypoint_forward(x, sd, train=False)
+        lg = ro.keypoint_forward(x, sd, train=False, logits_only=True)
+    np.testing.assert_allclose(pts.numpy(), z["eval_pts"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(lg[:1].numpy(), z["eval_logits"], rtol=1e-4, atol=1e-5)
+
+
+def test_cross_ratio_loss_all_variants():
+    z = load("cross_ratio.npz")
+    hm, thm, tpts = T(z["hm"]), T(z["thm"]), T(z["tpts"])
+    for lt in ("l2_softargmax", "l2_heatmap", "l1_softargmax"):
+        for geo in (False, True):
+            tag = f"{lt}:{int(geo)}"
+            p = T(z["pts"]).clone().requires_grad_(True)
+            h = hm.clone().requires_grad_(True)
+            loc, gl, tot = ro.cross_ratio_loss(h, p, thm, tpts, lt, geo, 0.05, 0.07)
+            tot.backward()
+            np.testing.assert_allclose([float(loc), float(gl), float(tot)], z[f"loss::{tag}"], rtol=1e-6, atol=1e-8)
+            dp = p.grad if p.grad is not None else torch.zeros_like(p)
+            np.testing.assert_allclose(dp.numpy(), z[f"dpts::{tag}"], rtol=1e-5, atol=1e-8)
+            if lt == "l2_heatmap":
+                np.testing.assert_allclose(h.grad[0, 0].numpy(), z[f"dhm_sample::{tag}"], rtol=1e-5, atol=1e-10)
+    with pytest.raises(NameError):
+        ro.cross_ratio_loss(hm, T(z["pts"]), thm, tpts, "nonsense", True)
+
+
+def test_oracle_rektnet_init_param_count():
+    sd = ro.init_state(0)
+    assert sum(v.numel() for k, v in sd.items() if "running" not in k) == 311383
