@@ -1,0 +1,125 @@
+/* libmdcv_hip.so — C ABI of the MI355X (gfx950) hot path of CVC-YOLOv3 + RektNet training.
+ *
+ * The reference (cv-core/MIT-Driverless-CV-TrainingInfra) has NO native/FFI layer: its hot path is Python calling
+ * stock torch ops.  This ABI is therefore the boundary the reference *would* bind if it had one; each entry point
+ * names the reference call site(s) it replaces.  Conventions:
+ *   - plain C symbols, plain pointers and sizes; the CALLER owns every buffer (device memory), kernels allocate nothing
+ *   - enqueue-only on the caller's HIP stream (`stream` = hipStream_t as void*), no synchronisation inside
+ *   - return 0 on success, a negative MDCV_E* for argument errors, or a positive hipError_t
+ *   - dtype: 0 = fp32 (parity mode, exact-f32 MFMA), 1 = bf16 (production, fp32 accumulate)
+ *   - activations are NHWC with an explicit channel stride `ld*` (elements); channel counts are padded to a multiple
+ *     of 8 and pad channels hold exact zeros; weights/gradients at the boundary are OIHW fp32 like torch parameters
+ */
+#ifndef MDCV_HIP_H
+#define MDCV_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDCV_OK 0
+#define MDCV_EARG (-1)
+#define MDCV_F32 0
+#define MDCV_BF16 1
+#define MDCV_ACT_NONE 0
+#define MDCV_ACT_LEAKY 1
+#define MDCV_ACT_RELU 2
+
+/* ---- convolution (nn.Conv2d fwd/bwd: CVC-YOLOv3/models.py:59-65 ; RektNet/keypoint_net.py:17,25 ; RektNet/resnet.py:12-19)
+ * mode 0: forward.  in=[B,Hin,Win,Cin], out=[B,Hout,Wout,Nout], w_packed=[Nout][KH*KW][Cin] (from mdcv_pack_weights w_fwd).
+ * mode 1: data gradient.  in=dY [B,Hin,Win,Cin=Cout_pad] on the conv's OUTPUT grid, out=dX on the conv's INPUT grid
+ *         [B,Hout,Wout,Nout=Cin_pad], w_packed=[Cin_pad][KH*KW][Cout_pad] (w_dgrad).  stride in {1,2}.
+ * bias (fp32[Nout]) is added before statistics; addsrc (same layout as out) is added after (residual / fan-out grads);
+ * stats_partial, if given, receives [mdcv_conv2d_stats_rows(M)][2][Nout] fp32 = per-tile (sum, sum^2) per channel. */
+int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc,
+                const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
+                int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
+                int KH, int KW, int stride, int pad, int dil, void* stream);
+int mdcv_conv2d_stats_rows(int M);
+
+/* weight gradient: dW (OIHW fp32, real channel counts) = dY^T * im2col(X).  ws = splits*Cout*KH*KW*Cin floats of scratch. */
+int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot);
+int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits,
+                      float* dw_oihw, int accumulate, int B, int Hin, int Win, int Cin, int Cin_real,
+                      int Hout, int Wout, int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream);
+
+/* OIHW fp32 parameters -> GEMM operand layouts (w_dgrad may be NULL) */
+int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,
+                      int Cout_pad, int Cin_pad, void* stream);
+
+/* ---- layout conversion at the API edge (reference tensors are NCHW fp32: train.py:60, train_eval.py:60) */
+int mdcv_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int ldc, int Cpad, void* stream);
+int mdcv_nhwc_to_nchw(int dtype, const void* src, int ldc, float* dst, int B, int C, int H, int W, void* stream);
+
+/* ---- BatchNorm2d (eps 1e-5, momentum 0.1) + LeakyReLU/ReLU + shortcut add (models.py:66-71,325-327 ; resnet.py:22-27) */
+int mdcv_partial_reduce(const float* partial, int rows, int nsums, int C, double* accum, void* stream);
+int mdcv_bn_finalize(double* accum, double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float momentum, float eps, float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
+int mdcv_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                        float* scale, float* shift, int C, void* stream);
+/* out = act(y1*s1+b1 [+ y2*s2+b2]) [+ resid] */
+int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const float* b1, const void* y2, int ld2, const float* s2,
+                    const float* b2, const void* resid, int ldr, void* out, int ldo, int M, int C, int act, float slope, void* stream);
+int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,
+                           const float* mean1, const float* invstd1, const void* y2, int ld2, const float* s2, const float* b2,
+                           const float* mean2, const float* invstd2, double* accum, int M, int C, int act, float slope, void* stream);
+int mdcv_bn_bwd_finalize(double* accum, int kx, int nsums, int zero_after, double count, const float* gamma, const float* mean,
+                         const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int C, void* stream);
+int mdcv_bn_act_bwd_apply(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,
+                          const float* cA1, const float* cB1, const float* cC1, void* dy1, int ldy1,
+                          const void* y2, int ld2, const float* s2, const float* b2, const float* cA2, const float* cB2,
+                          const float* cC2, void* dy2, int ldy2, int M, int C, int act, float slope, void* stream);
+int mdcv_colsum(int dtype, const void* x, int ldc, int M, int C, double* accum, void* stream);
+int mdcv_accum_to_f32(double* accum, float* out, int n, int zero_after, void* stream);
+
+/* ---- nn.Upsample(scale 2, nearest) fwd/bwd (models.py:86-88); H,W are the LOW-resolution dims */
+int mdcv_upsample2x_fwd(int dtype, const void* in, int ldi, void* out, int ldo, int B, int H, int W, int C, void* stream);
+int mdcv_upsample2x_bwd(int dtype, const void* dout, int ldo, void* din, int ldi, int B, int H, int W, int C, void* stream);
+
+/* ---- YOLOLayer.forward (models.py:140-220) + build_targets / bbox_iou (utils/utils.py:163-275)
+ * logits NHWC, channel = a*(5+C)+attr.  anchors_scaled = anchors/stride, fp32 [A][2].  targets fp32 [B][T][5].
+ * train: out7[0] += loss, out7[1..6] += (x,y,w,h,obj,noobj) parts; dlogits = d loss / d logits (* *gscale if given). */
+long long mdcv_yolo_head_workspace_bytes(int B, int A, int Gh, int Gw);
+int mdcv_yolo_head_train(int dtype, const void* logits, int ldc, void* dlogits, int ldd, int Cpad, const float* targets,
+                         const float* anchors_scaled, int B, int T, int A, int C, int Gh, int Gw, float thresh, float xy_loss,
+                         float wh_loss, float obj_loss, float noobj_loss, void* workspace, float* out7, const float* gscale,
+                         void* stream);
+int mdcv_yolo_head_grad(int dtype, const void* logits, int ldc, void* dlogits, int ldd, int Cpad, const float* targets,
+                        const float* anchors_scaled, int B, int T, int A, int C, int Gh, int Gw, float thresh, float xy_loss,
+                        float wh_loss, float obj_loss, float noobj_loss, void* workspace, const float* gscale, void* stream);
+int mdcv_yolo_head_decode(int dtype, const void* logits, int ldc, const float* anchors_scaled, float stride, int B, int A, int C, int Gh,
+                          int Gw, float* out, int rows_total, int row_off, void* stream);
+long long mdcv_build_targets_workspace_bytes(int B, int T, int A, int Gh, int Gw);
+int mdcv_build_targets(const float* targets, const float* anchors, int B, int T, int A, int C, int Gh, int Gw, float thresh,
+                       unsigned char* mask, unsigned char* conf_mask, float* tx, float* ty, float* tw, float* th, float* tconf,
+                       unsigned char* tcls, void* workspace, int* err_out, void* stream);
+
+/* ---- KeypointNet head (keypoint_net.py:46-56,68-70) and CrossRatioLoss (cross_ratio_loss.py:20-63) */
+int mdcv_softargmax_fwd(int dtype, const void* logits, int ldc, int B, int K, int H, int W, float* hm, float* pts, void* stream);
+int mdcv_softargmax_bwd(int dtype, const float* hm, const float* pts, const float* dpts, const float* dhm, float* sdot_ws, int B, int K,
+                        int H, int W, void* dlogits, int ldd, void* stream);
+int mdcv_cross_ratio_loss(const float* hm, const float* pts, const float* thm, const float* tpts, int B, int H, int W, int loss_type,
+                          int include_geo, float gamma_horz, float gamma_vert, double* acc_ws, const float* gscale, float* out3,
+                          float* dpts, float* dhm, void* stream);
+
+/* ---- optimizer step over the flat fp32 parameter buffer (train.py:180-187,72 ; train_eval.py:263,72) */
+int mdcv_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+int mdcv_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, int step, float lr, float momentum, float weight_decay,
+                  float grad_scale, void* stream);
+
+/* ---- runtime plumbing: device query, HIP events on a caller stream, hipGraph capture of a launch sequence */
+int mdcv_device_info(int* cu_count, int* wave_size, long long* hbm_bytes, char* arch, int arch_len);
+int mdcv_event_create(void** ev);
+int mdcv_event_record(void* ev, void* stream);
+int mdcv_event_sync(void* ev);
+int mdcv_event_elapsed_ms(void* start, void* stop, float* ms);
+int mdcv_event_destroy(void* ev);
+int mdcv_graph_begin(void* stream);
+int mdcv_graph_end(void* stream, void** graph_exec);
+int mdcv_graph_launch(void* graph_exec, void* stream);
+int mdcv_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,74 @@
+// Shared device helpers for the MDCV gfx950 kernels.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;   // raw bf16 bits; all arithmetic is done in fp32
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define MDCV_OK 0
+#define MDCV_EARG (-1)
+#define MDCV_F32 0
+#define MDCV_BF16 1
+
+#define MDCV_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return (int)e__;                   \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {            // round-to-nearest-even, NaN preserved
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+// element traits: VEC = elements per 16-byte vector
+template <typename T> struct ET;
+template <> struct ET<float> {
+  static constexpr int VEC = 4;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ void unpack(const uint4& q, float* f) {
+    f[0] = __uint_as_float(q.x); f[1] = __uint_as_float(q.y); f[2] = __uint_as_float(q.z); f[3] = __uint_as_float(q.w);
+  }
+  __device__ static __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  }
+};
+template <> struct ET<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  __device__ static __forceinline__ void unpack(const uint4& q, float* f) {
+    f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xffff0000u);
+    f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xffff0000u);
+    f[4] = __uint_as_float(q.z << 16); f[5] = __uint_as_float(q.z & 0xffff0000u);
+    f[6] = __uint_as_float(q.w << 16); f[7] = __uint_as_float(q.w & 0xffff0000u);
+  }
+  __device__ static __forceinline__ uint4 pack(const float* f) {
+    return make_uint4((unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16), (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16),
+                      (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16), (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16));
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

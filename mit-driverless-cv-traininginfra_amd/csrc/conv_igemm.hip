@@ -1,0 +1,557 @@
+// NHWC implicit-GEMM convolution for gfx950 (MFMA): forward, data-gradient and weight-gradient.
+//
+// Replaces the nn.Conv2d calls on the reference hot path (CVC-YOLOv3/models.py:59-65,
+// RektNet/keypoint_net.py:17,25, RektNet/resnet.py:12-19) and their autograd backward.
+//
+// GEMM view (fwd):   Y[m, n] = sum_k  Xcol[m, k] * W[n, k]      m = (img, ho, wo)   n = cout   k = (kh, kw, ci)
+//      (dgrad):      dX[m, n] = sum_k dYcol[m, k] * Wt[n, k]    m = (img, hi, wi)   n = cin    k = (kh, kw, co)
+//      (wgrad):      dW[co, k] = sum_m dY[m, co] * Xcol[m, k]   reduction over pixels, split over the grid
+//
+// Activations are NHWC with an explicit channel stride (ldc) so route-concat is a strided write, channels padded
+// to a multiple of 8 (pad lanes are exactly zero).  Element type T is bf16 (production: v_mfma_f32_16x16x32_bf16)
+// or fp32 (parity mode: v_mfma_f32_16x16x4_f32, bit-exact fmaf chains).  Accumulation is always fp32.
+//
+// Tiling: 256 threads = 4 waves; K tile = 64 bytes per row (32 bf16 / 16 fp32); global->register->LDS staging with
+// the next tile's loads issued before the current tile's MFMAs (one barrier per K tile, 2 LDS buffers);
+// LDS rows padded to 80 bytes; epilogue staged through LDS for 16-byte coalesced stores; BatchNorm batch statistics
+// (sum, sum of squares per output channel) are produced from the fp32 accumulators in the epilogue.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWB = 80;  // LDS bytes per tile row (64 payload + 16 pad)
+
+struct ConvArgs {
+  const void* in; const void* w; void* out; const float* bias; const void* addsrc; float* stats;
+  int in_ldc, out_ldc, add_ldc;
+  int Hin, Win, Cin, Hout, Wout, Nout;
+  int KH, KW, stride, pad, dil;
+  int M, Ktot, tiles_n, sshift;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  template <int FM, int FN>
+  __device__ static __forceinline__ void mma(const unsigned char* sa, const unsigned char* sb, int lane, f32x4_t (&acc)[FM][FN]) {
+    bf16x8_t a[FM], b[FN];
+    const int off = (lane & 15) * ROWB + (lane >> 4) * 16;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 16 * ROWB + off);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 16 * ROWB + off);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+};
+template <> struct Frag<float> {
+  template <int FM, int FN>
+  __device__ static __forceinline__ void mma(const unsigned char* sa, const unsigned char* sb, int lane, f32x4_t (&acc)[FM][FN]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float a[FM], b[FN];
+      const int off = (lane & 15) * ROWB + (ks * 4 + (lane >> 4)) * 4;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const float*>(sa + i * 16 * ROWB + off);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const float*>(sb + j * 16 * ROWB + off);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+};
+
+// MODE 0: forward gather  hi = ho*stride - pad + kh*dil
+// MODE 1: data gradient   hi = (h + pad - kh*dil) / stride when divisible   (stride is 1 or 2)
+template <typename T, int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int VEC = ET<T>::VEC;
+  constexpr int BK = 4 * VEC;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int NPA = BM / 64, NPB = (BN + 63) / 64;
+  constexpr int PIPE = 2 * (BM + BN) * ROWB;
+  constexpr int SROW = BN * (int)sizeof(T) + 16;
+  constexpr int STAGE = BM * SROW;
+  constexpr int STAT_OFF = PIPE > STAGE ? PIPE : STAGE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
+  const int arow = tid >> 2, kv = tid & 3;
+  const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
+  const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
+
+  // per-row pixel decomposition (fixed for the whole K loop)
+  int bh[NPA], bw[NPA], ib[NPA];
+  bool rv[NPA];
+  const int HWo = a.Hout * a.Wout;
+#pragma unroll
+  for (int p = 0; p < NPA; ++p) {
+    const int m = tile_m * BM + arow + p * 64;
+    rv[p] = m < a.M;
+    const int mm = rv[p] ? m : 0;
+    const int img = mm / HWo, rem = mm - img * HWo;
+    const int ho = rem / a.Wout, wo = rem - ho * a.Wout;
+    ib[p] = img * a.Hin * a.Win;
+    if (MODE == 0) { bh[p] = ho * a.stride - a.pad; bw[p] = wo * a.stride - a.pad; }
+    else           { bh[p] = ho + a.pad;            bw[p] = wo + a.pad; }
+  }
+  // per-thread K cursor: k = kt*BK + kv*VEC  ->  (kh, kw, c)
+  int kc, kh, kw;
+  {
+    const int k0 = kv * VEC, tap = k0 / a.Cin;
+    kc = k0 - tap * a.Cin; kh = tap / a.KW; kw = tap - kh * a.KW;
+  }
+  const int smask = a.stride - 1;
+
+  uint4 ra[NPA], rb[NPB];
+  auto load_tile = [&](int kt) {
+    const bool kvalid = kh < a.KH;
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) {
+      int hi, wi; bool ok = rv[p] && kvalid;
+      if (MODE == 0) { hi = bh[p] + kh * a.dil; wi = bw[p] + kw * a.dil; }
+      else {
+        const int th = bh[p] - kh * a.dil, tw = bw[p] - kw * a.dil;
+        ok = ok && th >= 0 && tw >= 0 && (((th | tw) & smask) == 0);
+        hi = th >> a.sshift; wi = tw >> a.sshift;
+      }
+      ok = ok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *reinterpret_cast<const uint4*>(in + ((size_t)(ib[p] + hi * a.Win + wi) * a.in_ldc + kc));
+      ra[p] = v;
+    }
+    const int k = kt * BK + kv * VEC;
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+      const int brow = arow + p * 64;
+      const int n = tile_n * BN + brow;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (brow < BN && n < a.Nout && k < a.Ktot) v = *reinterpret_cast<const uint4*>(w + ((size_t)n * a.Ktot + k));
+      rb[p] = v;
+    }
+  };
+  auto advance = [&]() {
+    kc += BK;
+    while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* sA = smem + buf * (BM + BN) * ROWB;
+    unsigned char* sB = sA + BM * ROWB;
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) *reinterpret_cast<uint4*>(sA + (arow + p * 64) * ROWB + kv * 16) = ra[p];
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+      const int brow = arow + p * 64;
+      if (brow < BN) *reinterpret_cast<uint4*>(sB + brow * ROWB + kv * 16) = rb[p];
+    }
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (a.Ktot + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) { advance(); load_tile(kt + 1); }
+    const unsigned char* sA = smem + cur * (BM + BN) * ROWB + wm * TM * ROWB;
+    const unsigned char* sB = smem + cur * (BM + BN) * ROWB + BM * ROWB + wn * TN * ROWB;
+    Frag<T>::template mma<FM, FN>(sA, sB, lane, acc);
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  const int n0 = tile_n * BN + wn * TN, m0 = tile_m * BM + wm * TM;
+  if (a.bias) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + j * 16 + (lane & 15);
+      const float bv = n < a.Nout ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += bv;
+    }
+  }
+  float* sstat = reinterpret_cast<float*>(smem + STAT_OFF);   // [WM][2][BN]
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + i * 16 + (lane >> 4) * 4 + r;
+          const float v = m < a.M ? acc[i][j][r] : 0.f;
+          s += v; q += v * v;
+        }
+      s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+      if (lane < 16) {
+        sstat[(wm * 2 + 0) * BN + wn * TN + j * 16 + lane] = s;
+        sstat[(wm * 2 + 1) * BN + wn * TN + j * 16 + lane] = q;
+      }
+    }
+  }
+  // stage the tile as T (the K loop ended with a barrier, so the pipeline buffers are free)
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * TM + i * 16 + (lane >> 4) * 4 + r, col = wn * TN + j * 16 + (lane & 15);
+        ET<T>::st(reinterpret_cast<T*>(smem + row * SROW) + col, acc[i][j][r]);
+      }
+  __syncthreads();
+  if (a.stats && tid < BN) {
+    const int n = tile_n * BN + tid;
+    if (n < a.Nout) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int r = 0; r < WM; ++r) { s += sstat[(r * 2 + 0) * BN + tid]; q += sstat[(r * 2 + 1) * BN + tid]; }
+      a.stats[((size_t)tile_m * 2 + 0) * a.Nout + n] = s;
+      a.stats[((size_t)tile_m * 2 + 1) * a.Nout + n] = q;
+    }
+  }
+  T* __restrict__ out = reinterpret_cast<T*>(a.out);
+  const T* __restrict__ addsrc = reinterpret_cast<const T*>(a.addsrc);
+  constexpr int VPR = BN / VEC;
+  for (int v = tid; v < BM * VPR; v += 256) {
+    const int row = v / VPR, cv = v - row * VPR;
+    const int m = tile_m * BM + row, n = tile_n * BN + cv * VEC;
+    if (m < a.M && n < a.Nout) {
+      uint4 d = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
+      if (addsrc) {
+        float x[VEC], y[VEC];
+        ET<T>::unpack(d, x);
+        ET<T>::unpack(*reinterpret_cast<const uint4*>(addsrc + ((size_t)m * a.add_ldc + n)), y);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x[e] += y[e];
+        d = ET<T>::pack(x);
+      }
+      *reinterpret_cast<uint4*>(out + ((size_t)m * a.out_ldc + n)) = d;
+    }
+  }
+}
+
+template <typename T, int MODE, int BM, int BN, int WM, int WN>
+int launch_conv(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  constexpr int PIPE = 2 * (BM + BN) * ROWB;
+  constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
+  constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;
+  static bool attr_set = false;
+  auto kern = conv_igemm_kernel<T, MODE, BM, BN, WM, WN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  a.tiles_n = cdiv(a.Nout, BN);
+  const int tiles_m = cdiv(a.M, BM);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(256), LDS, st, a);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+template <typename T, int MODE>
+int dispatch_conv(const ConvArgs& a, hipStream_t st) {
+  if (a.Nout > 64) return launch_conv<T, MODE, 128, 128, 2, 2>(a, st);
+  if (a.Nout > 32) return launch_conv<T, MODE, 128, 64, 2, 2>(a, st);
+  if (a.Nout > 16) return launch_conv<T, MODE, 128, 32, 4, 1>(a, st);
+  return launch_conv<T, MODE, 128, 16, 4, 1>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dW[co, k] = sum_m dY[m, co] * Xcol[m, k]; pixels (the reduction) are split across the grid and each
+// split writes an fp32 partial slab ws[split][Cout][Ktot]; mdcv_wgrad_reduce sums the slabs into the OIHW fp32 grad.
+// Both operands are pixel-major in HBM, so tiles are transposed on the way into LDS ([channel][pixel] rows) with the
+// channel<->row permutation  row = j*OQ + oct  (channel = oct*VEC + j)  which keeps the transposing ds_writes 2-way.
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const void* dy; const void* x; float* ws;
+  int dy_ldc, x_ldc;
+  int Hin, Win, Cin, Hout, Wout, Cout;
+  int KH, KW, stride, pad, dil;
+  int M, Ktot, tiles_k, tiles_ck, pix_per_split;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int VEC = ET<T>::VEC;
+  constexpr int BP = 4 * VEC;          // pixels per reduction tile (64 bytes per LDS row)
+  constexpr int OQ = 128 / VEC;        // 16-byte vectors per pixel across the 128-wide tile
+  constexpr int FM = 4, FN = 4;        // 2x2 waves, 64x64 per wave
+  constexpr int PIPE = 2 * 256 * ROWB;
+  constexpr int OROW = 132;            // fp32 staging pitch
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int split = blockIdx.x / a.tiles_ck;
+  const int tck = blockIdx.x - split * a.tiles_ck;
+  const int tile_co = tck / a.tiles_k, tile_k = tck - tile_co * a.tiles_k;
+  const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+
+  const int oct = tid % OQ, pp = tid / OQ;           // this thread stages pixels 2pp, 2pp+1 of each tile
+  const int co0 = tile_co * 128 + oct * VEC;
+  const bool a_ok = co0 < a.Cout;
+  const int kcol0 = tile_k * 128 + oct * VEC;
+  const bool b_ok = kcol0 < a.Ktot;
+  int dh, dw, ci;
+  {
+    const int kk = b_ok ? kcol0 : 0;
+    const int tap = kk / a.Cin;
+    ci = kk - tap * a.Cin;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    dh = kh * a.dil - a.pad; dw = kw * a.dil - a.pad;
+  }
+  const int p_begin = split * a.pix_per_split;
+  const int p_end = min(a.M, p_begin + a.pix_per_split);
+  // running (img, ho, wo) of pixel  p_begin + 2pp  ; advanced by BP per tile
+  int m_cur = p_begin + 2 * pp;
+  int img, ho, wo;
+  {
+    const int HWo = a.Hout * a.Wout;
+    img = m_cur / HWo; const int rem = m_cur - img * HWo;
+    ho = rem / a.Wout; wo = rem - ho * a.Wout;
+  }
+  uint4 ra[2], rb[2];
+  auto load_tile = [&]() {
+    int i2 = img, h2 = ho, w2 = wo;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int m = m_cur + e;
+      const bool pv = m < p_end;
+      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+      if (pv && a_ok) va = *reinterpret_cast<const uint4*>(dy + ((size_t)m * a.dy_ldc + co0));
+      const int hi = h2 * a.stride + dh, wi = w2 * a.stride + dw;
+      if (pv && b_ok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win)
+        vb = *reinterpret_cast<const uint4*>(x + ((size_t)((i2 * a.Hin + hi) * a.Win + wi) * a.x_ldc + ci));
+      ra[e] = va; rb[e] = vb;
+      if (++w2 == a.Wout) { w2 = 0; if (++h2 == a.Hout) { h2 = 0; ++i2; } }
+    }
+  };
+  auto advance = [&]() {
+    m_cur += BP;
+    wo += BP;
+    while (wo >= a.Wout) { wo -= a.Wout; if (++ho == a.Hout) { ho = 0; ++img; } }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* sA = smem + buf * 256 * ROWB;
+    unsigned char* sB = sA + 128 * ROWB;
+    if (sizeof(T) == 2) {
+      const unsigned a0[4] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w}, a1[4] = {ra[1].x, ra[1].y, ra[1].z, ra[1].w};
+      const unsigned b0[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, b1[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // channels 2q, 2q+1 of the octet ; word = (pixel 2pp | pixel 2pp+1 << 16)
+        *reinterpret_cast<unsigned*>(sA + ((2 * q) * OQ + oct) * ROWB + pp * 4) = (a0[q] & 0xffffu) | (a1[q] << 16);
+        *reinterpret_cast<unsigned*>(sA + ((2 * q + 1) * OQ + oct) * ROWB + pp * 4) = (a0[q] >> 16) | (a1[q] & 0xffff0000u);
+        *reinterpret_cast<unsigned*>(sB + ((2 * q) * OQ + oct) * ROWB + pp * 4) = (b0[q] & 0xffffu) | (b1[q] << 16);
+        *reinterpret_cast<unsigned*>(sB + ((2 * q + 1) * OQ + oct) * ROWB + pp * 4) = (b0[q] >> 16) | (b1[q] & 0xffff0000u);
+      }
+    } else {
+      const unsigned a0[4] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w}, a1[4] = {ra[1].x, ra[1].y, ra[1].z, ra[1].w};
+      const unsigned b0[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, b1[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // channel q of the quad ; two fp32 pixels side by side
+        *reinterpret_cast<uint2*>(sA + (q * OQ + oct) * ROWB + pp * 8) = make_uint2(a0[q], a1[q]);
+        *reinterpret_cast<uint2*>(sB + (q * OQ + oct) * ROWB + pp * 8) = make_uint2(b0[q], b1[q]);
+      }
+    }
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nt = (p_end - p_begin + BP - 1) / BP;
+  if (nt > 0) {
+    load_tile();
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) { advance(); load_tile(); }
+    const unsigned char* sA = smem + cur * 256 * ROWB + wm * 64 * ROWB;
+    const unsigned char* sB = smem + cur * 256 * ROWB + 128 * ROWB + wn * 64 * ROWB;
+    Frag<T>::template mma<FM, FN>(sA, sB, lane, acc);
+    if (t + 1 < nt) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+  // stage fp32 tile [co_local][k_local] (undo the row permutation), then coalesced rows into the slab
+  float* so = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int Ra = (wm * FM + i) * 16 + (lane >> 4) * 4 + r;
+        const int Rb = (wn * FN + j) * 16 + (lane & 15);
+        const int col = (Ra % OQ) * VEC + Ra / OQ;
+        const int kl = (Rb % OQ) * VEC + Rb / OQ;
+        so[col * OROW + kl] = acc[i][j][r];
+      }
+  __syncthreads();
+  float* __restrict__ ws = a.ws + (size_t)split * a.Cout * a.Ktot;
+  for (int v = tid; v < 128 * 32; v += 256) {
+    const int row = v >> 5, c4 = (v & 31) * 4;
+    const int co = tile_co * 128 + row, k = tile_k * 128 + c4;
+    if (co < a.Cout && k < a.Ktot)   // Ktot is a multiple of 8, so a float4 never straddles the edge
+      *reinterpret_cast<float4*>(ws + (size_t)co * a.Ktot + k) = *reinterpret_cast<const float4*>(so + row * OROW + c4);
+  }
+  (void)PIPE;
+}
+
+// slabs -> OIHW fp32 gradient (real Cin, i.e. without channel padding)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int Cout_pad,
+                                    int Cout, int Cin_real, int Cin_pad, int KK, int Ktot, int accumulate) {
+  const int total = Cout * Cin_real * KK;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int co = e / (Cin_real * KK), rem = e - co * (Cin_real * KK);
+    const int ci = rem / KK, t = rem - ci * KK;
+    const float* p = ws + (size_t)co * Ktot + t * Cin_pad + ci;
+    const size_t slab = (size_t)Cout_pad * Ktot;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += p[sp * slab];
+    dw[e] = accumulate ? dw[e] + s : s;
+  }
+}
+
+// OIHW fp32 master weights -> GEMM operand layouts (T):
+//   wf[n][tap][ci_pad]  (forward "B" operand, n < Cout_pad)      wd[ci][tap][co_pad]  (dgrad "B" operand, ci < Cin_pad)
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin,
+                                    int KK, int Cout_pad, int Cin_pad) {
+  const int nf = Cout_pad * KK * Cin_pad;
+  const int nd = wd ? Cin_pad * KK * Cout_pad : 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nf + nd; e += gridDim.x * blockDim.x) {
+    if (e < nf) {
+      const int n = e / (KK * Cin_pad), rem = e - n * (KK * Cin_pad);
+      const int t = rem / Cin_pad, ci = rem - t * Cin_pad;
+      const float v = (n < Cout && ci < Cin) ? w[((size_t)n * Cin + ci) * KK + t] : 0.f;
+      ET<T>::st(wf + e, v);
+    } else {
+      const int f = e - nf;
+      const int ci = f / (KK * Cout_pad), rem = f - ci * (KK * Cout_pad);
+      const int t = rem / Cout_pad, co = rem - t * Cout_pad;
+      const float v = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * KK + t] : 0.f;
+      ET<T>::st(wd + f, v);
+    }
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc,
+                const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
+                int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
+                int KH, int KW, int stride, int pad, int dil, void* stream) {
+  if (!in || !w_packed || !out) return MDCV_EARG;
+  if ((Cin & 7) || (Nout & 7) || (in_ldc & 7) || (out_ldc & 7) || (addsrc && (add_ldc & 7))) return MDCV_EARG;
+  if (stride != 1 && stride != 2) return MDCV_EARG;
+  if (mode != 0 && mode != 1) return MDCV_EARG;
+  ConvArgs a;
+  a.in = in; a.w = w_packed; a.out = out; a.bias = bias; a.addsrc = addsrc; a.stats = stats_partial;
+  a.in_ldc = in_ldc; a.out_ldc = out_ldc; a.add_ldc = add_ldc;
+  a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Nout = Nout;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;
+  a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin; a.tiles_n = 0; a.sshift = stride == 2 ? 1 : 0;
+  if (a.M <= 0) return MDCV_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16) return mode == 0 ? dispatch_conv<bf16_t, 0>(a, st) : dispatch_conv<bf16_t, 1>(a, st);
+  if (dtype == MDCV_F32) return mode == 0 ? dispatch_conv<float, 0>(a, st) : dispatch_conv<float, 1>(a, st);
+  return MDCV_EARG;
+}
+
+// number of rows of the [tiles_m][2][Nout] BatchNorm partial-statistics buffer mdcv_conv2d writes
+int mdcv_conv2d_stats_rows(int M) { return cdiv(M, 128); }
+
+// choose the pixel split of the weight-gradient kernel; returns the number of fp32 slabs
+int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot) {
+  const int bp = dtype == MDCV_BF16 ? 32 : 16;
+  const int tiles = cdiv(Cout, 128) * cdiv(Ktot, 128);
+  int s = cdiv(768, tiles);
+  const int max_s = cdiv(M, bp * 8);
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  int pps = cdiv(cdiv(M, s), bp) * bp;
+  return cdiv(M, pps);
+}
+
+int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits,
+                      float* dw_oihw, int accumulate, int B, int Hin, int Win, int Cin, int Cin_real,
+                      int Hout, int Wout, int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream) {
+  if (!dy || !x || !ws || !dw_oihw) return MDCV_EARG;
+  if ((Cin & 7) || (Cout & 7) || (dy_ldc & 7) || (x_ldc & 7) || splits < 1) return MDCV_EARG;
+  WgradArgs a;
+  a.dy = dy; a.x = x; a.ws = ws; a.dy_ldc = dy_ldc; a.x_ldc = x_ldc;
+  a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;
+  a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin;
+  const int bp = dtype == MDCV_BF16 ? 32 : 16;
+  a.pix_per_split = cdiv(cdiv(a.M, splits), bp) * bp;
+  if (cdiv(a.M, a.pix_per_split) != splits) return MDCV_EARG;
+  a.tiles_k = cdiv(a.Ktot, 128);
+  a.tiles_ck = a.tiles_k * cdiv(Cout, 128);
+  hipStream_t st = (hipStream_t)stream;
+  const int lds = 128 * 132 * 4;   // fp32 staging (67584 B) > pipeline (40960 B)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e1 != hipSuccess) return (int)e1;
+    if (e2 != hipSuccess) return (int)e2;
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)(a.tiles_ck * splits);
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3(grid), dim3(256), lds, st, a);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  const int KK = KH * KW;
+  const int total = Cout_real * Cin_real * KK;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)min(cdiv(total, 256), 4096)), dim3(256), 0, st, ws, dw_oihw, splits, Cout,
+                     Cout_real, Cin_real, Cin, KK, a.Ktot, accumulate);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,
+                      int Cout_pad, int Cin_pad, void* stream) {
+  if (!w_oihw || !w_fwd) return MDCV_EARG;
+  const int KK = KH * KW;
+  const long long n = (long long)Cout_pad * KK * Cin_pad * (w_dgrad ? 2 : 1);
+  const unsigned grid = (unsigned)min(cdiv(n, 256), 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16)
+    hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w_oihw, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, Cout, Cin, KK, Cout_pad, Cin_pad);
+  else if (dtype == MDCV_F32)
+    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, st, w_oihw, (float*)w_fwd, (float*)w_dgrad, Cout, Cin, KK, Cout_pad, Cin_pad);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,558 @@
+// HBM-bound NHWC elementwise / per-channel-reduction kernels for gfx950.
+//
+// Replaces nn.BatchNorm2d (train + eval), nn.LeakyReLU / nn.ReLU, the shortcut add, nn.Upsample(nearest) and
+// their autograd backward on the reference hot path (CVC-YOLOv3/models.py:66-71,86-88,325-327;
+// RektNet/resnet.py:22-27, keypoint_net.py:59).
+//
+// All kernels are "strip" kernels: a block owns a contiguous strip of pixels, a thread owns one 16-byte channel
+// vector (8 bf16 / 4 fp32) and walks down the strip, so every access is a coalesced 16-byte load/store and per-channel
+// reductions stay in registers until one LDS fold + one fp64 atomic per channel per block.
+#include "common.h"
+
+namespace {
+
+struct Strip {
+  int CV, PPI, PB;   // vectors per pixel, pixels per block-iteration, pixels per block
+};
+template <typename T> static Strip make_strip(int M, int C, int target_blocks) {
+  Strip s;
+  s.CV = C / ET<T>::VEC;
+  s.PPI = 256 / s.CV; if (s.PPI < 1) s.PPI = 1;
+  long long pb = ((long long)M + target_blocks - 1) / target_blocks;
+  pb = ((pb + s.PPI - 1) / s.PPI) * s.PPI;
+  if (pb < s.PPI) pb = s.PPI;
+  s.PB = (int)pb;
+  return s;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act, float slope) { return act == 0 ? v : (v > 0.f ? v : v * slope); }
+__device__ __forceinline__ float act_grad(float pre, int act, float slope) { return act == 0 ? 1.f : (pre > 0.f ? 1.f : slope); }
+
+// ---------------------------------------------------------------- layout conversion
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int H, int W, int ldc, int Cpad) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = Cpad / VEC;
+  const long long total = (long long)B * H * W * CV;
+  const int HW = H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const long long pix = i / CV;
+    const int b = (int)(pix / HW), hw = (int)(pix - (long long)b * HW);
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = cv * VEC + e;
+      v[e] = c < C ? src[((size_t)b * C + c) * HW + hw] : 0.f;
+    }
+    *reinterpret_cast<uint4*>(dst + (size_t)pix * ldc + cv * VEC) = ET<T>::pack(v);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W, int ldc) {
+  const long long total = (long long)B * C * H * W;
+  const int HW = H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int hw = (int)(i % HW);
+    const long long bc = i / HW;
+    const int c = (int)(bc % C), b = (int)(bc / C);
+    dst[i] = ET<T>::ld(src + ((size_t)b * HW + hw) * ldc + c);
+  }
+}
+
+// ---------------------------------------------------------------- BatchNorm statistics
+// partial[rows][nsums][C] (fp32, from the conv epilogue) -> accum[nsums][C] (fp64)
+__global__ void partial_reduce_kernel(const float* __restrict__ partial, int rows, int nsums, int C, double* __restrict__ accum, int rows_per_block) {
+  const int cols = nsums * C;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    double s = 0.0;
+    for (int r = r0; r < r1; ++r) s += (double)partial[(size_t)r * cols + c];
+    atomicAdd(&accum[c], s);
+  }
+}
+
+// accum[0]=sum, accum[1]=sumsq over `count` samples per channel -> batch mean / biased var -> scale, shift ; running stats
+__global__ void bn_finalize_kernel(double* __restrict__ accum, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double s = accum[c], q = accum[C + c];
+  accum[c] = 0.0; accum[C + c] = 0.0;                 // ready for the next step
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma[c], b = beta[c];
+  scale[c] = g * invstd;
+  shift[c] = b - (float)mean * g * invstd;
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                      const float* __restrict__ rv, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(rv[c] + eps);
+  scale[c] = gamma[c] * is;
+  shift[c] = beta[c] - rm[c] * gamma[c] * is;
+}
+
+// ---------------------------------------------------------------- fused BN-apply + activation (+ second BN branch) (+ residual)
+struct BnActArgs {
+  const void* y1; const void* y2; const void* resid; void* out;
+  const float* s1; const float* b1; const float* s2; const float* b2;
+  int ld1, ld2, ldr, ldo, M, C, act, PB, CV, PPI;
+  float slope;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs a) {
+  constexpr int VEC = ET<T>::VEC;
+  const int tid = threadIdx.x;
+  if (tid >= a.PPI * a.CV) return;
+  const int cv = tid % a.CV, pi = tid / a.CV;
+  float s1[VEC], b1[VEC], s2[VEC], b2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const int c = cv * VEC + e;
+    s1[e] = a.s1 ? a.s1[c] : 1.f; b1[e] = a.s1 ? a.b1[c] : 0.f;
+    s2[e] = a.y2 ? a.s2[c] : 0.f; b2[e] = a.y2 ? a.b2[c] : 0.f;
+  }
+  const long long p0 = (long long)blockIdx.x * a.PB;
+  const long long p1 = min((long long)a.M, p0 + a.PB);
+  const T* y1 = reinterpret_cast<const T*>(a.y1);
+  const T* y2 = reinterpret_cast<const T*>(a.y2);
+  const T* rs = reinterpret_cast<const T*>(a.resid);
+  T* out = reinterpret_cast<T*>(a.out);
+  for (long long p = p0 + pi; p < p1; p += a.PPI) {
+    float v[VEC], w[VEC];
+    ET<T>::unpack(*reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC), v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = v[e] * s1[e] + b1[e];
+    if (y2) {
+      ET<T>::unpack(*reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC), w);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] += w[e] * s2[e] + b2[e];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = act_fwd(v[e], a.act, a.slope);
+    if (rs) {
+      ET<T>::unpack(*reinterpret_cast<const uint4*>(rs + p * a.ldr + cv * VEC), w);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] += w[e];
+    }
+    *reinterpret_cast<uint4*>(out + p * a.ldo + cv * VEC) = ET<T>::pack(v);
+  }
+}
+
+// backward, pass 1: g = dout * act'(pre);  accum += [sum g, sum g*xhat1, (sum g*xhat2)]   (fp64 atomics, one per channel per block)
+struct BnBwdArgs {
+  const void* dout; const void* y1; const void* y2; void* dy1; void* dy2;
+  const float* s1; const float* b1; const float* m1; const float* is1;
+  const float* s2; const float* b2; const float* m2; const float* is2;
+  const float* cA1; const float* cB1; const float* cC1; const float* cA2; const float* cB2; const float* cC2;
+  double* accum;
+  int ldd, ld1, ld2, ldy1, ldy2, M, C, act, PB, CV, PPI;
+  float slope;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdArgs a) {
+  constexpr int VEC = ET<T>::VEC;
+  __shared__ float red[256 * 12];
+  const int tid = threadIdx.x;
+  const bool active = tid < a.PPI * a.CV;
+  const int cv = active ? tid % a.CV : 0, pi = active ? tid / a.CV : 0;
+  const int nsum = a.y2 ? 3 : 2;
+  float s1[VEC], b1[VEC], m1[VEC], i1[VEC], s2[VEC], b2[VEC], m2[VEC], i2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const int c = cv * VEC + e;
+    s1[e] = a.s1[c]; b1[e] = a.b1[c]; m1[e] = a.m1[c]; i1[e] = a.is1[c];
+    s2[e] = a.y2 ? a.s2[c] : 0.f; b2[e] = a.y2 ? a.b2[c] : 0.f; m2[e] = a.y2 ? a.m2[c] : 0.f; i2[e] = a.y2 ? a.is2[c] : 0.f;
+  }
+  float sg[VEC], sx1[VEC], sx2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { sg[e] = 0.f; sx1[e] = 0.f; sx2[e] = 0.f; }
+  const long long p0 = (long long)blockIdx.x * a.PB;
+  const long long p1 = min((long long)a.M, p0 + a.PB);
+  const T* dout = reinterpret_cast<const T*>(a.dout);
+  const T* y1 = reinterpret_cast<const T*>(a.y1);
+  const T* y2 = reinterpret_cast<const T*>(a.y2);
+  if (active)
+    for (long long p = p0 + pi; p < p1; p += a.PPI) {
+      float d[VEC], v[VEC], w[VEC];
+      ET<T>::unpack(*reinterpret_cast<const uint4*>(dout + p * a.ldd + cv * VEC), d);
+      ET<T>::unpack(*reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC), v);
+      if (y2) ET<T>::unpack(*reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC), w);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float pre = v[e] * s1[e] + b1[e];
+        if (y2) pre += w[e] * s2[e] + b2[e];
+        const float g = d[e] * act_grad(pre, a.act, a.slope);
+        sg[e] += g;
+        sx1[e] += g * (v[e] - m1[e]) * i1[e];
+        if (y2) sx2[e] += g * (w[e] - m2[e]) * i2[e];
+      }
+    }
+  // fold the PPI pixel-lanes that share a channel vector
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    red[tid * 12 + e] = sg[e];
+    if (VEC == 4) { red[tid * 12 + 4 + e] = sx1[e]; red[tid * 12 + 8 + e] = sx2[e]; }
+  }
+  __syncthreads();
+  if (VEC == 4) {
+    if (active && pi == 0) {
+      for (int k = 0; k < nsum; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float s = 0.f;
+          for (int q = 0; q < a.PPI; ++q) s += red[(q * a.CV + cv) * 12 + k * 4 + e];
+          atomicAdd(&a.accum[(size_t)k * a.C + cv * VEC + e], (double)s);
+        }
+    }
+  } else {
+    // VEC == 8: three rounds through the 12-float slots (8 used)
+    for (int k = 0; k < nsum; ++k) {
+      if (k > 0) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) red[tid * 12 + e] = k == 1 ? sx1[e] : sx2[e];
+        __syncthreads();
+      }
+      if (active && pi == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float s = 0.f;
+          for (int q = 0; q < a.PPI; ++q) s += red[(q * a.CV + cv) * 12 + e];
+          atomicAdd(&a.accum[(size_t)k * a.C + cv * VEC + e], (double)s);
+        }
+      }
+    }
+  }
+}
+
+// backward finalize: accum[0]=sum g, accum[kx]=sum g*xhat  ->  dgamma, dbeta and the per-channel coefficients of
+//    dy = cA*g + cB*y + cC   ( = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) )
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ accum, int kx, int zero_after, double count, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cC,
+                                       int C, int nsums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = accum[c], sgx = accum[(size_t)kx * C + c];
+  if (zero_after) for (int k = 0; k < nsums; ++k) accum[(size_t)k * C + c] = 0.0;
+  dgamma[c] = (float)sgx;
+  dbeta[c] = (float)sg;
+  const double g = gamma[c], is = invstd[c], mu = mean[c];
+  const double mg = sg / count, mgx = sgx / count;
+  cA[c] = (float)(g * is);
+  cB[c] = (float)(-g * is * is * mgx);
+  cC[c] = (float)(-g * is * mg + g * is * is * mu * mgx);
+}
+
+// backward, pass 2: dy_i = cA_i*g + cB_i*y_i + cC_i
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnBwdArgs a) {
+  constexpr int VEC = ET<T>::VEC;
+  const int tid = threadIdx.x;
+  if (tid >= a.PPI * a.CV) return;
+  const int cv = tid % a.CV, pi = tid / a.CV;
+  float s1[VEC], b1[VEC], s2[VEC], b2[VEC], A1[VEC], B1[VEC], C1[VEC], A2[VEC], B2[VEC], C2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const int c = cv * VEC + e;
+    s1[e] = a.s1[c]; b1[e] = a.b1[c]; A1[e] = a.cA1[c]; B1[e] = a.cB1[c]; C1[e] = a.cC1[c];
+    s2[e] = a.y2 ? a.s2[c] : 0.f; b2[e] = a.y2 ? a.b2[c] : 0.f;
+    A2[e] = a.y2 ? a.cA2[c] : 0.f; B2[e] = a.y2 ? a.cB2[c] : 0.f; C2[e] = a.y2 ? a.cC2[c] : 0.f;
+  }
+  const long long p0 = (long long)blockIdx.x * a.PB;
+  const long long p1 = min((long long)a.M, p0 + a.PB);
+  const T* dout = reinterpret_cast<const T*>(a.dout);
+  const T* y1 = reinterpret_cast<const T*>(a.y1);
+  const T* y2 = reinterpret_cast<const T*>(a.y2);
+  T* dy1 = reinterpret_cast<T*>(a.dy1);
+  T* dy2 = reinterpret_cast<T*>(a.dy2);
+  for (long long p = p0 + pi; p < p1; p += a.PPI) {
+    float d[VEC], v[VEC], w[VEC], o1[VEC], o2[VEC];
+    ET<T>::unpack(*reinterpret_cast<const uint4*>(dout + p * a.ldd + cv * VEC), d);
+    ET<T>::unpack(*reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC), v);
+    if (y2) ET<T>::unpack(*reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC), w);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float pre = v[e] * s1[e] + b1[e];
+      if (y2) pre += w[e] * s2[e] + b2[e];
+      const float g = d[e] * act_grad(pre, a.act, a.slope);
+      o1[e] = A1[e] * g + B1[e] * v[e] + C1[e];
+      if (y2) o2[e] = A2[e] * g + B2[e] * w[e] + C2[e];
+    }
+    *reinterpret_cast<uint4*>(dy1 + p * a.ldy1 + cv * VEC) = ET<T>::pack(o1);
+    if (y2) *reinterpret_cast<uint4*>(dy2 + p * a.ldy2 + cv * VEC) = ET<T>::pack(o2);
+  }
+}
+
+// ---------------------------------------------------------------- per-channel column sum (bias gradients of BN-less convs)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ldc, int M, int C, double* __restrict__ accum, int PB, int CV, int PPI) {
+  constexpr int VEC = ET<T>::VEC;
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const bool active = tid < PPI * CV;
+  const int cv = active ? tid % CV : 0, pi = active ? tid / CV : 0;
+  float s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+  const long long p0 = (long long)blockIdx.x * PB, p1 = min((long long)M, p0 + PB);
+  if (active)
+    for (long long p = p0 + pi; p < p1; p += PPI) {
+      float v[VEC];
+      ET<T>::unpack(*reinterpret_cast<const uint4*>(x + p * ldc + cv * VEC), v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s[e] += v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[tid * 8 + e] = s[e];
+  __syncthreads();
+  if (active && pi == 0) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float t = 0.f;
+      for (int q = 0; q < PPI; ++q) t += red[(q * CV + cv) * 8 + e];
+      atomicAdd(&accum[cv * VEC + e], (double)t);
+    }
+  }
+}
+__global__ void accum_to_f32_kernel(double* __restrict__ accum, float* __restrict__ out, int n, int zero_after) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = (float)accum[i];
+  if (zero_after) accum[i] = 0.0;
+}
+
+// ---------------------------------------------------------------- nearest x2 upsample
+template <typename T>
+__global__ void upsample2x_fwd_kernel(const T* __restrict__ in, int ldi, T* __restrict__ out, int ldo, int B, int H, int W, int C) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = C / VEC;
+  const long long total = (long long)B * H * W * 4 * CV;       // one thread per OUTPUT vector
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const long long op = i / CV;
+    const int W2 = 2 * W, H2 = 2 * H;
+    const int ow = (int)(op % W2);
+    const long long t = op / W2;
+    const int oh = (int)(t % H2), b = (int)(t / H2);
+    const long long ip = ((long long)b * H + (oh >> 1)) * W + (ow >> 1);
+    *reinterpret_cast<uint4*>(out + op * ldo + cv * VEC) = *reinterpret_cast<const uint4*>(in + ip * ldi + cv * VEC);
+  }
+}
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ dout, int ldo, T* __restrict__ din, int ldi, int B, int H, int W, int C) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = C / VEC;
+  const long long total = (long long)B * H * W * CV;           // one thread per INPUT vector: sum of its 2x2 outputs
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const long long ip = i / CV;
+    const int w = (int)(ip % W);
+    const long long t = ip / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const long long op = ((long long)b * 2 * H + 2 * h + dy) * 2 * W + 2 * w + dx;
+        float v[VEC];
+        ET<T>::unpack(*reinterpret_cast<const uint4*>(dout + op * ldo + cv * VEC), v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] += v[e];
+      }
+    *reinterpret_cast<uint4*>(din + ip * ldi + cv * VEC) = ET<T>::pack(s);
+  }
+}
+
+static unsigned ew_grid(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdcv_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int ldc, int Cpad, void* stream) {
+  if (!src || !dst || (Cpad & 7) || (ldc & 7) || Cpad < C) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(ew_grid((long long)B * H * W * Cpad / 8)), dim3(256), 0, st, src, (bf16_t*)dst, B, C, H, W, ldc, Cpad);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_grid((long long)B * H * W * Cpad / 4)), dim3(256), 0, st, src, (float*)dst, B, C, H, W, ldc, Cpad);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_nhwc_to_nchw(int dtype, const void* src, int ldc, float* dst, int B, int C, int H, int W, void* stream) {
+  if (!src || !dst) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = ew_grid((long long)B * C * H * W);
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)src, dst, B, C, H, W, ldc);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)src, dst, B, C, H, W, ldc);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_partial_reduce(const float* partial, int rows, int nsums, int C, double* accum, void* stream) {
+  if (!partial || !accum || rows < 1) return MDCV_EARG;
+  const int rpb = 64;
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, partial, rows, nsums, C, accum, rpb);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_bn_finalize(double* accum, double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float momentum, float eps, float* scale, float* shift, float* mean, float* invstd, int C, void* stream) {
+  if (!accum || !gamma || !beta || !scale || !shift || !mean || !invstd) return MDCV_EARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, accum, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                        float* scale, float* shift, int C, void* stream) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                     running_var, eps, scale, shift, C);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+// out = act(y1*s1+b1 [+ y2*s2+b2]) [+ resid] ; s1 == NULL means identity on y1 (plain add / copy)
+int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const float* b1, const void* y2, int ld2, const float* s2,
+                    const float* b2, const void* resid, int ldr, void* out, int ldo, int M, int C, int act, float slope, void* stream) {
+  if (!y1 || !out || (C & 7) || (ld1 & 7) || (ldo & 7)) return MDCV_EARG;
+  BnActArgs a;
+  a.y1 = y1; a.y2 = y2; a.resid = resid; a.out = out; a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2;
+  a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr; a.ldo = ldo; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16) {
+    Strip s = make_strip<bf16_t>(M, C, 4096); if (s.CV > 256) return MDCV_EARG;
+    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
+    hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+  } else if (dtype == MDCV_F32) {
+    Strip s = make_strip<float>(M, C, 4096); if (s.CV > 256) return MDCV_EARG;
+    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
+    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+  } else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+// pass 1 of the BN(+act) backward: accum[0] += sum g ; accum[1] += sum g*xhat1 ; accum[2] += sum g*xhat2 (if y2)
+int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,
+                           const float* mean1, const float* invstd1, const void* y2, int ld2, const float* s2, const float* b2,
+                           const float* mean2, const float* invstd2, double* accum, int M, int C, int act, float slope, void* stream) {
+  if (!dout || !y1 || !accum || (C & 7)) return MDCV_EARG;
+  BnBwdArgs a = {};
+  a.dout = dout; a.y1 = y1; a.y2 = y2; a.s1 = s1; a.b1 = b1; a.m1 = mean1; a.is1 = invstd1; a.s2 = s2; a.b2 = b2; a.m2 = mean2; a.is2 = invstd2;
+  a.accum = accum; a.ldd = ldd; a.ld1 = ld1; a.ld2 = ld2; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16) {
+    Strip s = make_strip<bf16_t>(M, C, 1024); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
+    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+  } else if (dtype == MDCV_F32) {
+    Strip s = make_strip<float>(M, C, 1024); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
+    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+  } else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_bn_bwd_finalize(double* accum, int kx, int nsums, int zero_after, double count, const float* gamma, const float* mean,
+                         const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int C, void* stream) {
+  if (!accum || !gamma || !dgamma || !dbeta || !cA || !cB || !cC) return MDCV_EARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, accum, kx, zero_after, count,
+                     gamma, mean, invstd, dgamma, dbeta, cA, cB, cC, C, nsums);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_bn_act_bwd_apply(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,
+                          const float* cA1, const float* cB1, const float* cC1, void* dy1, int ldy1,
+                          const void* y2, int ld2, const float* s2, const float* b2, const float* cA2, const float* cB2,
+                          const float* cC2, void* dy2, int ldy2, int M, int C, int act, float slope, void* stream) {
+  if (!dout || !y1 || !dy1 || (C & 7)) return MDCV_EARG;
+  BnBwdArgs a = {};
+  a.dout = dout; a.y1 = y1; a.y2 = y2; a.dy1 = dy1; a.dy2 = dy2; a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2;
+  a.cA1 = cA1; a.cB1 = cB1; a.cC1 = cC1; a.cA2 = cA2; a.cB2 = cB2; a.cC2 = cC2;
+  a.ldd = ldd; a.ld1 = ld1; a.ld2 = ld2; a.ldy1 = ldy1; a.ldy2 = ldy2; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16) {
+    Strip s = make_strip<bf16_t>(M, C, 4096); if (s.CV > 256) return MDCV_EARG;
+    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+  } else if (dtype == MDCV_F32) {
+    Strip s = make_strip<float>(M, C, 4096); if (s.CV > 256) return MDCV_EARG;
+    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+  } else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_colsum(int dtype, const void* x, int ldc, int M, int C, double* accum, void* stream) {
+  if (!x || !accum || (C & 7)) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16) {
+    Strip s = make_strip<bf16_t>(M, C, 1024); if (s.CV > 256) return MDCV_EARG;
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, (const bf16_t*)x, ldc, M, C, accum, s.PB, s.CV, s.PPI);
+  } else if (dtype == MDCV_F32) {
+    Strip s = make_strip<float>(M, C, 1024); if (s.CV > 256) return MDCV_EARG;
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, (const float*)x, ldc, M, C, accum, s.PB, s.CV, s.PPI);
+  } else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_accum_to_f32(double* accum, float* out, int n, int zero_after, void* stream) {
+  hipLaunchKernelGGL(accum_to_f32_kernel, dim3((unsigned)cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, accum, out, n, zero_after);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_upsample2x_fwd(int dtype, const void* in, int ldi, void* out, int ldo, int B, int H, int W, int C, void* stream) {
+  if (!in || !out || (C & 7)) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL(upsample2x_fwd_kernel<bf16_t>, dim3(ew_grid((long long)B * H * W * 4 * C / 8)), dim3(256), 0, st, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, B, H, W, C);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(ew_grid((long long)B * H * W * 4 * C / 4)), dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, B, H, W, C);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_upsample2x_bwd(int dtype, const void* dout, int ldo, void* din, int ldi, int B, int H, int W, int C, void* stream) {
+  if (!dout || !din || (C & 7)) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(ew_grid((long long)B * H * W * C / 8)), dim3(256), 0, st, (const bf16_t*)dout, ldo, (bf16_t*)din, ldi, B, H, W, C);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(ew_grid((long long)B * H * W * C / 4)), dim3(256), 0, st, (const float*)dout, ldo, (float*)din, ldi, B, H, W, C);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+}  // extern "C"

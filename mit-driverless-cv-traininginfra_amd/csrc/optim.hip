@@ -1,0 +1,108 @@
+// Fused flat-buffer optimizers for gfx950 (HBM-bound: one pass over params / grads / state).
+// Replaces torch.optim.Adam / SGD.step() as called from CVC-YOLOv3/train.py:180-187,72 and RektNet/train_eval.py:263,72
+// (222 / 54 small tensors per step in the reference -> one launch over the flat parameter buffer).
+// Update rules are torch's (Adam: bias-corrected, eps added after sqrt(v_hat); SGD: momentum buffer, dampening 0).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                                   float bc1, float bc2_sqrt, float grad_scale) {
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = G[e] * grad_scale + weight_decay * P[e];
+      M[e] = beta1 * M[e] + (1.f - beta1) * gr;
+      V[e] = beta2 * V[e] + (1.f - beta2) * gr * gr;
+      P[e] -= (lr / bc1) * M[e] / (sqrtf(V[e]) / bc2_sqrt + eps);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  for (long long i = (n4 << 2) + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gr = g[i] * grad_scale + weight_decay * p[i];
+    m[i] = beta1 * m[i] + (1.f - beta1) * gr;
+    v[i] = beta2 * v[i] + (1.f - beta2) * gr * gr;
+    p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long long n, float lr,
+                                                  float momentum, float weight_decay, int first_step, float grad_scale) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float gr = g[i] * grad_scale + weight_decay * p[i];
+    if (momentum != 0.f) {
+      const float b = first_step ? gr : momentum * buf[i] + gr;
+      buf[i] = b;
+      gr = b;
+    }
+    p[i] -= lr * gr;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdcv_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || step < 1) return MDCV_EARG;
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return MDCV_EARG;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  long long g = (n / 4 + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, sqrtf(bc2), grad_scale);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, int step, float lr, float momentum, float weight_decay,
+                  float grad_scale, void* stream) {
+  if (!params || !grads || (momentum != 0.f && !momentum_buf) || step < 1) return MDCV_EARG;
+  long long g = (n + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1;
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, n, lr, momentum, weight_decay,
+                     step == 1 ? 1 : 0, grad_scale);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+// ---- device / runtime helpers (plumbing for the Python host)
+int mdcv_device_info(int* cu_count, int* wave_size, long long* hbm_bytes, char* arch, int arch_len) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return (int)e;
+  hipDeviceProp_t p;
+  e = hipGetDeviceProperties(&p, dev); if (e != hipSuccess) return (int)e;
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (wave_size) *wave_size = p.warpSize;
+  if (hbm_bytes) *hbm_bytes = (long long)p.totalGlobalMem;
+  if (arch && arch_len > 0) { int i = 0; for (; i < arch_len - 1 && p.gcnArchName[i]; ++i) arch[i] = p.gcnArchName[i]; arch[i] = 0; }
+  return MDCV_OK;
+}
+
+// HIP-event timing on a caller stream (bench.py measures kernels on the stream they are launched on)
+int mdcv_event_create(void** ev) { hipEvent_t e; hipError_t r = hipEventCreate(&e); *ev = (void*)e; return (int)r; }
+int mdcv_event_record(void* ev, void* stream) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream); }
+int mdcv_event_sync(void* ev) { return (int)hipEventSynchronize((hipEvent_t)ev); }
+int mdcv_event_elapsed_ms(void* start, void* stop, float* ms) { return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop); }
+int mdcv_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+
+// hipGraph capture of a launch sequence issued through this library on `stream`
+int mdcv_graph_begin(void* stream) { return (int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal); }
+int mdcv_graph_end(void* stream, void** graph_exec) {
+  hipGraph_t g; hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g); if (e != hipSuccess) return (int)e;
+  hipGraphExec_t ge; e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e != hipSuccess) return (int)e;
+  *graph_exec = (void*)ge;
+  return MDCV_OK;
+}
+int mdcv_graph_launch(void* graph_exec, void* stream) { return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream); }
+int mdcv_graph_destroy(void* graph_exec) { return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec); }
+
+}  // extern "C"

@@ -1,0 +1,255 @@
+// RektNet keypoint head + loss as wavefront-reduction kernels for gfx950.
+//
+//   flat softmax over H*W + soft-argmax   <- RektNet/keypoint_net.py:46-56,68-70
+//   CrossRatioLoss forward + backward     <- RektNet/cross_ratio_loss.py:20-63 (backward formulas: SURVEY appendix B)
+//
+// Logits come from the 1x1 head conv as NHWC (channel = keypoint, stride ldc); heat-maps leave as NCHW fp32 because
+// that is what the reference API returns.  The head always computes in fp32.
+#include "common.h"
+
+namespace {
+
+// one block per (image, keypoint): max, exp/sum, normalise, expected x/y
+template <typename T>
+__global__ __launch_bounds__(256) void softargmax_fwd_kernel(const T* __restrict__ logits, int ldc, int K, int H, int W,
+                                                             float* __restrict__ hm, float* __restrict__ pts) {
+  extern __shared__ float sh[];              // H*W exps
+  __shared__ float red[8];
+  const int bk = blockIdx.x, b = bk / K, k = bk - b * K;
+  const int HW = H * W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* src = logits + (size_t)b * HW * ldc + k;
+  float mx = -INFINITY;
+  for (int j = tid; j < HW; j += 256) { const float v = ET<T>::ld(src + (size_t)j * ldc); sh[j] = v; mx = fmaxf(mx, v); }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < HW; j += 256) { const float e = expf(sh[j] - mx); sh[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  const float inv = 1.f / sum;
+  const float stepx = ((W - 1.f) / W) / (W > 1 ? (W - 1.f) : 1.f), stepy = ((H - 1.f) / H) / (H > 1 ? (H - 1.f) : 1.f);   // linspace(0,(n-1)/n,n)
+  float ex = 0.f, ey = 0.f;
+  float* dst = hm + (size_t)bk * HW;
+  for (int j = tid; j < HW; j += 256) {
+    const float p = sh[j] * inv;
+    dst[j] = p;
+    const int yy = j / W, xx = j - yy * W;
+    ex += p * (xx * stepx); ey += p * (yy * stepy);
+  }
+  ex = wave_sum(ex); ey = wave_sum(ey);
+  if (lane == 0) { red[wave] = ex; red[4 + wave] = ey; }
+  __syncthreads();
+  if (tid == 0) {
+    pts[(size_t)bk * 2 + 0] = red[0] + red[1] + red[2] + red[3];     // (x, y) order, keypoint_net.py:56
+    pts[(size_t)bk * 2 + 1] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+// s[b,k] = sum_j p_j * dhm_j   (softmax Jacobian term, only needed when the heat-map itself carries a gradient)
+__global__ __launch_bounds__(256) void softmax_dot_kernel(const float* __restrict__ hm, const float* __restrict__ dhm, int HW, float* __restrict__ s) {
+  __shared__ float red[4];
+  const size_t off = (size_t)blockIdx.x * HW;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < HW; j += 256) acc += hm[off + j] * dhm[off + j];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) s[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// dz[b,j,k] = p * ( gx*(vx_j - xhat) + gy*(vy_j - yhat) + dhm_j - s )   one thread per pixel, all K keypoints -> one NHWC vector store
+template <typename T, int CP>
+__global__ __launch_bounds__(256) void softargmax_bwd_kernel(const float* __restrict__ hm, const float* __restrict__ pts, const float* __restrict__ dpts,
+                                                             const float* __restrict__ dhm, const float* __restrict__ sdot, int B, int K, int H, int W,
+                                                             T* __restrict__ dlogits, int ldd) {
+  const int HW = H * W;
+  const long long total = (long long)B * HW;
+  const float stepx = ((W - 1.f) / W) / (W > 1 ? (W - 1.f) : 1.f), stepy = ((H - 1.f) / H) / (H > 1 ? (H - 1.f) : 1.f);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW), j = (int)(i - (long long)b * HW);
+    const int yy = j / W, xx = j - yy * W;
+    const float vx = xx * stepx, vy = yy * stepy;
+    float o[CP];
+#pragma unroll
+    for (int k = 0; k < CP; ++k) {
+      float g = 0.f;
+      if (k < K) {
+        const size_t bk = (size_t)b * K + k;
+        const float p = hm[bk * HW + j];
+        float t = 0.f;
+        if (dpts) t += dpts[bk * 2] * (vx - pts[bk * 2]) + dpts[bk * 2 + 1] * (vy - pts[bk * 2 + 1]);
+        if (dhm) t += dhm[bk * HW + j] - sdot[bk];
+        g = p * t;
+      }
+      o[k] = g;
+    }
+    T* dst = dlogits + (size_t)i * ldd;
+#pragma unroll
+    for (int v = 0; v < CP / ET<T>::VEC; ++v) *reinterpret_cast<uint4*>(dst + v * ET<T>::VEC) = ET<T>::pack(o + v * ET<T>::VEC);
+  }
+}
+
+// sum (hm - thm)^2 -> acc (fp64) ; dhm = 2 (hm - thm) / B * up
+__global__ __launch_bounds__(256) void hm_l2_kernel(const float* __restrict__ hm, const float* __restrict__ thm, long long n, float scale,
+                                                    const float* __restrict__ gscale, float* __restrict__ dhm, double* __restrict__ acc) {
+  __shared__ double red[4];
+  const float up = gscale ? gscale[0] : 1.f;
+  double s = 0.0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float d = hm[i] - thm[i];
+    s += (double)(d * d);
+    if (dhm) dhm[i] = 2.f * d * scale * up;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+}
+
+// difference vectors d_q = P[a]-P[b] used by the six geometric terms (cross_ratio_loss.py:36-55)
+__constant__ int DQ_A[9] = {5, 3, 1, 6, 4, 2, 2, 4, 6};
+__constant__ int DQ_B[9] = {3, 1, 0, 4, 2, 0, 1, 3, 5};
+//                 q:        0    1    2    3    4    5    6    7    8
+//                          d53  d31  d10  d64  d42  d20  d21  d43  d65
+__constant__ int TERM_U[6] = {1, 2, 3, 4, 7, 8};     // vA: d31.d53  vB: d10.d31  vC: d64.d42  vD: d42.d20  hA: d43.d21  hB: d65.d43
+__constant__ int TERM_V[6] = {0, 1, 4, 5, 6, 7};
+
+// single block: location loss on points + geometric loss, forward value and d/dpts
+//   loss_type: 0 l2_softargmax, 1 l2_heatmap (location part supplied in hm_acc), 2 l1_softargmax
+__global__ __launch_bounds__(256) void cross_ratio_kernel(const float* __restrict__ pts, const float* __restrict__ tpts, int B, int loss_type,
+                                                          int include_geo, float gamma_h, float gamma_v, double* __restrict__ hm_acc,
+                                                          const float* __restrict__ gscale, float* __restrict__ out3, float* __restrict__ dpts) {
+  __shared__ double red[4][19];
+  __shared__ double tot[19];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float up = gscale ? gscale[0] : 1.f, up_geo = gscale ? gscale[1] : 1.f;   // upstream grads of (location, geo) parts
+  double part[19];                                   // 0: location sum ; 1..18: sums of the 9 unit vectors (x,y)
+#pragma unroll
+  for (int k = 0; k < 19; ++k) part[k] = 0.0;
+  for (int i = tid; i < B; i += 256) {
+    const float* P = pts + (size_t)i * 14;
+    const float* Tg = tpts + (size_t)i * 14;
+    if (loss_type != 1) {
+      float s = 0.f;
+      for (int c = 0; c < 14; ++c) { const float d = P[c] - Tg[c]; s += loss_type == 0 ? d * d : fabsf(d); }
+      part[0] += (double)s;
+    }
+    if (include_geo) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const float dx = P[2 * DQ_A[q]] - P[2 * DQ_B[q]], dy = P[2 * DQ_A[q] + 1] - P[2 * DQ_B[q] + 1];
+        const float nrm = fmaxf(sqrtf(dx * dx + dy * dy), 1e-12f);       // F.normalize eps
+        part[1 + 2 * q] += (double)(dx / nrm); part[2 + 2 * q] += (double)(dy / nrm);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 19; ++k) { const double s = wave_sum_d(part[k]); if (lane == 0) red[wave][k] = s; }
+  __syncthreads();
+  if (tid < 19) tot[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  __syncthreads();
+  const double invB = 1.0 / (double)B, invB2 = invB * invB;
+  const double wt[6] = {gamma_v / 4.0, gamma_v / 4.0, gamma_v / 4.0, gamma_v / 4.0, gamma_h / 2.0, gamma_h / 2.0};
+  if (tid == 0) {
+    double loc = loss_type == 1 ? hm_acc[0] * invB : tot[0] * invB;
+    if (loss_type == 1) hm_acc[0] = 0.0;
+    double geo = 0.0;
+    if (include_geo)
+      for (int t = 0; t < 6; ++t) {
+        const int u = TERM_U[t], v = TERM_V[t];
+        const double dot = tot[1 + 2 * u] * tot[1 + 2 * v] + tot[2 + 2 * u] * tot[2 + 2 * v];
+        geo += wt[t] * (1.0 - dot * invB2);            // mean over the [B,B] all-pairs matrix of 1 - u_i.v_j
+      }
+    out3[0] = (float)loc; out3[1] = (float)geo; out3[2] = (float)(loc + geo);
+  }
+  if (!dpts) return;
+  for (int i = tid; i < B; i += 256) {
+    const float* P = pts + (size_t)i * 14;
+    const float* Tg = tpts + (size_t)i * 14;
+    float g[14];
+    for (int c = 0; c < 14; ++c) {
+      const float d = P[c] - Tg[c];
+      g[c] = up * (loss_type == 0 ? 2.f * d * (float)invB : (loss_type == 2 ? ((d > 0.f) - (d < 0.f)) * (float)invB : 0.f));
+    }
+    if (include_geo) {
+      float G[9][2];
+      for (int q = 0; q < 9; ++q) { G[q][0] = 0.f; G[q][1] = 0.f; }
+      for (int t = 0; t < 6; ++t) {
+        const int u = TERM_U[t], v = TERM_V[t];
+        const float w = (float)(wt[t] * invB2);
+        G[u][0] -= w * (float)tot[1 + 2 * v]; G[u][1] -= w * (float)tot[2 + 2 * v];
+        G[v][0] -= w * (float)tot[1 + 2 * u]; G[v][1] -= w * (float)tot[2 + 2 * u];
+      }
+      for (int q = 0; q < 9; ++q) {
+        const int pa = DQ_A[q], pb = DQ_B[q];
+        const float dx = P[2 * pa] - P[2 * pb], dy = P[2 * pa + 1] - P[2 * pb + 1];
+        const float nrm = fmaxf(sqrtf(dx * dx + dy * dy), 1e-12f);
+        const float ux = dx / nrm, uy = dy / nrm;
+        const float ug = ux * G[q][0] + uy * G[q][1];
+        const float ddx = (G[q][0] - ux * ug) / nrm, ddy = (G[q][1] - uy * ug) / nrm;
+        g[2 * pa] += up_geo * ddx; g[2 * pa + 1] += up_geo * ddy; g[2 * pb] -= up_geo * ddx; g[2 * pb + 1] -= up_geo * ddy;
+      }
+    }
+    for (int c = 0; c < 14; ++c) dpts[(size_t)i * 14 + c] = g[c];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdcv_softargmax_fwd(int dtype, const void* logits, int ldc, int B, int K, int H, int W, float* hm, float* pts, void* stream) {
+  if (!logits || !hm || !pts || H * W * 4 > 64 * 1024) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned lds = (unsigned)(H * W * 4);
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL(softargmax_fwd_kernel<bf16_t>, dim3((unsigned)(B * K)), dim3(256), lds, st, (const bf16_t*)logits, ldc, K, H, W, hm, pts);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL(softargmax_fwd_kernel<float>, dim3((unsigned)(B * K)), dim3(256), lds, st, (const float*)logits, ldc, K, H, W, hm, pts);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+// dlogits (NHWC, 8 channels: K real + zero pad) from d pts and/or d heat-map ; sdot_ws: B*K floats of scratch
+int mdcv_softargmax_bwd(int dtype, const float* hm, const float* pts, const float* dpts, const float* dhm, float* sdot_ws, int B, int K,
+                        int H, int W, void* dlogits, int ldd, void* stream) {
+  if (!hm || !pts || !dlogits || K > 8 || (ldd & 7)) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dhm) {
+    if (!sdot_ws) return MDCV_EARG;
+    hipLaunchKernelGGL(softmax_dot_kernel, dim3((unsigned)(B * K)), dim3(256), 0, st, hm, dhm, H * W, sdot_ws);
+    MDCV_CHECK_LAUNCH();
+  }
+  const unsigned grid = (unsigned)cdiv((long long)B * H * W, 256);
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL((softargmax_bwd_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, hm, pts, dpts, dhm, sdot_ws, B, K, H, W, (bf16_t*)dlogits, ldd);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL((softargmax_bwd_kernel<float, 8>), dim3(grid), dim3(256), 0, st, hm, pts, dpts, dhm, sdot_ws, B, K, H, W, (float*)dlogits, ldd);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+// CrossRatioLoss forward + gradients in one call.  loss_type: 0 l2_softargmax, 1 l2_heatmap, 2 l1_softargmax.
+// out3 = (location, geo, total) ; dpts [B,7,2] ; dhm [B,7,H,W] (l2_heatmap only) ; acc_ws: one zero-initialised double.
+// gscale (device, 2 floats, may be NULL = ones): upstream gradients of the location part and of the geo part.
+int mdcv_cross_ratio_loss(const float* hm, const float* pts, const float* thm, const float* tpts, int B, int H, int W, int loss_type,
+                          int include_geo, float gamma_horz, float gamma_vert, double* acc_ws, const float* gscale, float* out3,
+                          float* dpts, float* dhm, void* stream) {
+  if (!pts || !tpts || !out3 || !acc_ws || loss_type < 0 || loss_type > 2) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (loss_type == 1) {
+    if (!hm || !thm) return MDCV_EARG;
+    const long long n = (long long)B * 7 * H * W;
+    hipLaunchKernelGGL(hm_l2_kernel, dim3((unsigned)min(cdiv(n, 1024), 2048)), dim3(256), 0, st, hm, thm, n, 1.f / (float)B, gscale, dhm, acc_ws);
+    MDCV_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(cross_ratio_kernel, dim3(1), dim3(256), 0, st, pts, tpts, B, loss_type, include_geo, gamma_horz, gamma_vert, acc_ws, gscale, out3, dpts);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+}  // extern "C"

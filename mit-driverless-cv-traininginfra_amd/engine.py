@@ -1,0 +1,325 @@
+"""Static execution plans over libmdcv_hip.so.
+
+A network (Darknet cfg or KeypointNet) is lowered ONCE per (batch shape, mode) into two flat launch lists — forward and
+backward — over statically allocated NHWC buffers in HBM (288 GB per MI355X: nothing is recycled, every activation,
+raw conv output and gradient keeps its own buffer).  Executing a step is a loop over pre-bound C calls on the current
+HIP stream, or one hipGraph replay of the captured list.  PyTorch is used only for device memory and streams.
+
+Gradient routing (fan-out, residual adds, route-concat slices) is resolved at plan-build time:
+  * a tensor whose gradient is just another tensor's gradient (shortcut branch, concat slice) aliases that buffer;
+  * the first computed contribution writes the buffer, later ones accumulate through the conv kernel's `addsrc`
+    epilogue (out = GEMM + addsrc), so residual/fan-out sums cost no extra pass over HBM.
+"""
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, ACT_NONE, ACT_LEAKY, ACT_RELU  # noqa: F401
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def parse_precision(p):
+    if p in (BF16, "bf16", torch.bfloat16):
+        return BF16
+    if p in (F32, "fp32", "f32", torch.float32):
+        return F32
+    raise ValueError(f"precision must be 'bf16' or 'fp32', got {p!r}")
+
+
+class Act:
+    """NHWC activation view: [B,H,W,C] with channel stride ldc inside `buf` (C already padded to a multiple of 8)."""
+    __slots__ = ("buf", "B", "H", "W", "C", "ldc", "off", "ptr")
+
+    def __init__(self, buf, B, H, W, C, ldc, off=0):
+        self.buf, self.B, self.H, self.W, self.C, self.ldc, self.off = buf, B, H, W, C, ldc, off
+        self.ptr = buf.data_ptr() + off * buf.element_size()
+
+    @property
+    def M(self):
+        return self.B * self.H * self.W
+
+    def slice(self, off, C):
+        return Act(self.buf, self.B, self.H, self.W, C, self.ldc, self.off + off)
+
+    def dense(self):
+        """[B,H,W,C] strided torch view (debug / tests)."""
+        return self.buf.view(self.B, self.H, self.W, self.ldc)[..., self.off:self.off + self.C]
+
+
+class TNode:
+    """Activation tensor in the plan + the state of its gradient while the backward list is being built."""
+    __slots__ = ("act", "gstate", "grad", "needs_grad", "name")
+
+    def __init__(self, act, needs_grad=True, name=""):
+        self.act, self.gstate, self.grad, self.needs_grad, self.name = act, "none", None, needs_grad, name
+
+
+class ConvSpec:
+    """One nn.Conv2d: parameters + geometry + packed operand buffers."""
+
+    def __init__(self, plan, weight, bias, stride, pad, dil, cin_pad=None):
+        self.weight, self.bias = weight, bias
+        self.cout, self.cin, self.kh, self.kw = weight.shape
+        self.stride, self.pad, self.dil = stride, pad, dil
+        self.cout_pad = pad8(self.cout)
+        self.cin_pad = cin_pad if cin_pad is not None else pad8(self.cin)
+        self.ktot = self.kh * self.kw * self.cin_pad
+        dt = plan.tdtype
+        self.wf = torch.zeros(self.cout_pad * self.ktot, dtype=dt, device=plan.device)
+        self.wd = None
+        self.bias_pad = None
+        if bias is not None:
+            self.bias_pad = torch.zeros(self.cout_pad, dtype=torch.float32, device=plan.device)
+
+    def out_hw(self, H, W):
+        ek = self.dil * (self.kh - 1) + 1
+        return (H + 2 * self.pad - ek) // self.stride + 1, (W + 2 * self.pad - ek) // self.stride + 1
+
+
+class BnSpec:
+    def __init__(self, plan, bn):
+        self.bn = bn
+        C = bn.num_features
+        self.C = C
+        dev = plan.device
+        z = lambda n=C: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
+        self.scale, self.shift, self.mean, self.invstd = z(), z(), z(), z()
+        self.cA, self.cB, self.cC = z(), z(), z()
+        self.accum = torch.zeros(3 * C, dtype=torch.float64, device=dev)
+
+
+class Plan:
+    def __init__(self, device, precision, training, grad_sink=None):
+        _lib.require_gpu()
+        self.L = _lib.lib()
+        self.device = device
+        self.dtype = parse_precision(precision)
+        self.tdtype = torch.bfloat16 if self.dtype == BF16 else torch.float32
+        self.training = training
+        self.fwd, self.bwd = [], []
+        self.keep = []                 # keeps every buffer alive
+        self.grad_of = {}              # id(param) -> fp32 gradient tensor the backward list writes
+        self.grad_sink = grad_sink     # callable(param) -> preallocated grad tensor (flat buffer view) or None
+        self.ws_floats = 0             # shared wgrad slab scratch (max over layers)
+        self._ws = None
+        self.bytes = 0
+        self.graph_fwd = self.graph_bwd = None
+
+    # ------------------------------------------------------------------ buffers
+    def new_act(self, B, H, W, C, zero=False):
+        Cp = pad8(C)
+        buf = (torch.zeros if zero else torch.empty)(B * H * W * Cp, dtype=self.tdtype, device=self.device)
+        self.keep.append(buf)
+        self.bytes += buf.numel() * buf.element_size()
+        return Act(buf, B, H, W, Cp, Cp)
+
+    def f32(self, n, zero=True):
+        t = (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def param_grad(self, p):
+        g = self.grad_of.get(id(p))
+        if g is None:
+            g = self.grad_sink(p) if self.grad_sink else None
+            if g is None:
+                g = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+            self.grad_of[id(p)] = g
+        return g
+
+    def wgrad_ws(self):
+        if self._ws is None or self._ws.numel() < self.ws_floats:
+            self._ws = torch.empty(max(self.ws_floats, 1), dtype=torch.float32, device=self.device)
+        return self._ws
+
+    # ------------------------------------------------------------------ launch lists
+    def call(self, lst, fn, *args):
+        lst.append((fn, args))
+
+    def run(self, lst, stream=None):
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        for fn, args in lst:
+            rc = fn(*args, stream)
+            if rc:
+                raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
+
+    # ------------------------------------------------------------------ gradient routing
+    def grad_target(self, t):
+        """Buffer a COMPUTED contribution to d(t) must write, plus the tensor it must add (None, alias or itself)."""
+        if t.gstate == "none":
+            t.grad = self._alloc_like(t.act)
+            t.gstate = "own"
+            return t.grad, None
+        if t.gstate == "alias":
+            src = t.grad
+            t.grad = self._alloc_like(t.act)
+            t.gstate = "own"
+            return t.grad, src
+        return t.grad, t.grad
+
+    def grad_identity(self, t, src):
+        """d(t) += src where src is an existing gradient buffer (shortcut branch / concat slice)."""
+        if not t.needs_grad:
+            return
+        if t.gstate == "none":
+            t.grad, t.gstate = src, "alias"
+            return
+        if t.gstate == "alias":
+            a = t.grad
+            t.grad = self._alloc_like(t.act)
+            t.gstate = "own"
+        else:
+            a = t.grad
+        o = t.grad
+        self.call(self.bwd, self.L.bn_act_fwd, self.dtype, a.ptr, a.ldc, None, None, None, 0, None, None, src.ptr, src.ldc,
+                  o.ptr, o.ldc, o.M, o.C, ACT_NONE, 0.0)
+
+    def _alloc_like(self, a):
+        return self.new_act(a.B, a.H, a.W, a.C)
+
+    # ------------------------------------------------------------------ op emitters
+    def emit_input(self, B, C, H, W):
+        """NCHW fp32 user tensor -> NHWC T (channels zero-padded to 8).  Returns (TNode, setter)."""
+        a = self.new_act(B, H, W, C)
+        node = TNode(a, needs_grad=False, name="input")
+        holder = {"src": None}
+        L, dt = self.L, self.dtype
+
+        def convert(stream):
+            x = holder["src"]
+            return L.nchw_to_nhwc(dt, x.data_ptr(), a.ptr, B, C, H, W, a.ldc, a.C, stream)
+        convert.__name__ = "nchw_to_nhwc"
+        self.fwd.append((convert, ()))
+        return node, holder
+
+    def emit_pack(self, cs, need_dgrad):
+        L = self.L
+        if need_dgrad and cs.wd is None:
+            cs.wd = torch.zeros(cs.cin_pad * cs.kh * cs.kw * cs.cout_pad, dtype=self.tdtype, device=self.device)
+        self.call(self.fwd, L.pack_weights, self.dtype, cs.weight.data_ptr(), cs.wf.data_ptr(),
+                  cs.wd.data_ptr() if cs.wd is not None else None, cs.cout, cs.cin, cs.kh, cs.kw, cs.cout_pad, cs.cin_pad)
+        if cs.bias is not None:
+            bp, b = cs.bias_pad, cs.bias
+
+            def copy_bias(stream, bp=bp, b=b, n=cs.cout):
+                bp[:n].copy_(b.detach().reshape(-1), non_blocking=True)
+                return 0
+            copy_bias.__name__ = "copy_bias"
+            self.fwd.append((copy_bias, ()))
+
+    def emit_conv_fwd(self, cs, x, y, stats_partial=None):
+        """x, y: Act.  y.C == cs.cout_pad."""
+        assert x.C == cs.cin_pad and y.C == cs.cout_pad, (x.C, cs.cin_pad, y.C, cs.cout_pad)
+        self.call(self.fwd, self.L.conv2d, self.dtype, 0, x.ptr, x.ldc, cs.wf.data_ptr(), y.ptr, y.ldc,
+                  cs.bias_pad.data_ptr() if cs.bias_pad is not None else None, None, 0,
+                  stats_partial.data_ptr() if stats_partial is not None else None,
+                  x.B, x.H, x.W, cs.cin_pad, y.H, y.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
+
+    def emit_conv_bwd(self, cs, xnode, y_shape_act, dy):
+        """dy: Act gradient of the raw conv output.  Emits wgrad (+bias grad) and, if the input needs it, dgrad."""
+        L, dt = self.L, self.dtype
+        x = xnode.act
+        gw = self.param_grad(cs.weight)
+        splits = L.conv2d_wgrad_splits(dt, dy.M, cs.cout_pad, cs.ktot)
+        self.ws_floats = max(self.ws_floats, splits * cs.cout_pad * cs.ktot)
+        plan = self
+
+        def wgrad(stream, cs=cs, x=x, dy=dy, gw=gw, splits=splits):
+            return L.conv2d_wgrad(dt, dy.ptr, dy.ldc, x.ptr, x.ldc, plan.wgrad_ws().data_ptr(), splits, gw.data_ptr(), 0,
+                                  x.B, x.H, x.W, cs.cin_pad, cs.cin, dy.H, dy.W, cs.cout_pad, cs.cout, cs.kh, cs.kw,
+                                  cs.stride, cs.pad, cs.dil, stream)
+        wgrad.__name__ = "conv2d_wgrad"
+        self.bwd.append((wgrad, ()))
+        if xnode.needs_grad:
+            out, add = self.grad_target(xnode)
+            self.call(self.bwd, L.conv2d, dt, 1, dy.ptr, dy.ldc, cs.wd.data_ptr(), out.ptr, out.ldc, None,
+                      add.ptr if add is not None else None, add.ldc if add is not None else 0, None,
+                      x.B, dy.H, dy.W, cs.cout_pad, x.H, x.W, cs.cin_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
+
+    def emit_bias_grad(self, cs, dy, zero_only=False):
+        gb = self.param_grad(cs.bias)
+        if zero_only:   # bias in front of a BatchNorm: its gradient is identically zero
+            def zero(stream, gb=gb):
+                gb.zero_()
+                return 0
+            zero.__name__ = "zero_bias_grad"
+            self.bwd.append((zero, ()))
+            return
+        acc = torch.zeros(cs.cout_pad, dtype=torch.float64, device=self.device)
+        tmp = self.f32(cs.cout_pad)
+        self.keep.append(acc)
+        self.call(self.bwd, self.L.colsum, self.dtype, dy.ptr, dy.ldc, dy.M, cs.cout_pad, acc.data_ptr())
+        self.call(self.bwd, self.L.accum_to_f32, acc.data_ptr(), tmp.data_ptr(), cs.cout_pad, 1)
+
+        def copy(stream, gb=gb, tmp=tmp, n=cs.cout):
+            gb.copy_(tmp[:n].view_as(gb), non_blocking=True)
+            return 0
+        copy.__name__ = "copy_bias_grad"
+        self.bwd.append((copy, ()))
+
+    def emit_bn_stats(self, bs, y, partial, rows):
+        """conv-epilogue partial sums -> batch statistics -> scale/shift (+ running stats)."""
+        L = self.L
+        bn = bs.bn
+        self.call(self.fwd, L.partial_reduce, partial.data_ptr(), rows, 2, bs.C, bs.accum.data_ptr())
+        self.call(self.fwd, L.bn_finalize, bs.accum.data_ptr(), float(y.M), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                  bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), bs.invstd.data_ptr(), bs.C)
+
+    def emit_bn_eval(self, bs):
+        bn = bs.bn
+        self.call(self.fwd, self.L.bn_eval_coeffs, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                  bn.running_var.data_ptr(), float(bn.eps), bs.scale.data_ptr(), bs.shift.data_ptr(), bs.C)
+
+    def emit_bn_act_fwd(self, y1, bs1, out, act, slope, y2=None, bs2=None, resid=None):
+        self.call(self.fwd, self.L.bn_act_fwd, self.dtype, y1.ptr, y1.ldc, bs1.scale.data_ptr(), bs1.shift.data_ptr(),
+                  y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
+                  bs2.scale.data_ptr() if bs2 is not None else None, bs2.shift.data_ptr() if bs2 is not None else None,
+                  resid.ptr if resid is not None else None, resid.ldc if resid is not None else 0,
+                  out.ptr, out.ldc, out.M, out.C, act, float(slope))
+
+    def emit_bn_act_bwd(self, dout, y1, bs1, act, slope, y2=None, bs2=None):
+        """Returns the gradient(s) of the raw conv output(s): dy1 [, dy2]."""
+        L, dt = self.L, self.dtype
+        dy1 = self._alloc_like(y1)
+        dy2 = self._alloc_like(y2) if y2 is not None else None
+        n = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        self.call(self.bwd, L.bn_act_bwd_reduce, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.mean),
+                  n(bs1.invstd), y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
+                  n(bs2.scale) if bs2 else None, n(bs2.shift) if bs2 else None, n(bs2.mean) if bs2 else None,
+                  n(bs2.invstd) if bs2 else None, bs1.accum.data_ptr(), y1.M, y1.C, act, float(slope))
+        nsums = 3 if y2 is not None else 2
+        g1, b1 = self.param_grad(bs1.bn.weight), self.param_grad(bs1.bn.bias)
+        if y2 is not None:
+            g2, b2 = self.param_grad(bs2.bn.weight), self.param_grad(bs2.bn.bias)
+            self.call(self.bwd, L.bn_bwd_finalize, bs1.accum.data_ptr(), 2, nsums, 0, float(y1.M), bs2.bn.weight.data_ptr(),
+                      n(bs2.mean), n(bs2.invstd), g2.data_ptr(), b2.data_ptr(), n(bs2.cA), n(bs2.cB), n(bs2.cC), bs2.C)
+        self.call(self.bwd, L.bn_bwd_finalize, bs1.accum.data_ptr(), 1, nsums, 1, float(y1.M), bs1.bn.weight.data_ptr(),
+                  n(bs1.mean), n(bs1.invstd), g1.data_ptr(), b1.data_ptr(), n(bs1.cA), n(bs1.cB), n(bs1.cC), bs1.C)
+        self.call(self.bwd, L.bn_act_bwd_apply, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.cA),
+                  n(bs1.cB), n(bs1.cC), dy1.ptr, dy1.ldc,
+                  y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
+                  n(bs2.scale) if bs2 else None, n(bs2.shift) if bs2 else None, n(bs2.cA) if bs2 else None,
+                  n(bs2.cB) if bs2 else None, n(bs2.cC) if bs2 else None,
+                  dy2.ptr if dy2 is not None else None, dy2.ldc if dy2 is not None else 0, y1.M, y1.C, act, float(slope))
+        return (dy1, dy2) if y2 is not None else dy1
+
+    # ------------------------------------------------------------------ hipGraph capture of the launch lists
+    def capture(self, which, stream=None):
+        """Capture a launch list into a hipGraph (all pointers are static by construction)."""
+        L = self.L
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        lst = self.fwd if which == "fwd" else self.bwd
+        import ctypes
+        L.check(L.graph_begin(stream), "graph_begin")
+        try:
+            self.run(lst, stream)
+        finally:
+            ge = ctypes.c_void_p()
+            rc = L.graph_end(stream, ctypes.byref(ge))
+        L.check(rc, "graph_end")
+        return ge

@@ -1,0 +1,211 @@
+"""MI355X-native drop-in for the reference's RektNet/keypoint_net.py (KeypointNet).
+
+`KeypointNet(num_kpt=7, image_size=(80,80), onnx_mode=False, init_weight=True)`; `forward(x)` -> `(hm, pts.view(-1,K,2))`
+(hm = flat softmax over H*W, pts = soft-argmax in (x,y) order) or raw logits when `onnx_mode` — reference
+keypoint_net.py:12-70.  Sub-module names (conv, bn, res1..4.{conv1,bn1,conv2,bn2,shortcut_conv,shortcut_bn}, out) match
+the reference so `load_state_dict` of reference checkpoints works (train_eval.py:95-96, detect.py:36-37).
+
+forward/backward run as one static launch plan of gfx950 kernels (NHWC bf16 or fp32): implicit-GEMM MFMA convs (7x7 stem,
+dilated 3x3, 3x3, 1x1) with BN statistics in the epilogue, fused BN+ReLU, fused dual-BN + add + ReLU at the end of each
+residual block, softmax/soft-argmax wavefront reductions.  The head conv is evaluated once (the reference evaluates it
+twice and discards the first result, keypoint_net.py:64,68 — same values).  No CPU fallback.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..engine import TNode, ConvSpec, BnSpec, parse_precision, ACT_RELU
+from ..yolo.models import _NetPlan, FlatParamsMixin, _bump_counters
+from .resnet import ResNet
+
+
+class _KeypointFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, plan, x, *params):
+        plan.run_forward(x)
+        ctx.model, ctx.plan = model, plan
+        return plan.hm.clone(), plan.pts.clone()
+
+    @staticmethod
+    def backward(ctx, dhm, dpts):
+        model, plan = ctx.model, ctx.plan
+        plan.flags = (dpts is not None, dhm is not None)
+        if dpts is not None:
+            plan.dpts.copy_(dpts)
+        if dhm is not None:
+            plan.dhm_buf().copy_(dhm)
+        model._run_backward(plan, None)
+        return (None, None, None) + (None,) * len(model._plist)
+
+
+class _KpPlan(_NetPlan):
+    flags = (True, False)
+
+    def dhm_buf(self):
+        if self._dhm is None:
+            self._dhm = torch.zeros_like(self.hm)
+        return self._dhm
+
+    def run_backward(self, gout):
+        st = torch.cuda.current_stream().cuda_stream
+        if self.use_graph:
+            g = self.graphs_bwd.get(self.flags)
+            if g is None:
+                self.run(self.bwd, st)
+                self.graphs_bwd[self.flags] = self.capture("bwd", st)
+            else:
+                self.L.check(self.L.graph_launch(g, st), "graph_launch")
+        else:
+            self.run(self.bwd, st)
+
+
+class KeypointNet(nn.Module, FlatParamsMixin):
+    def __init__(self, num_kpt=7, image_size=(80, 80), onnx_mode=False, init_weight=True, precision=None):
+        super().__init__()
+        width = 16
+        self.conv = nn.Conv2d(3, width, kernel_size=7, stride=1, padding=3)
+        self.bn = nn.BatchNorm2d(width)
+        self.relu = nn.ReLU()
+        self.res1 = ResNet(width, width)
+        self.res2 = ResNet(width, width * 2)
+        self.res3 = ResNet(width * 2, width * 4)
+        self.res4 = ResNet(width * 4, width * 8)
+        self.out = nn.Conv2d(width * 8, num_kpt, kernel_size=1, stride=1, padding=0)
+        if init_weight:
+            self._initialize_weights()
+        self.image_size = image_size
+        self.num_kpt = num_kpt
+        self.onnx_mode = onnx_mode
+        self.precision = parse_precision(precision if precision is not None else os.environ.get("MDCV_PRECISION", "bf16"))
+        self.use_graph = os.environ.get("MDCV_GRAPH", "0") == "1"
+        self._plans = {}
+
+    def _initialize_weights(self):
+        """kaiming-normal (fan_out, relu) conv weights, zero biases, BN weight 1 / bias 0 (reference :33-44)."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        _lib.require_gpu(x)
+        if not self._flat_ok():
+            self._flatten()
+        B, _, H, W = x.shape
+        if (H, W) != tuple(self.image_size):
+            raise ValueError(f"KeypointNet was built for image_size={self.image_size}, got {(H, W)}")
+        key = (B, H, W, self.training, self.onnx_mode, self.precision, x.device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._build_plan(x.device, B, H, W, self.training, self.onnx_mode)
+            self._plans[key] = plan
+        if self.onnx_mode:
+            plan.run_forward(x)
+            return plan.logits_nchw.clone()
+        if torch.is_grad_enabled():
+            hm, pts = _KeypointFn.apply(self, plan, x, *self._plist)
+        else:
+            plan.run_forward(x)
+            hm, pts = plan.hm.clone(), plan.pts.clone()
+        return hm, pts.view(-1, self.num_kpt, 2)
+
+    def _build_plan(self, device, B, H, W, bn_train, logits_only):
+        plan = _KpPlan(device, self.precision, bn_train, grad_sink=self._grad_view)
+        plan.use_graph = self.use_graph
+        plan.graphs_bwd = {}
+        plan._dhm = None
+        plan.pre = []
+        L, dt = plan.L, plan.dtype
+        K = self.num_kpt
+        xin, holder = plan.emit_input(B, 3, H, W)
+        plan.pre.append(plan.fwd.pop())
+        plan.in_holder = holder
+        plan.targets = None
+        nbt = []
+        recs = []
+
+        def conv_bn(conv, bn, xnode):
+            cs = ConvSpec(plan, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0], cin_pad=xnode.act.C)
+            plan.emit_pack(cs, need_dgrad=xnode.needs_grad)
+            bs = BnSpec(plan, bn)
+            y = plan.new_act(B, H, W, conv.out_channels)
+            if bn_train:
+                rows = L.conv2d_stats_rows(y.M)
+                partial = plan.f32(rows * 2 * y.C, zero=False)
+                plan.emit_conv_fwd(cs, xnode.act, y, partial)
+                plan.emit_bn_stats(bs, y, partial, rows)
+                nbt.append(bn.num_batches_tracked)
+            else:
+                plan.emit_conv_fwd(cs, xnode.act, y)
+                plan.emit_bn_eval(bs)
+            return cs, bs, y
+
+        cs0, bs0, y0 = conv_bn(self.conv, self.bn, xin)
+        a = TNode(plan.new_act(B, H, W, 16), name="stem")
+        plan.emit_bn_act_fwd(y0, bs0, a.act, ACT_RELU, 0.0)
+        recs.append(("stem", cs0, bs0, xin, y0, a))
+        for blk in (self.res1, self.res2, self.res3, self.res4):
+            x = a
+            cs1, bs1, y1 = conv_bn(blk.conv1, blk.bn1, x)
+            mid = TNode(plan.new_act(B, H, W, blk.conv1.out_channels), name="mid")
+            plan.emit_bn_act_fwd(y1, bs1, mid.act, ACT_RELU, 0.0)
+            cs2, bs2, y2 = conv_bn(blk.conv2, blk.bn2, mid)
+            css, bss, ys = conv_bn(blk.shortcut_conv, blk.shortcut_bn, x)
+            out = TNode(plan.new_act(B, H, W, blk.conv2.out_channels), name="blk")
+            plan.emit_bn_act_fwd(y2, bs2, out.act, ACT_RELU, 0.0, y2=ys, bs2=bss)
+            recs.append(("block", x, cs1, bs1, y1, mid, cs2, bs2, y2, css, bss, ys, out))
+            a = out
+        csh = ConvSpec(plan, self.out.weight, self.out.bias, 1, 0, 1, cin_pad=a.act.C)
+        plan.emit_pack(csh, need_dgrad=True)
+        lg = TNode(plan.new_act(B, H, W, K), name="logits")
+        plan.emit_conv_fwd(csh, a.act, lg.act)
+        if bn_train and nbt:
+            plan.call(plan.fwd, _bump_counters, nbt)
+        if logits_only:
+            plan.logits_nchw = torch.empty(B, K, H, W, dtype=torch.float32, device=device)
+            plan.call(plan.fwd, L.nhwc_to_nchw, dt, lg.act.ptr, lg.act.ldc, plan.logits_nchw.data_ptr(), B, K, H, W)
+            plan.has_bwd = False
+            return plan
+        plan.hm = torch.empty(B, K, H, W, dtype=torch.float32, device=device)
+        plan.pts = torch.empty(B, K, 2, dtype=torch.float32, device=device)
+        plan.dpts = torch.zeros(B, K, 2, dtype=torch.float32, device=device)
+        plan.sdot = torch.zeros(B * K, dtype=torch.float32, device=device)
+        plan.call(plan.fwd, L.softargmax_fwd, dt, lg.act.ptr, lg.act.ldc, B, K, H, W, plan.hm.data_ptr(), plan.pts.data_ptr())
+        plan.has_bwd = True
+
+        # ---------------- backward ----------------
+        dlg, add = plan.grad_target(lg)
+
+        def head_bwd(stream):
+            use_pts, use_hm = plan.flags
+            return L.softargmax_bwd(dt, plan.hm.data_ptr(), plan.pts.data_ptr(), plan.dpts.data_ptr() if use_pts else None,
+                                    plan.dhm_buf().data_ptr() if use_hm else None, plan.sdot.data_ptr(), B, K, H, W, dlg.ptr, dlg.ldc, stream)
+        head_bwd.__name__ = "softargmax_bwd"
+        plan.bwd.append((head_bwd, ()))
+        plan.emit_bias_grad(csh, dlg)
+        plan.emit_conv_bwd(csh, a, lg.act, dlg)
+        for r in reversed(recs):
+            if r[0] == "block":
+                _, x, cs1, bs1, y1, mid, cs2, bs2, y2, css, bss, ys, out = r
+                dy2, dys = plan.emit_bn_act_bwd(out.grad, y2, bs2, ACT_RELU, 0.0, y2=ys, bs2=bss)
+                plan.emit_conv_bwd(cs2, mid, y2, dy2)
+                plan.emit_conv_bwd(css, x, ys, dys)
+                dy1 = plan.emit_bn_act_bwd(mid.grad, y1, bs1, ACT_RELU, 0.0)
+                plan.emit_conv_bwd(cs1, x, y1, dy1)
+                for cs in (cs1, cs2, css):
+                    plan.emit_bias_grad(cs, None, zero_only=True)
+            else:
+                _, cs0, bs0, xin_, y0, a0 = r
+                dy0 = plan.emit_bn_act_bwd(a0.grad, y0, bs0, ACT_RELU, 0.0)
+                plan.emit_conv_bwd(cs0, xin_, y0, dy0)
+                plan.emit_bias_grad(cs0, None, zero_only=True)
+        return plan

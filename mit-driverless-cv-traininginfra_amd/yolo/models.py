@@ -1,0 +1,673 @@
+"""MI355X-native drop-in for the reference's CVC-YOLOv3/models.py (Darknet, YOLOLayer, create_modules).
+
+Same Python surface — `Darknet(config_path, xy_loss, wh_loss, no_object_loss, object_loss, vanilla_anchor)`, the getters,
+`forward(x, targets=None)`, darknet `.weights` load/save, `module_list` / `module_defs` / `hyperparams`, state_dict keys
+(`module_list.<i>.conv_<i>.weight` ...) — so the reference's train.py / validate.py / detect.py call sequence runs
+unchanged (reference: CVC-YOLOv3/models.py:15-422; callers train.py:100-120,182,191,196,208,217).
+
+Underneath, `forward` does not run the nn.Modules: the cfg is lowered once per input shape into a static launch plan
+(engine.Plan) of hand-written gfx950 kernels from libmdcv_hip.so — NHWC bf16 (or fp32 parity mode) implicit-GEMM MFMA
+convolutions with BatchNorm statistics in the epilogue, fused BN-apply+LeakyReLU(+shortcut), zero-copy route concat,
+fused YOLO heads — and the whole backward is one autograd node that runs the mirrored plan.  The nn.Modules only hold the
+fp32 master parameters (OIHW) and BatchNorm buffers.  There is no CPU fallback.
+
+Extra (non-reference) knobs: `precision=` ctor kwarg or env MDCV_PRECISION in {"bf16" (default), "fp32"};
+env MDCV_GRAPH=1 replays the plan through hipGraphs.
+"""
+from __future__ import division
+
+import csv
+import os
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..engine import Plan, TNode, ConvSpec, BnSpec, pad8, parse_precision, ACT_NONE, ACT_LEAKY, ACT_RELU
+from .utils.parse_config import parse_model_config
+
+vanilla_anchor_list = [[10, 13], [16, 30], [33, 23], [30, 61], [62, 45], [59, 119], [116, 90], [156, 198], [373, 326]]
+
+
+def _read_anchor_row(csv_uri):
+    """Row 0 of train.csv holds the k-means anchors as one quoted field 'w,h|w,h|...' (reference models.py:29-35)."""
+    with open(csv_uri) as fh:
+        first = next(csv.reader(fh))
+    text = str(first)[2:-2]
+    return [[float(v) for v in pair.split(",")] for pair in text.split("'")[0].split("|")]
+
+
+class EmptyLayer(nn.Module):
+    """Placeholder module for 'route' and 'shortcut' sections (keeps module_list indices aligned with the cfg)."""
+
+
+def create_modules(module_defs, xy_loss, wh_loss, no_object_loss, object_loss, vanilla_anchor):
+    """cfg sections -> (hyperparams, nn.ModuleList).  Naming / ordering rules follow reference models.py:15-110 so that
+    state_dict keys and `.weights` traversal (`module[0]` conv, `module[1]` BN) stay compatible."""
+    hyper = module_defs.pop(0)
+    channels = [int(hyper["channels"])]
+    img_w, img_h = int(hyper["width"]), int(hyper["height"])
+    n_cls = int(hyper["classes"])
+    slope = float(hyper["leaky_slope"])
+    activation = hyper["conv_activation"]
+    masks = [[int(v) for v in grp.split(",")] for grp in hyper["yolo_masks"].split("|")]
+    anchors_all = _read_anchor_row(hyper["train_uri"])          # opened unconditionally, like the reference (Q11)
+    if vanilla_anchor:
+        anchors_all = vanilla_anchor_list
+    ignore = float(hyper["build_targets_ignore_thresh"])
+
+    mods = nn.ModuleList()
+    head = 0
+    for i, d in enumerate(module_defs):
+        seq = nn.Sequential()
+        kind = d["type"]
+        if kind == "convolutional":
+            is_head = d["filters"] == "preyolo"                   # bias, no BN, linear (models.py:51-54)
+            filters = (n_cls + 5) * len(masks[head]) if is_head else int(d["filters"])
+            k = int(d["size"])
+            seq.add_module("conv_%d" % i, nn.Conv2d(channels[-1], filters, k, int(d["stride"]), (k - 1) // 2, bias=is_head))
+            if not is_head:
+                seq.add_module("batch_norm_%d" % i, nn.BatchNorm2d(filters))
+                if activation == "leaky":
+                    seq.add_module("leaky_%d" % i, nn.LeakyReLU(slope))
+                if activation == "ReLU":
+                    seq.add_module("ReLU_%d" % i, nn.ReLU())
+        elif kind == "maxpool":
+            k, s = int(d["size"]), int(d["stride"])
+            if k == 2 and s == 1:
+                seq.add_module("_debug_padding_%d" % i, nn.ZeroPad2d((0, 1, 0, 1)))
+            seq.add_module("maxpool_%d" % i, nn.MaxPool2d(k, s, (k - 1) // 2))
+            filters = channels[-1]
+        elif kind == "upsample":
+            seq.add_module("upsample_%d" % i, nn.Upsample(scale_factor=int(d["stride"]), mode="nearest"))
+            filters = channels[-1]
+        elif kind == "route":
+            filters = 0
+            for v in (int(t) for t in d["layers"].split(",")):
+                filters += channels[v + 1 if v > 0 else v]          # `channels` has the input in front (models.py:93-96)
+            seq.add_module("route_%d" % i, EmptyLayer())
+        elif kind == "shortcut":
+            filters = channels[int(d["from"])]
+            seq.add_module("shortcut_%d" % i, EmptyLayer())
+        elif kind == "yolo":
+            seq.add_module("yolo_%d" % i, YOLOLayer([anchors_all[v] for v in masks[head]], n_cls, img_h, img_w, ignore, activation,
+                                                    xy_loss, wh_loss, object_loss, no_object_loss))
+            head += 1
+            filters = channels[-1]
+        else:
+            raise ValueError("unknown cfg section [%s]" % kind)
+        mods.append(seq)
+        channels.append(filters)
+    return hyper, mods
+
+
+class _YoloHeadFn(torch.autograd.Function):
+    """Stand-alone YOLOLayer on an NCHW sample: NHWC fp32 staging + the fused head kernels."""
+
+    @staticmethod
+    def forward(ctx, layer, sample, targets):
+        L = _lib.lib()
+        B, ch, Gh, Gw = sample.shape
+        A, C = layer.num_anchors, layer.num_classes
+        dev = sample.device
+        st = torch.cuda.current_stream().cuda_stream
+        cp = pad8(ch)
+        lg = torch.empty(B * Gh * Gw * cp, dtype=torch.float32, device=dev)
+        src = sample.detach().to(torch.float32).contiguous()
+        L.check(L.nchw_to_nhwc(_lib.F32, src.data_ptr(), lg.data_ptr(), B, ch, Gh, Gw, cp, cp, st), "nchw_to_nhwc")
+        tg = targets.detach().to(device=dev, dtype=torch.float32).contiguous()
+        anchors = layer.scaled_anchors(Gh).to(dev)
+        ws = torch.empty(int(L.yolo_head_workspace_bytes(B, A, Gh, Gw)), dtype=torch.uint8, device=dev)
+        out7 = torch.zeros(7, dtype=torch.float32, device=dev)
+        geo = (B, tg.shape[1], A, C, Gh, Gw, float(layer.ignore_thres), float(layer.xy_loss), float(layer.wh_loss),
+               float(layer.object_loss), float(layer.no_object_loss))
+        L.check(L.yolo_head_train(_lib.F32, lg.data_ptr(), cp, None, 0, cp, tg.data_ptr(), anchors.data_ptr(), *geo, ws.data_ptr(),
+                                  out7.data_ptr(), None, st), "yolo_head_train")
+        ctx.saved = (lg, tg, anchors, ws, geo, cp, ch)
+        return out7
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = _lib.lib()
+        lg, tg, anchors, ws, geo, cp, ch = ctx.saved
+        B, Gh, Gw = geo[0], geo[4], geo[5]
+        st = torch.cuda.current_stream().cuda_stream
+        g = gout.contiguous()
+        dl = torch.empty_like(lg)
+        L.check(L.yolo_head_grad(_lib.F32, lg.data_ptr(), cp, dl.data_ptr(), cp, cp, tg.data_ptr(), anchors.data_ptr(), *geo, ws.data_ptr(),
+                                 g.data_ptr(), st), "yolo_head_grad")
+        ds = torch.empty(B, ch, Gh, Gw, dtype=torch.float32, device=lg.device)
+        L.check(L.nhwc_to_nchw(_lib.F32, dl.data_ptr(), cp, ds.data_ptr(), B, ch, Gh, Gw, st), "nhwc_to_nchw")
+        return None, ds, None
+
+
+class YOLOLayer(nn.Module):
+    """Detection head.  ctor argument order as in the reference (note object_loss before no_object_loss, models.py:121).
+    forward(sample, targets) -> (loss, tensor(6 parts: x,y,w,h,obj,noobj)) ; forward(sample) -> [B, A*G*G, 5+C]."""
+
+    def __init__(self, anchors, num_classes, img_height, img_width, build_targets_ignore_thresh, conv_activation, xy_loss, wh_loss,
+                 object_loss, no_object_loss):
+        super().__init__()
+        self.anchors = anchors
+        self.num_anchors = len(anchors)
+        self.num_classes = num_classes
+        self.bbox_attrs = 5 + num_classes
+        self.image_height, self.image_width = img_height, img_width
+        self.ignore_thres = build_targets_ignore_thresh
+        self.xy_loss, self.wh_loss = xy_loss, wh_loss
+        self.no_object_loss, self.object_loss = no_object_loss, object_loss
+        self.conv_activation = conv_activation
+
+    def stride_for(self, grid_h):
+        return self.image_height / grid_h                          # cfg height, used for both axes (models.py:145)
+
+    def scaled_anchors(self, grid_h):
+        s = self.stride_for(grid_h)
+        return torch.tensor([(aw / s, ah / s) for aw, ah in self.anchors], dtype=torch.float32)
+
+    def forward(self, sample, targets=None):
+        _lib.require_gpu(sample)
+        if targets is not None:
+            out7 = _YoloHeadFn.apply(self, sample, targets)
+            return out7[0], out7[1:].detach()
+        L = _lib.lib()
+        B, ch, Gh, Gw = sample.shape
+        st = torch.cuda.current_stream().cuda_stream
+        cp = pad8(ch)
+        lg = torch.empty(B * Gh * Gw * cp, dtype=torch.float32, device=sample.device)
+        src = sample.detach().to(torch.float32).contiguous()
+        L.check(L.nchw_to_nhwc(_lib.F32, src.data_ptr(), lg.data_ptr(), B, ch, Gh, Gw, cp, cp, st), "nchw_to_nhwc")
+        rows = self.num_anchors * Gh * Gw
+        out = torch.empty(B, rows, self.bbox_attrs, dtype=torch.float32, device=sample.device)
+        an = self.scaled_anchors(Gh).to(sample.device)
+        L.check(L.yolo_head_decode(_lib.F32, lg.data_ptr(), cp, an.data_ptr(), float(self.stride_for(Gh)), B, self.num_anchors,
+                                   self.num_classes, Gh, Gw, out.data_ptr(), rows, 0, st), "yolo_head_decode")
+        return out
+
+
+class _DarknetTrainFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward = plan.fwd, backward = plan.bwd."""
+
+    @staticmethod
+    def forward(ctx, model, plan, x, targets, *params):
+        plan.run_forward(x, targets)
+        ctx.model, ctx.plan = model, plan
+        return plan.out7.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        model, plan = ctx.model, ctx.plan
+        model._run_backward(plan, gout)
+        return (None, None, None, None) + (None,) * len(model._plist)
+
+
+class _NetPlan(Plan):
+    """engine.Plan + the per-network I/O buffers and the run_* entry points."""
+
+    def run_forward(self, x, targets=None):
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        self.in_holder["src"] = x
+        if targets is not None:
+            self.targets.copy_(targets.reshape(self.targets.shape), non_blocking=True)
+        st = torch.cuda.current_stream().cuda_stream
+        self.run(self.pre, st)
+        if self.use_graph:
+            if self.graph_fwd is None:
+                self.run(self.fwd, st)                                 # warm run (function attributes, lazy buffers)
+                self.graph_fwd = self.capture("fwd", st)
+            else:
+                self.L.check(self.L.graph_launch(self.graph_fwd, st), "graph_launch")
+        else:
+            self.run(self.fwd, st)
+
+    def run_backward(self, gout):
+        st = torch.cuda.current_stream().cuda_stream
+        self.gscale.copy_(gout.reshape(-1)[:self.gscale.numel()], non_blocking=True)
+        if self.use_graph:
+            if self.graph_bwd is None:
+                self.run(self.bwd, st)
+                self.graph_bwd = self.capture("bwd", st)
+            else:
+                self.L.check(self.L.graph_launch(self.graph_bwd, st), "graph_launch")
+        else:
+            self.run(self.bwd, st)
+
+
+class FlatParamsMixin:
+    """Keeps all parameters (and their gradients) as views of two flat fp32 buffers so the optimizer step and the RCCL
+    gradient all-reduce are single passes over contiguous HBM."""
+
+    def _flatten(self):
+        plist = [p for p in self.parameters()]
+        dev = plist[0].device
+        total = sum(p.numel() for p in plist)
+        pflat = torch.empty(total, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self._goff = {}
+        with torch.no_grad():
+            for p in plist:
+                n = p.numel()
+                pflat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = pflat[off:off + n].view(p.shape)
+                self._goff[id(p)] = (off, n)
+                off += n
+        self._plist, self._pflat, self._gflat = plist, pflat, gflat
+        self._flat_ptrs = [p.data_ptr() for p in plist]
+        self._plans = {}
+
+    def _flat_ok(self):
+        pl = getattr(self, "_plist", None)
+        if pl is None:
+            return False
+        return pl[0].data_ptr() == self._flat_ptrs[0] and pl[-1].data_ptr() == self._flat_ptrs[-1] and \
+            pl[len(pl) // 2].data_ptr() == self._flat_ptrs[len(pl) // 2]
+
+    def _grad_view(self, p):
+        off, n = self._goff[id(p)]
+        return self._gflat[off:off + n].view(p.shape)
+
+    def flat_parameters(self):
+        """(flat fp32 parameter buffer, flat fp32 gradient buffer) — what FusedAdam / the all-reduce operate on."""
+        if not self._flat_ok():
+            self._flatten()
+        return self._pflat, self._gflat
+
+    def _run_backward(self, plan, gout):
+        pl = self._plist
+        keep = None
+        if pl[0].grad is not None:                       # gradients were not reset to None: accumulate semantics
+            keep = self._gflat.clone()
+        plan.run_backward(gout)
+        if keep is not None:
+            self._gflat.add_(keep)
+        for p in pl:
+            v = self._grad_view(p)
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():      # foreign .grad tensor: fold ours in, then re-point
+                v.add_(p.grad)
+                p.grad = v
+
+
+class Darknet(nn.Module, FlatParamsMixin):
+    """YOLOv3 object detection model (reference: CVC-YOLOv3/models.py:222-422)."""
+
+    def __init__(self, config_path, xy_loss, wh_loss, no_object_loss, object_loss, vanilla_anchor, precision=None):
+        super().__init__()
+        self.module_defs = parse_model_config(config_path)
+        self.hyperparams, self.module_list = create_modules(self.module_defs, xy_loss, wh_loss, no_object_loss, object_loss, vanilla_anchor)
+        h = self.hyperparams
+        self.img_width, self.img_height = int(h["width"]), int(h["height"])
+        self.onnx_height = int(h["onnx_height"])
+        self.onnx_name = config_path.split("/")[-1].split(".")[0] + "_" + str(self.img_width) + str(self.onnx_height) + ".onnx"
+        self.num_classes = int(h["classes"])
+        ch = int(h["channels"])
+        if ch not in (1, 3):
+            print("Channels in cfg file is not set properly, making it colour")
+        self.bw = ch == 1
+        self.validate_uri, self.train_uri = h["validate_uri"], h["train_uri"]
+        self.num_train_images, self.num_validate_images = int(h["num_train_images"]), int(h["num_validate_images"])
+        self.conf_thresh, self.nms_thresh, self.iou_thresh = float(h["conf_thresh"]), float(h["nms_thresh"]), float(h["iou_thresh"])
+        self.start_weights_dim = [int(v) for v in h["start_weights_dim"].split(",")]
+        self.conv_activation = h["conv_activation"]
+        self.xy_loss, self.wh_loss, self.no_object_loss, self.object_loss = xy_loss, wh_loss, no_object_loss, object_loss
+        self.anchors = vanilla_anchor_list if vanilla_anchor else _read_anchor_row(h["train_uri"])
+        self.seen = 0
+        self.header_info = np.array([0, 0, 0, self.seen, 0], dtype=np.int32)
+        self._stamp = (datetime.now().strftime("%B").lower(), str(datetime.now().year))
+        self.precision = parse_precision(precision if precision is not None else os.environ.get("MDCV_PRECISION", "bf16"))
+        self.use_graph = os.environ.get("MDCV_GRAPH", "0") == "1"
+        self._plans = {}
+
+    # ---- getters consumed by train.py / validate.py / detect.py (reference models.py:279-310)
+    def get_start_weight_dim(self): return self.start_weights_dim
+    def get_onnx_name(self): return self.onnx_name
+    def get_bw(self): return self.bw
+    def get_loss_constant(self): return [self.xy_loss, self.wh_loss, self.no_object_loss, self.object_loss]
+    def get_conv_activation(self): return self.conv_activation
+    def get_num_classes(self): return self.num_classes
+    def get_anchors(self): return self.anchors
+    def get_threshs(self): return self.conf_thresh, self.nms_thresh, self.iou_thresh
+    def img_size(self): return self.img_width, self.img_height
+    def get_links(self): return self.validate_uri, self.train_uri
+    def num_images(self): return self.num_validate_images, self.num_train_images
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x, targets=None):
+        _lib.require_gpu(x)
+        if not self._flat_ok():
+            self._flatten()
+        B, _, H, W = x.shape
+        T = targets.shape[1] if targets is not None else 0
+        key = (B, H, W, T, targets is not None, self.training, self.precision, x.device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._build_plan(x.device, B, H, W, T, targets is not None, self.training)
+            self._plans[key] = plan
+        if targets is None:
+            plan.run_forward(x)
+            return plan.eval_out.clone()
+        if torch.is_grad_enabled() and plan.has_bwd:
+            out7 = _DarknetTrainFn.apply(self, plan, x, targets, *self._plist)
+        else:
+            plan.run_forward(x, targets)
+            out7 = plan.out7.clone()
+        d = out7.detach()
+        return (out7[0], d[1], d[2], d[3], d[4], d[5], d[6])
+
+    # ------------------------------------------------------------------------------------------ plan
+    def _build_plan(self, device, B, H, W, T, with_targets, bn_train):
+        defs, mods = self.module_defs, self.module_list
+        n = len(defs)
+        plan = _NetPlan(device, self.precision, bn_train, grad_sink=self._grad_view)
+        plan.use_graph = self.use_graph
+        plan.pre = []
+        L, dt = plan.L, plan.dtype
+        cin = int(self.hyperparams["channels"])
+        xin, holder = plan.emit_input(B, cin, H, W)
+        plan.pre.append(plan.fwd.pop())                      # the NCHW->NHWC edge stays outside any captured graph
+        plan.in_holder = holder
+        plan.targets = torch.zeros(B, max(T, 1), 5, dtype=torch.float32, device=device)
+        plan.out7 = torch.zeros(7, dtype=torch.float32, device=device)
+        plan.gscale = torch.ones(1, dtype=torch.float32, device=device)
+        plan.has_bwd = with_targets
+
+        def res(i, v):                                       # cfg layer reference -> absolute module index
+            return i + v if v < 0 else v
+
+        # ---- who consumes what (fusion + concat planning)
+        users = [[] for _ in range(n)]
+        for i, d in enumerate(defs):
+            k = d["type"]
+            if k in ("convolutional", "upsample", "maxpool", "yolo") and i > 0:
+                users[i - 1].append(i)
+            elif k == "route":
+                for v in (int(t) for t in d["layers"].split(",")):
+                    users[res(i, v)].append(i)
+            elif k == "shortcut":
+                users[i - 1].append(i)
+                users[res(i, int(d["from"]))].append(i)
+        # ---- shapes
+        shp = []
+        c, h, w = cin, H, W
+        for i, d in enumerate(defs):
+            k = d["type"]
+            if k == "convolutional":
+                conv = mods[i][0]
+                c = conv.out_channels
+                h = (h + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] + 1
+                w = (w + 2 * conv.padding[1] - conv.kernel_size[1]) // conv.stride[1] + 1
+            elif k == "upsample":
+                h, w = h * int(d["stride"]), w * int(d["stride"])
+            elif k == "maxpool":
+                raise NotImplementedError("maxpool sections (yolo_baseline_tiny.cfg) are not lowered yet (SURVEY §8f-3)")
+            elif k == "route":
+                src = [res(i, int(t)) for t in d["layers"].split(",")]
+                c = sum(shp[s][0] for s in src)
+                h, w = shp[src[0]][1], shp[src[0]][2]
+            elif k == "shortcut":
+                c, h, w = shp[i - 1]
+            shp.append((c, h, w))
+        # ---- concat destinations: a producer writes straight into its slice of the route buffer
+        dest = {}
+        parents = {}
+        for i, d in enumerate(defs):
+            if d["type"] == "route":
+                src = [res(i, int(t)) for t in d["layers"].split(",")]
+                if len(src) > 1:
+                    ctot = sum(pad8(shp[s][0]) for s in src)
+                    par = plan.new_act(B, shp[i][1], shp[i][2], ctot)
+                    parents[i] = par
+                    off = 0
+                    for s in src:
+                        if s not in dest and defs[s]["type"] in ("convolutional", "upsample", "shortcut"):
+                            dest[s] = (par, off)
+                        off += pad8(shp[s][0])
+
+        def out_act(i):
+            c_, h_, w_ = shp[i]
+            if i in dest:
+                par, off = dest[i]
+                return par.slice(off, pad8(c_))
+            return plan.new_act(B, h_, w_, c_)
+
+        plan.call(plan.fwd, _zero_tensor, plan.out7)
+        outs = [None] * n
+        recs = []
+        cur = xin
+        slope = float(self.hyperparams["leaky_slope"])
+        act_code = ACT_LEAKY if self.conv_activation == "leaky" else (ACT_RELU if self.conv_activation == "ReLU" else ACT_NONE)
+        heads = []
+        fused_into = {}
+        rows_total = 0
+        for i, d in enumerate(defs):
+            if d["type"] == "yolo":
+                rows_total += mods[i][0].num_anchors * shp[i][1] * shp[i][2]
+        row_off = 0
+        if not with_targets:
+            plan.eval_out = torch.zeros(B, rows_total, 5 + self.num_classes, dtype=torch.float32, device=device)
+        nbt = []
+        for i, d in enumerate(defs):
+            k = d["type"]
+            if k == "convolutional":
+                conv = mods[i][0]
+                has_bn = d["filters"] != "preyolo"
+                cs = ConvSpec(plan, conv.weight, conv.bias, conv.stride[0], conv.padding[0], 1, cin_pad=cur.act.C)
+                plan.emit_pack(cs, need_dgrad=with_targets and cur.needs_grad)
+                ho, wo = shp[i][1], shp[i][2]
+                if has_bn:
+                    bn = mods[i][1]
+                    bs = BnSpec(plan, bn)
+                    y = plan.new_act(B, ho, wo, conv.out_channels)
+                    fuse = (i + 1 < n and defs[i + 1]["type"] == "shortcut" and users[i] == [i + 1]
+                            and res(i + 1, int(defs[i + 1]["from"])) != i)
+                    if bn_train:
+                        rows = L.conv2d_stats_rows(y.M)
+                        partial = plan.f32(rows * 2 * y.C, zero=False)
+                        plan.emit_conv_fwd(cs, cur.act, y, partial)
+                        plan.emit_bn_stats(bs, y, partial, rows)
+                        nbt.append(bn.num_batches_tracked)
+                    else:
+                        plan.emit_conv_fwd(cs, cur.act, y)
+                        plan.emit_bn_eval(bs)
+                    if fuse:
+                        rnode = outs[res(i + 1, int(defs[i + 1]["from"]))]
+                        z = TNode(out_act(i + 1), name="short%d" % (i + 1))
+                        plan.emit_bn_act_fwd(y, bs, z.act, act_code, slope, resid=rnode.act)
+                        fused_into[i + 1] = z
+                        recs.append(("convbn", cs, bs, cur, y, z, rnode))
+                        outs[i] = None
+                    else:
+                        z = TNode(out_act(i), name="conv%d" % i)
+                        plan.emit_bn_act_fwd(y, bs, z.act, act_code, slope)
+                        recs.append(("convbn", cs, bs, cur, y, z, None))
+                        outs[i] = z
+                    cur = z
+                else:
+                    y = TNode(out_act(i), name="logits%d" % i)
+                    plan.emit_conv_fwd(cs, cur.act, y.act)
+                    recs.append(("convlin", cs, cur, y))
+                    outs[i] = y
+                    cur = y
+            elif k == "shortcut":
+                if i in fused_into:
+                    outs[i] = fused_into[i]
+                else:
+                    a, b = outs[i - 1], outs[res(i, int(d["from"]))]
+                    z = TNode(out_act(i), name="short%d" % i)
+                    plan.call(plan.fwd, L.bn_act_fwd, dt, a.act.ptr, a.act.ldc, None, None, None, 0, None, None, b.act.ptr, b.act.ldc,
+                              z.act.ptr, z.act.ldc, z.act.M, z.act.C, ACT_NONE, 0.0)
+                    recs.append(("shortcut", a, b, z))
+                    outs[i] = z
+                cur = outs[i]
+            elif k == "upsample":
+                if int(d["stride"]) != 2:
+                    raise NotImplementedError("only x2 nearest upsample is lowered")
+                z = TNode(out_act(i), name="up%d" % i)
+                a = cur.act
+                plan.call(plan.fwd, L.upsample2x_fwd, dt, a.ptr, a.ldc, z.act.ptr, z.act.ldc, B, a.H, a.W, a.C)
+                recs.append(("upsample", cur, z))
+                outs[i] = z
+                cur = z
+            elif k == "route":
+                src = [res(i, int(t)) for t in d["layers"].split(",")]
+                if len(src) == 1:
+                    outs[i] = outs[src[0]]
+                else:
+                    par = parents[i]
+                    z = TNode(par, name="route%d" % i)
+                    off = 0
+                    parts = []
+                    for s in src:
+                        sn = outs[s]
+                        sl = par.slice(off, sn.act.C)
+                        inplace = dest.get(s, (None, None))[0] is par and sn.act.ptr == sl.ptr
+                        if not inplace:                      # fallback: explicit copy into the slice
+                            plan.call(plan.fwd, L.bn_act_fwd, dt, sn.act.ptr, sn.act.ldc, None, None, None, 0, None, None, None, 0,
+                                      sl.ptr, sl.ldc, sl.M, sl.C, ACT_NONE, 0.0)
+                        parts.append((sn, off))
+                        off += sn.act.C
+                    recs.append(("concat", parts, z))
+                    outs[i] = z
+                cur = outs[i]
+            elif k == "yolo":
+                yl = mods[i][0]
+                lg = cur
+                Gh, Gw = lg.act.H, lg.act.W
+                anchors = yl.scaled_anchors(Gh).to(device)
+                plan.keep.append(anchors)
+                A, C = yl.num_anchors, yl.num_classes
+                if with_targets:
+                    ws = torch.zeros(int(L.yolo_head_workspace_bytes(B, A, Gh, Gw)), dtype=torch.uint8, device=device)
+                    plan.keep.append(ws)
+                    geo = (B, T, A, C, Gh, Gw, float(yl.ignore_thres), float(yl.xy_loss), float(yl.wh_loss), float(yl.object_loss),
+                           float(yl.no_object_loss))
+                    plan.call(plan.fwd, L.yolo_head_train, dt, lg.act.ptr, lg.act.ldc, None, 0, lg.act.C, plan.targets.data_ptr(),
+                              anchors.data_ptr(), *geo, ws.data_ptr(), plan.out7.data_ptr(), None)
+                    recs.append(("yolo", lg, anchors, ws, geo))
+                else:
+                    plan.call(plan.fwd, L.yolo_head_decode, dt, lg.act.ptr, lg.act.ldc, anchors.data_ptr(), float(yl.stride_for(Gh)), B, A, C,
+                              Gh, Gw, plan.eval_out.data_ptr(), rows_total, row_off)
+                    row_off += A * Gh * Gw
+                heads.append(i)
+                outs[i] = cur
+        if bn_train and nbt:
+            plan.call(plan.fwd, _bump_counters, nbt)
+
+        # ---- backward list: mirror of the records, consumers before producers
+        if with_targets:
+            for r in reversed(recs):
+                kind = r[0]
+                if kind == "yolo":
+                    _, lg, anchors, ws, geo = r
+                    out, add = plan.grad_target(lg)
+                    assert add is None
+                    plan.call(plan.bwd, L.yolo_head_grad, dt, lg.act.ptr, lg.act.ldc, out.ptr, out.ldc, out.C, plan.targets.data_ptr(),
+                              anchors.data_ptr(), *geo, ws.data_ptr(), plan.gscale.data_ptr())
+                elif kind == "convlin":
+                    _, cs, xn, y = r
+                    if y.gstate == "none":
+                        continue
+                    plan.emit_bias_grad(cs, y.grad)
+                    plan.emit_conv_bwd(cs, xn, y.act, y.grad)
+                elif kind == "convbn":
+                    _, cs, bs, xn, y, z, rnode = r
+                    if z.gstate == "none":
+                        continue
+                    if rnode is not None:
+                        plan.grad_identity(rnode, z.grad)
+                    dy = plan.emit_bn_act_bwd(z.grad, y, bs, act_code, slope)
+                    plan.emit_conv_bwd(cs, xn, y, dy)
+                elif kind == "shortcut":
+                    _, a, b, z = r
+                    if z.gstate == "none":
+                        continue
+                    plan.grad_identity(a, z.grad)
+                    plan.grad_identity(b, z.grad)
+                elif kind == "upsample":
+                    _, xn, z = r
+                    if z.gstate == "none":
+                        continue
+                    out, add = plan.grad_target(xn)
+                    if add is None:
+                        plan.call(plan.bwd, L.upsample2x_bwd, dt, z.grad.ptr, z.grad.ldc, out.ptr, out.ldc, B, xn.act.H, xn.act.W, xn.act.C)
+                    else:
+                        tmp = plan.new_act(B, xn.act.H, xn.act.W, xn.act.C)
+                        plan.call(plan.bwd, L.upsample2x_bwd, dt, z.grad.ptr, z.grad.ldc, tmp.ptr, tmp.ldc, B, xn.act.H, xn.act.W, xn.act.C)
+                        plan.call(plan.bwd, L.bn_act_fwd, dt, tmp.ptr, tmp.ldc, None, None, None, 0, None, None, add.ptr, add.ldc,
+                                  out.ptr, out.ldc, out.M, out.C, ACT_NONE, 0.0)
+                elif kind == "concat":
+                    _, parts, z = r
+                    if z.gstate == "none":
+                        continue
+                    for sn, off in parts:
+                        plan.grad_identity(sn, z.grad.slice(off, sn.act.C))
+        plan.outs = outs
+        return plan
+
+    # ------------------------------------------------------------------------------------------ darknet .weights I/O
+    def load_weights(self, weights_path, start_weight_dim):
+        """Binary layout (reference models.py:339-397): int32[5] header, then for every conv in cfg order
+        BN bias, BN weight, running_mean, running_var, conv weight (OIHW)  |  head: bias, weight — read from a tensor that is
+        `start_weight_dim[head]` filters wide, of which the first num_filters are kept."""
+        with open(weights_path, "rb") as fp:
+            header = np.fromfile(fp, dtype=np.int32, count=5)
+            blob = np.fromfile(fp, dtype=np.float32)
+        self.header_info = header
+        self.seen = header[3]
+        pos, head = 0, 0
+
+        def take(dst, count=None):
+            nonlocal pos
+            cnt = dst.numel() if count is None else count
+            dst.data.copy_(torch.from_numpy(blob[pos:pos + cnt].copy()).view_as(dst))
+            pos += cnt
+        with torch.no_grad():
+            for d, m in zip(self.module_defs, self.module_list):
+                if d["type"] != "convolutional":
+                    continue
+                conv = m[0]
+                if d["filters"] != "preyolo":
+                    bn = m[1]
+                    take(bn.bias); take(bn.weight); take(bn.running_mean); take(bn.running_var)
+                    take(conv.weight)
+                else:
+                    wide = start_weight_dim[head]
+                    head += 1
+                    nb = conv.bias.numel()
+                    conv.bias.data.copy_(torch.from_numpy(blob[pos:pos + nb].copy()))
+                    pos += wide
+                    per = conv.weight.numel() // nb
+                    full = torch.from_numpy(blob[pos:pos + per * wide].copy()).view(wide, *conv.weight.shape[1:])
+                    conv.weight.data.copy_(full[:nb])
+                    pos += per * wide
+
+    def save_weights(self, path, cutoff=-1):
+        with open(path, "wb") as fp:
+            self.header_info[3] = self.seen
+            np.asarray(self.header_info, dtype=np.int32).tofile(fp)
+            for d, m in zip(self.module_defs[:cutoff], self.module_list[:cutoff]):
+                if d["type"] != "convolutional":
+                    continue
+                conv = m[0]
+                if d["filters"] != "preyolo":
+                    bn = m[1]
+                    for t in (bn.bias, bn.weight, bn.running_mean, bn.running_var):
+                        t.data.cpu().numpy().tofile(fp)
+                else:
+                    conv.bias.data.cpu().numpy().tofile(fp)
+                conv.weight.data.cpu().numpy().tofile(fp)
+
+
+def _zero_tensor(t, stream):
+    t.zero_()
+    return 0
+
+
+def _bump_counters(ts, stream):
+    torch._foreach_add_(ts, 1)
+    return 0

@@ -1,0 +1,57 @@
+"""GPU drop-ins for the two hot-path helpers of the reference's CVC-YOLOv3/utils/utils.py:
+
+  bbox_iou       (utils.py:163-193)  — tiny elementwise helper, plain torch on whatever device the boxes live on
+  build_targets  (utils.py:195-275)  — HIP kernel (csrc/yolo_head.hip), bit-exact masks / indices
+
+Return order and dtypes follow the reference: mask, conf_mask (uint8), tx, ty, tw, th, tconf (float32), tcls (uint8).
+"""
+import torch
+
+from ... import _lib
+
+
+def bbox_iou(box1, box2, x1y1x2y2=True):
+    """IoU with the reference's "+1 pixel" convention on [...,4] boxes (corner format unless x1y1x2y2=False)."""
+    if x1y1x2y2:
+        ax1, ay1, ax2, ay2 = box1[..., 0], box1[..., 1], box1[..., 2], box1[..., 3]
+        bx1, by1, bx2, by2 = box2[..., 0], box2[..., 1], box2[..., 2], box2[..., 3]
+    else:
+        ax1, ax2 = box1[..., 0] - box1[..., 2] / 2, box1[..., 0] + box1[..., 2] / 2
+        ay1, ay2 = box1[..., 1] - box1[..., 3] / 2, box1[..., 1] + box1[..., 3] / 2
+        bx1, bx2 = box2[..., 0] - box2[..., 2] / 2, box2[..., 0] + box2[..., 2] / 2
+        by1, by2 = box2[..., 1] - box2[..., 3] / 2, box2[..., 1] + box2[..., 3] / 2
+    iw = torch.clamp(torch.min(ax2, bx2) - torch.max(ax1, bx1) + 1, min=0)
+    ih = torch.clamp(torch.min(ay2, by2) - torch.max(ay1, by1) + 1, min=0)
+    inter = iw * ih
+    area_a = (ax2 - ax1 + 1) * (ay2 - ay1 + 1)
+    area_b = (bx2 - bx1 + 1) * (by2 - by1 + 1)
+    return inter / (area_a + area_b - inter + 1e-12)
+
+
+def build_targets(target, anchors, num_anchors, num_classes, grid_size_h, grid_size_w, ignore_thres):
+    """target [B,T,5] (cls,cx,cy,w,h; zero rows = padding), anchors [A,2] in grid units, both on the GPU.
+
+    A target whose centre falls outside the grid (cx or cy == 1.0) raises IndexError like the reference (this costs
+    one device sync; the fused training path in models.YOLOLayer does not pay it)."""
+    _lib.require_gpu(target)
+    L = _lib.lib()
+    dev = target.device
+    tg = target.detach().to(torch.float32).contiguous()
+    an = anchors.detach().to(device=dev, dtype=torch.float32).contiguous()
+    B, T = tg.shape[0], tg.shape[1]
+    A, C, Gh, Gw = int(num_anchors), int(num_classes), int(grid_size_h), int(grid_size_w)
+    shape = (B, A, Gh, Gw)
+    u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)          # noqa: E731
+    f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)       # noqa: E731
+    mask, conf_mask = u8(*shape), u8(*shape)
+    tx, ty, tw, th, tconf = f32(*shape), f32(*shape), f32(*shape), f32(*shape), f32(*shape)
+    tcls = u8(*shape, C)
+    ws = torch.empty(int(L.build_targets_workspace_bytes(B, T, A, Gh, Gw)), dtype=torch.uint8, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    L.check(L.build_targets(tg.data_ptr(), an.data_ptr(), B, T, A, C, Gh, Gw, float(ignore_thres), mask.data_ptr(),
+                            conf_mask.data_ptr(), tx.data_ptr(), ty.data_ptr(), tw.data_ptr(), th.data_ptr(), tconf.data_ptr(),
+                            tcls.data_ptr(), ws.data_ptr(), err.data_ptr(), stream), "build_targets")
+    if int(err.item()) != 0:
+        raise IndexError("build_targets: a target centre falls outside the grid (cx or cy >= 1.0)")
+    return mask, conf_mask, tx, ty, tw, th, tconf, tcls

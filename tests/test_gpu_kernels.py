@@ -1,0 +1,326 @@
+"""-m gpu: every HIP kernel through the C ABI against a torch-CPU fp32 reference of the same op.
+
+fp32 mode (exact-f32 MFMA) pins indexing/layout tightly; bf16 mode is checked against the same reference computed on
+bf16-rounded inputs with a tolerance that covers output rounding only.
+"""
+import ctypes
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mdcv import _lib  # noqa: E402
+from mdcv.engine import pad8  # noqa: E402
+
+F32, BF16 = 0, 1
+TD = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def to_nhwc(x, dtype, cpad=None):
+    """NCHW fp32 (cpu) -> device NHWC buffer [B,H,W,cpad] of dtype via the library kernel."""
+    L = _lib.lib()
+    B, C, H, W = x.shape
+    cp = cpad or pad8(C)
+    src = x.contiguous().cuda()
+    dst = torch.empty(B, H, W, cp, dtype=TD[dtype], device="cuda")
+    L.check(L.nchw_to_nhwc(dtype, src.data_ptr(), dst.data_ptr(), B, C, H, W, cp, cp, st()))
+    return dst
+
+
+def to_nchw(buf, dtype, C):
+    L = _lib.lib()
+    B, H, W, ldc = buf.shape
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device="cuda")
+    L.check(L.nhwc_to_nchw(dtype, buf.data_ptr(), ldc, out.data_ptr(), B, C, H, W, st()))
+    return out.cpu()
+
+
+def rnd(dtype, t):
+    return t.to(torch.bfloat16).float() if dtype == BF16 else t
+
+
+def pack(dtype, w, cin_pad=None, need_d=True):
+    L = _lib.lib()
+    co, ci, kh, kw = w.shape
+    cop, cip = pad8(co), cin_pad or pad8(ci)
+    wf = torch.zeros(cop * kh * kw * cip, dtype=TD[dtype], device="cuda")
+    wd = torch.zeros(cip * kh * kw * cop, dtype=TD[dtype], device="cuda") if need_d else None
+    wg = w.contiguous().cuda()
+    L.check(L.pack_weights(dtype, wg.data_ptr(), wf.data_ptr(), wd.data_ptr() if need_d else None, co, ci, kh, kw, cop, cip, st()))
+    return wf, wd
+
+
+def test_layout_roundtrip():
+    x = torch.randn(2, 5, 7, 9)
+    for dt in (F32, BF16):
+        buf = to_nhwc(x, dt)
+        assert buf.shape[-1] == 8
+        ref = rnd(dt, x)
+        assert torch.equal(buf.float().cpu()[..., :5], ref.permute(0, 2, 3, 1))
+        assert float(buf.float()[..., 5:].abs().max()) == 0.0
+        assert torch.equal(to_nchw(buf, dt, 5), ref)
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, dil, bias
+    (2, 3, 20, 20, 16, 3, 1, 1, 1, False),      # input layer (Cin padded 3->8)
+    (2, 16, 17, 19, 32, 3, 2, 1, 1, False),     # stride-2 downsample, odd sizes
+    (3, 32, 13, 13, 64, 1, 1, 0, 1, False),     # 1x1
+    (2, 64, 13, 13, 255, 1, 1, 0, 1, True),     # preyolo head: ragged Cout, bias
+    (2, 3, 24, 24, 16, 7, 1, 3, 1, True),       # RektNet stem 7x7
+    (2, 16, 20, 20, 32, 3, 1, 2, 2, True),      # dilated 3x3
+    (1, 128, 9, 9, 7, 1, 1, 0, 1, True),        # RektNet head Cout=7
+    (2, 48, 11, 11, 136, 3, 1, 1, 1, False),    # Cout > 128 (two N tiles), Cin not a multiple of 32
+    (1, 256, 13, 13, 512, 3, 1, 1, 1, False),   # big K
+]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case, dt):
+    L = _lib.lib()
+    B, Ci, H, W, Co, k, s, p, d, has_bias = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g) if has_bias else None
+    xr, wr = rnd(dt, x).requires_grad_(True), rnd(dt, w).requires_grad_(True)
+    yref = F.conv2d(xr, wr, b, stride=s, padding=p, dilation=d)
+    Ho, Wo = yref.shape[2], yref.shape[3]
+    cip, cop = pad8(Ci), pad8(Co)
+    xb = to_nhwc(x, dt)
+    wf, wd = pack(dt, w)
+    y = torch.empty(B, Ho, Wo, cop, dtype=TD[dt], device="cuda")
+    rows = L.conv2d_stats_rows(B * Ho * Wo)
+    stats = torch.zeros(rows, 2, cop, dtype=torch.float32, device="cuda")
+    bp = None
+    if has_bias:
+        bp = torch.zeros(cop, device="cuda")
+        bp[:Co] = b.cuda()
+    L.check(L.conv2d(dt, 0, xb.data_ptr(), cip, wf.data_ptr(), y.data_ptr(), cop, bp.data_ptr() if bp is not None else None, None, 0,
+                     stats.data_ptr(), B, H, W, cip, Ho, Wo, cop, k, k, s, p, d, st()), "conv fwd")
+    got = to_nchw(y, dt, Co)
+    tol = dict(rtol=1e-4, atol=1e-4) if dt == F32 else dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(got.numpy(), yref.detach().numpy(), **tol)
+    if cop > Co:
+        assert float(y.float()[..., Co:].abs().max()) == 0.0
+    # BN statistics epilogue (computed from the fp32 accumulators)
+    ssum = stats[:, 0, :Co].sum(0).cpu()
+    ssq = stats[:, 1, :Co].sum(0).cpu()
+    np.testing.assert_allclose(ssum.numpy(), yref.detach().sum((0, 2, 3)).numpy(), rtol=2e-3, atol=2e-2 * (B * Ho * Wo) ** 0.5)
+    np.testing.assert_allclose(ssq.numpy(), (yref.detach() ** 2).sum((0, 2, 3)).numpy(), rtol=5e-3, atol=1e-2)
+
+    # backward: random dY (pad channels zero)
+    dy = torch.randn(B, Co, Ho, Wo, generator=g)
+    dyr = rnd(dt, dy)
+    yref.backward(dyr)
+    dyb = to_nhwc(dy, dt)
+    # dgrad (+ addsrc)
+    add = torch.randn(B, Ci, H, W, generator=g)
+    addb = to_nhwc(add, dt)
+    dx = torch.empty(B, H, W, cip, dtype=TD[dt], device="cuda")
+    L.check(L.conv2d(dt, 1, dyb.data_ptr(), cop, wd.data_ptr(), dx.data_ptr(), cip, None, addb.data_ptr(), cip, None,
+                     B, Ho, Wo, cop, H, W, cip, k, k, s, p, d, st()), "conv dgrad")
+    gotdx = to_nchw(dx, dt, Ci)
+    np.testing.assert_allclose(gotdx.numpy(), (xr.grad + rnd(dt, add)).numpy(), **(dict(rtol=1e-4, atol=1e-4) if dt == F32 else dict(rtol=3e-2, atol=3e-2)))
+    # wgrad
+    M = B * Ho * Wo
+    ktot = k * k * cip
+    splits = L.conv2d_wgrad_splits(dt, M, cop, ktot)
+    ws = torch.empty(splits * cop * ktot, dtype=torch.float32, device="cuda")
+    dw = torch.full((Co, Ci, k, k), 7.0, dtype=torch.float32, device="cuda")
+    L.check(L.conv2d_wgrad(dt, dyb.data_ptr(), cop, xb.data_ptr(), cip, ws.data_ptr(), splits, dw.data_ptr(), 0, B, H, W, cip, Ci,
+                           Ho, Wo, cop, Co, k, k, s, p, d, st()), "conv wgrad")
+    ref = wr.grad.numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-4 if dt == F32 else 2e-2, atol=(1e-4 if dt == F32 else 2e-2) * scale)
+
+
+def test_conv_wgrad_many_splits_and_tiles():
+    """M large enough for many pixel splits; Ktot > 128 and Cout > 128 -> several output tiles."""
+    L = _lib.lib()
+    dt = F32
+    B, Ci, H, W, Co, k = 4, 16, 40, 40, 144, 3
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    w = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    F.conv2d(x, w, padding=1).backward(dy)
+    xb, dyb = to_nhwc(x, dt), to_nhwc(dy, dt)
+    ktot = 9 * Ci
+    splits = L.conv2d_wgrad_splits(dt, B * H * W, Co, ktot)
+    assert splits > 8
+    ws = torch.empty(splits * Co * ktot, dtype=torch.float32, device="cuda")
+    dw = torch.empty(Co, Ci, k, k, dtype=torch.float32, device="cuda")
+    L.check(L.conv2d_wgrad(dt, dyb.data_ptr(), Co, xb.data_ptr(), Ci, ws.data_ptr(), splits, dw.data_ptr(), 0, B, H, W, Ci, Ci, H, W, Co, Co,
+                           k, k, 1, 1, 1, st()))
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=2e-4, atol=2e-3)
+
+
+def test_conv_strided_channel_views():
+    """ldc > C on input and output (route-concat slices)."""
+    L = _lib.lib()
+    dt = F32
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 10, 10, generator=g)
+    w = torch.randn(24, 16, 3, 3, generator=g) * 0.1
+    ref = F.conv2d(x, w, padding=1)
+    big_in = torch.zeros(2, 10, 10, 40, device="cuda")
+    big_in[..., 8:24] = x.permute(0, 2, 3, 1).cuda()
+    big_out = torch.full((2, 10, 10, 64), -3.0, device="cuda")
+    wf, _ = pack(dt, w, need_d=False)
+    L.check(L.conv2d(dt, 0, big_in.data_ptr() + 8 * 4, 40, wf.data_ptr(), big_out.data_ptr() + 16 * 4, 64, None, None, 0, None,
+                     2, 10, 10, 16, 10, 10, 24, 3, 3, 1, 1, 1, st()))
+    got = big_out[..., 16:40].permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    assert float((big_out[..., :16] + 3).abs().max()) == 0 and float((big_out[..., 40:] + 3).abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", [F32, BF16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("C,act,dual,resid", [(16, 1, False, False), (64, 1, False, True), (32, 2, True, False), (128, 2, False, False), (1024, 1, False, True)])
+def test_bn_act_fwd_bwd(dt, C, act, dual, resid):
+    L = _lib.lib()
+    B, H, W = 3, 9, 7
+    M = B * H * W
+    g = torch.Generator().manual_seed(C + act)
+    slope = 0.1
+    y1 = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3
+    y2 = torch.randn(B, C, H, W, generator=g) if dual else None
+    rs = torch.randn(B, C, H, W, generator=g) if resid else None
+    gam1, bet1 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    gam2, bet2 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    dout = torch.randn(B, C, H, W, generator=g)
+    # reference on (rounded) inputs
+    a1 = rnd(dt, y1).requires_grad_(True)
+    a2 = rnd(dt, y2).requires_grad_(True) if dual else None
+    p1g, p1b = gam1.clone().requires_grad_(True), bet1.clone().requires_grad_(True)
+    p2g, p2b = gam2.clone().requires_grad_(True), bet2.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    pre = F.batch_norm(a1, rm, rv, p1g, p1b, training=True, momentum=0.1, eps=1e-5)
+    if dual:
+        pre = pre + F.batch_norm(a2, torch.zeros(C), torch.ones(C), p2g, p2b, training=True, momentum=0.1, eps=1e-5)
+    z = F.leaky_relu(pre, slope) if act == 1 else F.relu(pre)
+    if resid:
+        z = z + rnd(dt, rs)
+    z.backward(rnd(dt, dout))
+
+    def stats_for(y, gam, bet, rmean, rvar):
+        yb = to_nhwc(y, dt)
+        yf = yb.float().reshape(M, C)
+        partial = torch.stack((yf.sum(0), (yf * yf).sum(0))).reshape(1, 2, C).contiguous()
+        accum = torch.zeros(3 * C, dtype=torch.float64, device="cuda")
+        bufs = [torch.zeros(C, device="cuda") for _ in range(4)]
+        L.check(L.partial_reduce(partial.data_ptr(), 1, 2, C, accum.data_ptr(), st()))
+        L.check(L.bn_finalize(accum.data_ptr(), float(M), gam.cuda().data_ptr(), bet.cuda().data_ptr(), rmean.data_ptr(), rvar.data_ptr(), 0.1, 1e-5,
+                              *[b.data_ptr() for b in bufs], C, st()))
+        assert float(accum.abs().max()) == 0.0
+        return yb, accum, bufs
+    rmd, rvd = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    y1b, acc, (s1, b1, m1, i1) = stats_for(y1, gam1, bet1, rmd, rvd)
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-5)
+    if dual:
+        y2b, _, (s2, b2, m2, i2) = stats_for(y2, gam2, bet2, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"))
+    rsb = to_nhwc(rs, dt) if resid else None
+    out = torch.empty(B, H, W, C, dtype=TD[dt], device="cuda")
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    L.check(L.bn_act_fwd(dt, y1b.data_ptr(), C, s1.data_ptr(), b1.data_ptr(), P(y2b) if dual else None, C, P(s2) if dual else None,
+                         P(b2) if dual else None, P(rsb), C, out.data_ptr(), C, M, C, act, slope, st()))
+    tol = dict(rtol=1e-4, atol=1e-4) if dt == F32 else dict(rtol=2e-2, atol=3e-2)
+    np.testing.assert_allclose(to_nchw(out, dt, C).numpy(), z.detach().numpy(), **tol)
+    # backward
+    db = to_nhwc(dout, dt)
+    L.check(L.bn_act_bwd_reduce(dt, db.data_ptr(), C, y1b.data_ptr(), C, s1.data_ptr(), b1.data_ptr(), m1.data_ptr(), i1.data_ptr(),
+                                P(y2b) if dual else None, C, P(s2) if dual else None, P(b2) if dual else None, P(m2) if dual else None,
+                                P(i2) if dual else None, acc.data_ptr(), M, C, act, slope, st()))
+    outs = {}
+    nsums = 3 if dual else 2
+    order = [(2, gam2, m2, i2, 0)] if dual else []
+    order.append((1, gam1, m1, i1, 1))
+    for kx, gam, mm, ii, zero in order:
+        bufs = [torch.zeros(C, device="cuda") for _ in range(5)]
+        L.check(L.bn_bwd_finalize(acc.data_ptr(), kx, nsums, zero, float(M), gam.cuda().data_ptr(), mm.data_ptr(), ii.data_ptr(),
+                                  *[b.data_ptr() for b in bufs], C, st()))
+        outs[kx] = bufs
+    assert float(acc.abs().max()) == 0.0
+    dy1 = torch.empty(B, H, W, C, dtype=TD[dt], device="cuda")
+    dy2 = torch.empty(B, H, W, C, dtype=TD[dt], device="cuda") if dual else None
+    o1 = outs[1]
+    o2 = outs.get(2)
+    L.check(L.bn_act_bwd_apply(dt, db.data_ptr(), C, y1b.data_ptr(), C, s1.data_ptr(), b1.data_ptr(), o1[2].data_ptr(), o1[3].data_ptr(),
+                               o1[4].data_ptr(), dy1.data_ptr(), C, P(y2b) if dual else None, C, P(s2) if dual else None, P(b2) if dual else None,
+                               o2[2].data_ptr() if dual else None, o2[3].data_ptr() if dual else None, o2[4].data_ptr() if dual else None,
+                               P(dy2), C, M, C, act, slope, st()))
+    btol = dict(rtol=2e-3, atol=2e-4) if dt == F32 else dict(rtol=5e-2, atol=5e-2)
+    np.testing.assert_allclose(to_nchw(dy1, dt, C).numpy(), a1.grad.numpy(), **btol)
+    np.testing.assert_allclose(o1[0].cpu().numpy(), p1g.grad.numpy(), rtol=2e-3 if dt == F32 else 3e-2, atol=1e-3 if dt == F32 else 1e-1)
+    np.testing.assert_allclose(o1[1].cpu().numpy(), p1b.grad.numpy(), rtol=2e-3 if dt == F32 else 3e-2, atol=1e-3 if dt == F32 else 1e-1)
+    if dual:
+        np.testing.assert_allclose(to_nchw(dy2, dt, C).numpy(), a2.grad.numpy(), **btol)
+        np.testing.assert_allclose(o2[0].cpu().numpy(), p2g.grad.numpy(), rtol=2e-3 if dt == F32 else 3e-2, atol=1e-3 if dt == F32 else 1e-1)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16], ids=["fp32", "bf16"])
+def test_upsample_and_colsum(dt):
+    L = _lib.lib()
+    x = torch.randn(2, 16, 5, 6)
+    xb = to_nhwc(x, dt)
+    out = torch.zeros(2, 10, 12, 40, dtype=TD[dt], device="cuda")          # into a concat slice at channel 8
+    L.check(L.upsample2x_fwd(dt, xb.data_ptr(), 16, out.data_ptr() + 8 * out.element_size(), 40, 2, 5, 6, 16, st()))
+    ref = F.interpolate(rnd(dt, x), scale_factor=2, mode="nearest")
+    assert torch.equal(out[..., 8:24].float().permute(0, 3, 1, 2).cpu(), ref)
+    d = torch.randn(2, 16, 10, 12)
+    dbuf = torch.zeros(2, 10, 12, 40, dtype=TD[dt], device="cuda")
+    dbuf[..., 8:24] = rnd(dt, d).permute(0, 2, 3, 1).to(TD[dt]).cuda()
+    din = torch.empty(2, 5, 6, 16, dtype=TD[dt], device="cuda")
+    L.check(L.upsample2x_bwd(dt, dbuf.data_ptr() + 8 * dbuf.element_size(), 40, din.data_ptr(), 16, 2, 5, 6, 16, st()))
+    refd = rnd(dt, d).view(2, 16, 5, 2, 6, 2).sum((3, 5))
+    np.testing.assert_allclose(to_nchw(din, dt, 16).numpy(), refd.numpy(), rtol=1e-5 if dt == F32 else 1e-2, atol=1e-5 if dt == F32 else 2e-2)
+    # column sums with C = 24 (3 bf16 vectors / 6 fp32 vectors per pixel: the non-power-of-two strip path)
+    t = torch.randn(3, 24, 7, 5)
+    tb = to_nhwc(t, dt)
+    acc = torch.zeros(24, dtype=torch.float64, device="cuda")
+    o = torch.zeros(24, device="cuda")
+    L.check(L.colsum(dt, tb.data_ptr(), 24, 3 * 7 * 5, 24, acc.data_ptr(), st()))
+    L.check(L.accum_to_f32(acc.data_ptr(), o.data_ptr(), 24, 1, st()))
+    np.testing.assert_allclose(o.cpu().numpy(), rnd(dt, t).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_adam_sgd_match_torch():
+    L = _lib.lib()
+    n = 10007
+    g = torch.Generator().manual_seed(1)
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    for wd in (0.0, 0.01):
+        p = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.Adam([p], lr=1e-3, weight_decay=wd)
+        pd, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        gd = gr.cuda()
+        for step in (1, 2, 3):
+            p.grad = gr.clone()
+            opt.step()
+            L.check(L.adam_step(pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, step, 1e-3, 0.9, 0.999, 1e-8, wd, 1.0, st()))
+        np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-6)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([p], lr=1e-2, momentum=0.9)
+    pd, buf = p0.clone().cuda(), torch.zeros(n, device="cuda")
+    for step in (1, 2, 3):
+        p.grad = gr.clone()
+        opt.step()
+        L.check(L.sgd_step(pd.data_ptr(), gr.cuda().data_ptr(), buf.data_ptr(), n, step, 1e-2, 0.9, 0.0, 1.0, st()))
+    np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_device_is_gfx950():
+    L = _lib.lib()
+    cu, wave = ctypes.c_int(), ctypes.c_int()
+    hbm = ctypes.c_longlong()
+    arch = ctypes.create_string_buffer(64)
+    L.check(L.device_info(ctypes.byref(cu), ctypes.byref(wave), ctypes.byref(hbm), arch, 64))
+    assert wave.value == 64 and cu.value >= 200 and arch.value.decode().startswith("gfx950")
