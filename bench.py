@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Training-throughput benchmark of the MDCV hot path on MI355X (contract: see the task brief / DESIGN.md §measurement).
+
+  python bench.py --gpus 1 --steps K --warmup W            # single GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = zero_grad -> forward -> backward -> (RCCL gradient all-reduce when N>1) -> optimizer step on one synthetic batch
+already resident in HBM.  Primary workload: CVC-YOLOv3 (yolo_baseline topology) 416x416, classes=80, bf16, 32 images per GPU
+(BASELINE.json configs[2]/[3]); secondary workload reported in the same JSON line: RektNet 80x80 bf16, 256 images per GPU
+(configs[1]).  Weak scaling: per-GPU batch fixed.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+YOLO_TRAIN_GFLOP_PER_IMG = 197.59   # SURVEY.md §8d (conv only, fwd+dgrad+wgrad, classes=80, 416^2)
+REKT_TRAIN_GFLOP_PER_IMG = 11.872   # head conv counted once
+REKT_TRAIN_MB_PER_IMG = 57.8
+
+
+def write_yolo_cfg(dirname, size=416, classes=80):
+    """yolo_baseline topology, generated — the reference's cfg file does not travel."""
+    head = (f"[net]\nwidth={size}\nheight={size}\nonnx_height={size}\nclasses={classes}\nchannels=3\n"
+            "yolo_masks=6,7,8|3,4,5|0,1,2\nyolo_scales=32,16,8\nvalidate_uri=dataset/validate.csv\ntrain_uri=dataset/train.csv\n"
+            "weights_uri=none\nstart_weights_dim=255,255,255\nnum_train_images=-1\nnum_validate_images=-1\nleaky_slope=0.1\n"
+            "conv_activation=leaky\nbuild_targets_ignore_thresh=0.5\nconf_thresh=0.8\nnms_thresh=0.25\niou_thresh=0.5\n\n")
+
+    def conv(f, k, s=1):
+        return f"[convolutional]\nfilters={f}\nsize={k}\nstride={s}\n\n"
+
+    def res(c, n):
+        return "".join(conv(c // 2, 1) + conv(c, 3) + "[shortcut]\nfrom=-3\n\n" for _ in range(n))
+    body = conv(32, 3) + conv(64, 3, 2) + res(64, 1) + conv(128, 3, 2) + res(128, 2) + conv(256, 3, 2) + res(256, 8)
+    body += conv(512, 3, 2) + res(512, 8) + conv(1024, 3, 2) + res(1024, 4)
+    body += "".join(conv(512, 1) + conv(1024, 3) for _ in range(3)) + conv("preyolo", 1) + "[yolo]\n\n"
+    body += "[route]\nlayers=-4\n\n" + conv(256, 1) + "[upsample]\nstride=2\n\n[route]\nlayers=-1, 61\n\n"
+    body += "".join(conv(256, 1) + conv(512, 3) for _ in range(3)) + conv("preyolo", 1) + "[yolo]\n\n"
+    body += "[route]\nlayers=-4\n\n" + conv(128, 1) + "[upsample]\nstride=2\n\n[route]\nlayers=-1, 36\n\n"
+    body += "".join(conv(128, 1) + conv(256, 3) for _ in range(3)) + conv("preyolo", 1) + "[yolo]\n"
+    os.makedirs(os.path.join(dirname, "dataset"), exist_ok=True)
+    with open(os.path.join(dirname, "dataset", "train.csv"), "w") as f:
+        f.write('"10,13|16,30|33,23|30,61|62,45|59,119|116,90|156,198|373,326"\n')
+    path = os.path.join(dirname, f"yolo_baseline_{size}.cfg")
+    with open(path, "w") as f:
+        f.write(head + body)
+    return path
+
+
+def synth_targets(B, T, gen):
+    """[B,T,5]: 1..T cone-like boxes per image (cls 0, centre U(.05,.95), size U(.02,.30)), remaining rows zero."""
+    t = torch.zeros(B, T, 5)
+    for b in range(B):
+        n = int(torch.randint(1, T + 1, (1,), generator=gen))
+        t[b, :n, 1:3] = torch.rand(n, 2, generator=gen) * 0.9 + 0.05
+        t[b, :n, 3:5] = torch.rand(n, 2, generator=gen) * 0.28 + 0.02
+    return t
+
+
+def timed_region(fn, steps, warmup, device, world):
+    for _ in range(warmup):
+        fn()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def conv_flops(args):
+    """algorithmic FLOPs of one mdcv_conv2d launch (real work of the padded problem the kernel is given)."""
+    B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW = args[11], args[12], args[13], args[14], args[15], args[16], args[17], args[18], args[19]
+    mode, stride = args[1], args[20]
+    if mode == 0:
+        return 2.0 * B * Hout * Wout * Nout * KH * KW * Cin
+    return 2.0 * B * Hin * Win * Cin * KH * KW * Nout          # dgrad: one MAC per (dy pixel, tap, ci, co), stride-independent
+
+
+def kernel_breakdown(model, plan, step_fn):
+    """One extra, untimed step with a HIP event after every launch (on the launch stream): per-kernel time and the
+    dominant kernel's achieved rate."""
+    from mdcv.engine import run_timed
+    rec = {}
+
+    def add(lst):
+        for name, ms, args in lst:
+            r = rec.setdefault(name, [0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += ms
+            if name == "mdcv_conv2d":
+                r[2] += conv_flops(args)
+    orig_run = plan.run
+
+    def run_and_time(lst, stream=None):
+        add(run_timed(plan, lst, stream))
+    plan.run = run_and_time
+    g = plan.use_graph
+    plan.use_graph = False
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        plan.run = orig_run
+        plan.use_graph = g
+    return rec
+
+
+def wgrad_flops_total(model):
+    return None
+
+
+def cpu_baseline_yolo(cfg_path, workdir, budget_s=25.0):
+    """CPU oracle ("port": plain torch-CPU restatement of the reference, pinned to it by tests/golden) on the host cores."""
+    from oracle import yolo_oracle as yo
+    torch.set_num_threads(os.cpu_count())
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        orc = yo.DarknetOracle(cfg_path, anchors=yo.VANILLA_ANCHORS, seed=0)
+    finally:
+        os.chdir(cwd)
+    B = 2
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(B, 3, 416, 416, generator=g)
+    tg = synth_targets(B, 16, g)
+    params = [v.requires_grad_(True) for k, v in orc.trainable().items()]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    times = []
+    t_start = time.perf_counter()
+    for it in range(4):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        out = orc.forward(x, tg)
+        out[0].sum().backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s and it >= 1:
+            break
+    steady = times[1:] if len(times) > 1 else times
+    return {"value": B / (sum(steady) / len(steady)), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"YOLOv3 416^2 classes=80 fp32 CPU oracle, batch {B}, {len(steady)} timed train steps after 1 warm-up (Adam)"}
+
+
+def cpu_baseline_rektnet(budget_s=12.0):
+    from oracle import rektnet_oracle as ro
+    torch.set_num_threads(os.cpu_count())
+    sd = ro.init_state(0)
+    params = [v.requires_grad_(True) for k, v in sd.items() if "running" not in k]
+    opt = torch.optim.Adam(params, lr=0.1)
+    B = 8
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(B, 3, 80, 80, generator=g)
+    tp = torch.rand(B, 7, 2, generator=g) * (79 / 80)
+    times = []
+    t_start = time.perf_counter()
+    for it in range(8):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        hm, pts = ro.keypoint_forward(x, sd, train=True)
+        ro.cross_ratio_loss(hm, pts, None, tp, "l1_softargmax", True, 0.05, 0.05)[2].backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s and it >= 1:
+            break
+    steady = times[1:]
+    return {"value": B / (sum(steady) / len(steady)), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"RektNet 80^2 fp32 CPU oracle, batch {B}, {len(steady)} timed train steps after 1 warm-up (Adam, l1_softargmax+geo)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="both", choices=["both", "yolo", "rektnet"])
+    ap.add_argument("--yolo-batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--rekt-batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("MDCV_GRAPH", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the MDCV hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    os.environ["MDCV_GRAPH"] = str(a.graph)
+
+    from mdcv.yolo.models import Darknet
+    from mdcv.rektnet.keypoint_net import KeypointNet
+    from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+    from mdcv.optim import FusedAdam
+    from mdcv.parallel import GradAllReducer
+
+    result = {}
+    extra = {}
+    tmp = tempfile.mkdtemp(prefix="mdcv_bench_")
+    cfg = write_yolo_cfg(tmp)
+
+    if a.workload in ("both", "yolo"):
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            torch.manual_seed(0)                                # identical initial weights on every rank
+            net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision=a.precision)
+        finally:
+            os.chdir(cwd)
+        net = net.to(device).train()
+        opt = FusedAdam(net, lr=1e-3)
+        red = GradAllReducer(lambda: net.flat_parameters()[1], bucket_mb=64.0)
+        g = torch.Generator().manual_seed(1000 + rank)         # rank-seeded shard of the global batch
+        B = a.yolo_batch
+        x = torch.rand(B, 3, 416, 416, generator=g).to(device)
+        tg = synth_targets(B, 16, g).to(device)
+
+        def yolo_step():
+            opt.zero_grad()
+            out = net(x, tg)
+            out[0].sum().backward()
+            red.allreduce()
+            opt.step()
+            return out
+        dt = timed_region(yolo_step, a.steps, a.warmup, device, world)
+        ips = B * world * a.steps / dt
+        loss = float(yolo_step()[0])
+        result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
+        extra["yolo"] = {"images_per_sec": ips, "ms_per_step": 1e3 * dt / a.steps, "global_batch": B * world, "final_loss": loss,
+                         "mfma_frac_step": ips * YOLO_TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_TFLOPS * world)}
+        if rank == 0 and not a.no_breakdown:
+            plan = [p for p in net._plans.values() if p.has_bwd][0]
+            rec = kernel_breakdown(net, plan, yolo_step)
+            tot = sum(v[1] for v in rec.values())
+            conv = rec.get("mdcv_conv2d", [0, 0.0, 0.0])
+            extra["yolo"]["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])}
+            extra["yolo"]["kernel_launches_per_step"] = {k: v[0] for k, v in rec.items()}
+            extra["yolo"]["sum_kernel_ms"] = round(tot, 3)
+            if conv[1] > 0:
+                ach = conv[2] / (conv[1] * 1e-3) / 1e12
+                result["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16> (mdcv_conv2d: forward + data-gradient launches)",
+                                      "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                                      "traffic": None, "launches": conv[0], "avg_launch_ms": conv[1] / conv[0],
+                                      "flops_per_launch_avg": conv[2] / conv[0]}
+        del net, opt
+        torch.cuda.empty_cache()
+
+    if a.workload in ("both", "rektnet"):
+        torch.manual_seed(0)
+        kp = KeypointNet(7, (80, 80), precision=a.precision).to(device).train()
+        crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
+        opt = FusedAdam(kp, lr=0.1)
+        red = GradAllReducer(lambda: kp.flat_parameters()[1], bucket_mb=64.0)
+        g = torch.Generator().manual_seed(2000 + rank)
+        B = a.rekt_batch
+        x = torch.rand(B, 3, 80, 80, generator=g).to(device)
+        tp = (torch.rand(B, 7, 2, generator=g) * (79 / 80)).to(device)
+
+        def rekt_step():
+            opt.zero_grad()
+            hm, pts = kp(x)
+            loss = crit(hm, pts, None, tp)[2]
+            loss.backward()
+            red.allreduce()
+            opt.step()
+            return loss
+        dt = timed_region(rekt_step, a.steps, a.warmup, device, world)
+        ips = B * world * a.steps / dt
+        extra["rektnet"] = {"images_per_sec": ips, "ms_per_step": 1e3 * dt / a.steps, "global_batch": B * world,
+                            "final_loss": float(rekt_step()),
+                            "mfma_frac_step": ips * REKT_TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_TFLOPS * world),
+                            "hbm_frac_step": ips * REKT_TRAIN_MB_PER_IMG / 1e3 / (PEAK_HBM_GBS * world)}
+        if rank == 0 and not a.no_breakdown:
+            plan = [p for p in kp._plans.values() if p.has_bwd][0]
+            rec = kernel_breakdown(kp, plan, rekt_step)
+            extra["rektnet"]["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])}
+        if a.workload == "rektnet":
+            result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
+
+    if rank == 0:
+        primary = "rektnet" if a.workload == "rektnet" else "yolo"
+        line = {
+            "metric": "images/sec training (YOLOv3 416^2 + RektNet 80^2)", "value": result["value"], "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": result["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": ("CVC-YOLOv3 yolo_baseline 416x416 classes=80, train step (fwd+bwd+Adam), %d img/GPU" % a.yolo_batch)
+                       if primary == "yolo" else ("RektNet KeypointNet 80x80 train step (l1_softargmax+geo, Adam), %d img/GPU" % a.rekt_batch),
+                       "global_batch": (a.yolo_batch if primary == "yolo" else a.rekt_batch) * world, "parallelism": f"dp{world}",
+                       "hipgraph": bool(a.graph)},
+            "workloads": extra,
+        }
+        if "roofline" in result:
+            line["roofline"] = result["roofline"]
+        else:
+            line["roofline"] = None
+        if world == 1 and not a.no_cpu_baseline:
+            cb = cpu_baseline_yolo(cfg, tmp) if primary == "yolo" else cpu_baseline_rektnet()
+            line["cpu_baseline"] = cb
+            if a.workload == "both":
+                line["workloads"]["rektnet"]["cpu_baseline"] = cpu_baseline_rektnet()
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

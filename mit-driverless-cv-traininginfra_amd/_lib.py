@@ -53,6 +53,10 @@ class _Lib:
             raise MdcvError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"(or `make -C {os.path.join(_HERE, 'csrc')}`). There is no CPU fallback for the product path.")
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It must be in the process
+        # BEFORE our library is dlopen'ed so that both bind to the same runtime instance; two runtimes in one process
+        # do not share devices/streams (kernels launched through the second one fail with hipErrorNoDevice).
+        import torch  # noqa: F401
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         for name, (ret, argt, _) in self.protos.items():

@@ -72,6 +72,7 @@ class ConvSpec:
         self.bias_pad = None
         if bias is not None:
             self.bias_pad = torch.zeros(self.cout_pad, dtype=torch.float32, device=plan.device)
+        plan.keep.append(self)     # the launch lists hold raw device pointers: the plan must own every buffer
 
     def out_hw(self, H, W):
         ek = self.dil * (self.kh - 1) + 1
@@ -88,6 +89,7 @@ class BnSpec:
         self.scale, self.shift, self.mean, self.invstd = z(), z(), z(), z()
         self.cA, self.cB, self.cC = z(), z(), z()
         self.accum = torch.zeros(3 * C, dtype=torch.float64, device=dev)
+        plan.keep.append(self)
 
 
 class Plan:
@@ -323,3 +325,31 @@ class Plan:
             rc = L.graph_end(stream, ctypes.byref(ge))
         L.check(rc, "graph_end")
         return ge
+
+
+def run_timed(plan, lst, stream=None):
+    """Run a launch list with a HIP event after every op (on the launch stream).  Returns [(name, ms, args)]."""
+    import ctypes
+    L = plan.L
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    evs = []
+    for _ in range(len(lst) + 1):
+        e = ctypes.c_void_p()
+        L.check(L.event_create(ctypes.byref(e)), "event_create")
+        evs.append(e)
+    L.check(L.event_record(evs[0], stream))
+    for i, (fn, args) in enumerate(lst):
+        rc = fn(*args, stream)
+        if rc:
+            raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
+        L.check(L.event_record(evs[i + 1], stream))
+    L.check(L.event_sync(evs[-1]))
+    out = []
+    for i, (fn, args) in enumerate(lst):
+        ms = ctypes.c_float()
+        L.check(L.event_elapsed_ms(evs[i], evs[i + 1], ctypes.byref(ms)))
+        out.append((getattr(fn, "__name__", str(fn)), ms.value, args))
+    for e in evs:
+        L.event_destroy(e)
+    return out

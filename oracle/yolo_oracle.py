@@ -256,6 +256,8 @@ class DarknetOracle:
             self.layers.append(info)
             chans.append(filters)
         self.params = {}
+        self.keep_outs = False          # debugging aid: keep per-layer outputs (and their grads) of the last forward
+        self.last_outs = None
         if seed is not None:
             self.init_params(seed)
 
@@ -311,7 +313,10 @@ class DarknetOracle:
                 else:
                     x = r
                 heads.append(x)
+            if self.keep_outs and x.requires_grad:
+                x.retain_grad()
             outs.append(x)
+        self.last_outs = outs if self.keep_outs else None
         if targets is not None:
             return (sum(heads), *total_parts)
         return torch.cat(heads, 1)

@@ -216,8 +216,9 @@ def test_bn_act_fwd_bwd(dt, C, act, dual, resid):
         partial = torch.stack((yf.sum(0), (yf * yf).sum(0))).reshape(1, 2, C).contiguous()
         accum = torch.zeros(3 * C, dtype=torch.float64, device="cuda")
         bufs = [torch.zeros(C, device="cuda") for _ in range(4)]
+        gd, bd = gam.cuda(), bet.cuda()          # keep alive: the kernels are asynchronous
         L.check(L.partial_reduce(partial.data_ptr(), 1, 2, C, accum.data_ptr(), st()))
-        L.check(L.bn_finalize(accum.data_ptr(), float(M), gam.cuda().data_ptr(), bet.cuda().data_ptr(), rmean.data_ptr(), rvar.data_ptr(), 0.1, 1e-5,
+        L.check(L.bn_finalize(accum.data_ptr(), float(M), gd.data_ptr(), bd.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), 0.1, 1e-5,
                               *[b.data_ptr() for b in bufs], C, st()))
         assert float(accum.abs().max()) == 0.0
         return yb, accum, bufs
@@ -245,8 +246,10 @@ def test_bn_act_fwd_bwd(dt, C, act, dual, resid):
     order.append((1, gam1, m1, i1, 1))
     for kx, gam, mm, ii, zero in order:
         bufs = [torch.zeros(C, device="cuda") for _ in range(5)]
-        L.check(L.bn_bwd_finalize(acc.data_ptr(), kx, nsums, zero, float(M), gam.cuda().data_ptr(), mm.data_ptr(), ii.data_ptr(),
+        gd = gam.cuda()
+        L.check(L.bn_bwd_finalize(acc.data_ptr(), kx, nsums, zero, float(M), gd.data_ptr(), mm.data_ptr(), ii.data_ptr(),
                                   *[b.data_ptr() for b in bufs], C, st()))
+        torch.cuda.synchronize()
         outs[kx] = bufs
     assert float(acc.abs().max()) == 0.0
     dy1 = torch.empty(B, H, W, C, dtype=TD[dt], device="cuda")
@@ -313,7 +316,7 @@ def test_adam_sgd_match_torch():
     for step in (1, 2, 3):
         p.grad = gr.clone()
         opt.step()
-        L.check(L.sgd_step(pd.data_ptr(), gr.cuda().data_ptr(), buf.data_ptr(), n, step, 1e-2, 0.9, 0.0, 1.0, st()))
+        L.check(L.sgd_step(pd.data_ptr(), gd.data_ptr(), buf.data_ptr(), n, step, 1e-2, 0.9, 0.0, 1.0, st()))
     np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-6)
 
 
