@@ -96,6 +96,9 @@ def conv_flops(args):
     return 2.0 * B * Hin * Win * Cin * KH * KW * Nout          # dgrad: one MAC per (dy pixel, tap, ci, co), stride-independent
 
 
+LAUNCH_DUMP = []
+
+
 def kernel_breakdown(model, plan, step_fn):
     """One extra, untimed step with a HIP event after every launch (on the launch stream): per-kernel time and the
     dominant kernel's achieved rate."""
@@ -109,6 +112,9 @@ def kernel_breakdown(model, plan, step_fn):
             r[1] += ms
             if name == "mdcv_conv2d":
                 r[2] += conv_flops(args)
+                LAUNCH_DUMP.append((name, ms, [int(v) if isinstance(v, int) else 0 for v in args[11:23]] + [int(args[1])]))
+            elif name.startswith("mdcv_bn_act") or name in ("mdcv_partial_reduce",):
+                LAUNCH_DUMP.append((name, ms, [int(v) for v in args if isinstance(v, int) and 0 < v < (1 << 31)][-6:]))
     orig_run = plan.run
 
     def run_and_time(lst, stream=None):
@@ -199,6 +205,8 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MDCV_GRAPH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--dump-launches", default="")
+    ap.add_argument("--cpu-threads", type=int, default=0)
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -324,6 +332,9 @@ def main():
             if a.workload == "both":
                 line["workloads"]["rektnet"]["cpu_baseline"] = cpu_baseline_rektnet()
         print(json.dumps(line))
+    if rank == 0 and a.dump_launches:
+        with open(a.dump_launches, "w") as f:
+            json.dump(LAUNCH_DUMP, f)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
