@@ -113,6 +113,8 @@ def kernel_breakdown(model, plan, step_fn):
             if name == "mdcv_conv2d":
                 r[2] += conv_flops(args)
                 LAUNCH_DUMP.append((name, ms, [int(v) if isinstance(v, int) else 0 for v in args[11:23]] + [int(args[1])]))
+            elif name == "conv2d_wgrad":
+                LAUNCH_DUMP.append((name, ms, list(args)))
             elif name.startswith("mdcv_bn_act") or name in ("mdcv_partial_reduce",):
                 LAUNCH_DUMP.append((name, ms, [int(v) for v in args if isinstance(v, int) and 0 < v < (1 << 31)][-6:]))
     orig_run = plan.run
@@ -135,10 +137,14 @@ def wgrad_flops_total(model):
     return None
 
 
+CPU_THREADS = 16     # measured on the GPU box host (256 logical cores): torch-CPU conv training peaks at 16 threads for these
+                     # batch sizes (8: 0.082 s, 16: 0.053 s, 32: 0.103 s, 64: 0.20 s, 128: 0.6 s, 256: >10 s per RektNet B=8 step)
+
+
 def cpu_baseline_yolo(cfg_path, workdir, budget_s=25.0):
     """CPU oracle ("port": plain torch-CPU restatement of the reference, pinned to it by tests/golden) on the host cores."""
     from oracle import yolo_oracle as yo
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), CPU_THREADS))
     cwd = os.getcwd()
     os.chdir(workdir)
     try:
@@ -169,7 +175,7 @@ def cpu_baseline_yolo(cfg_path, workdir, budget_s=25.0):
 
 def cpu_baseline_rektnet(budget_s=12.0):
     from oracle import rektnet_oracle as ro
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), CPU_THREADS))
     sd = ro.init_state(0)
     params = [v.requires_grad_(True) for k, v in sd.items() if "running" not in k]
     opt = torch.optim.Adam(params, lr=0.1)
@@ -208,6 +214,9 @@ def main():
     ap.add_argument("--dump-launches", default="")
     ap.add_argument("--cpu-threads", type=int, default=0)
     a = ap.parse_args()
+    global CPU_THREADS
+    if a.cpu_threads:
+        CPU_THREADS = a.cpu_threads
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -59,9 +59,11 @@ int mdcv_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 /* out = act(y1*s1+b1 [+ y2*s2+b2]) [+ resid] */
 int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const float* b1, const void* y2, int ld2, const float* s2,
                     const float* b2, const void* resid, int ldr, void* out, int ldo, int M, int C, int act, float slope, void* stream);
+int mdcv_bn_act_bwd_reduce_ws_floats(int dtype, int M, int C, int nsums);
 int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,
                            const float* mean1, const float* invstd1, const void* y2, int ld2, const float* s2, const float* b2,
-                           const float* mean2, const float* invstd2, double* accum, int M, int C, int act, float slope, void* stream);
+                           const float* mean2, const float* invstd2, double* accum, float* partial_ws, int M, int C, int act, float slope,
+                           void* stream);
 int mdcv_bn_bwd_finalize(double* accum, int kx, int nsums, int zero_after, double count, const float* gamma, const float* mean,
                          const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int C, void* stream);
 int mdcv_bn_act_bwd_apply(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,

@@ -419,18 +419,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   (void)PIPE;
 }
 
-// slabs -> OIHW fp32 gradient (real Cin, i.e. without channel padding)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int Cout_pad,
-                                    int Cout, int Cin_real, int Cin_pad, int KK, int Ktot, int accumulate) {
-  const int total = Cout * Cin_real * KK;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int co = e / (Cin_real * KK), rem = e - co * (Cin_real * KK);
-    const int ci = rem / KK, t = rem - ci * KK;
-    const float* p = ws + (size_t)co * Ktot + t * Cin_pad + ci;
-    const size_t slab = (size_t)Cout_pad * Ktot;
+// slabs -> OIHW fp32 gradient (real Cin, i.e. without channel padding).
+// One block per (co, chunk of 64 input channels): slab rows [tap][ci] are read coalesced along ci and summed over the
+// splits, transposed through LDS, and written as the contiguous OIHW run [ci0..ci0+63][tap].
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int Cout_pad,
+                                                           int Cin_real, int Cin_pad, int KK, int Ktot, int accumulate) {
+  extern __shared__ float tile[];                       // [KK][65]
+  const int co = blockIdx.x, ci0 = blockIdx.y * 64;
+  const int nci = min(64, Cin_real - ci0);
+  const size_t slab = (size_t)Cout_pad * Ktot;
+  const float* row = ws + (size_t)co * Ktot;
+  for (int i = threadIdx.x; i < KK * 64; i += 256) {
+    const int t = i >> 6, c = i & 63;
     float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += p[sp * slab];
-    dw[e] = accumulate ? dw[e] + s : s;
+    if (c < nci) {
+      const float* p = row + t * Cin_pad + ci0 + c;
+      for (int sp = 0; sp < splits; ++sp) s += p[sp * slab];
+    }
+    tile[t * 65 + c] = s;
+  }
+  __syncthreads();
+  float* out = dw + ((size_t)co * Cin_real + ci0) * KK;
+  for (int i = threadIdx.x; i < nci * KK; i += 256) {
+    const int c = i / KK, t = i - c * KK;
+    const float v = tile[t * 65 + c];
+    out[i] = accumulate ? out[i] + v : v;
   }
 }
 
@@ -531,9 +544,8 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   const int KK = KH * KW;
-  const int total = Cout_real * Cin_real * KK;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)min(cdiv(total, 256), 4096)), dim3(256), 0, st, ws, dw_oihw, splits, Cout,
-                     Cout_real, Cin_real, Cin, KK, a.Ktot, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)Cout_real, (unsigned)cdiv(Cin_real, 64)), dim3(256), KK * 65 * 4, st, ws, dw_oihw,
+                     splits, Cout, Cin_real, Cin, KK, a.Ktot, accumulate);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -25,6 +25,61 @@ template <typename T> static Strip make_strip(int M, int C, int target_blocks) {
   return s;
 }
 
+// reduction kernels end in one fp64 atomic per channel per block: keep (blocks x channels x sums) within a budget
+static int reduce_blocks(int C, int nsums) {
+  long long g = 131072LL / ((long long)C * nsums);
+  if (g > 1024) g = 1024;
+  if (g < 16) g = 16;
+  return (int)g;
+}
+
+// fold the per-thread channel-vector sums of a block: lanes that own the same channel vector are CV apart.
+// Requires 256 % CV == 0.  red: 256*VEC floats.  Result: threads tid < CV hold the block total for vector tid in v[].
+template <int VEC>
+__device__ __forceinline__ void block_fold(float (&v)[VEC], int CV, float* red, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  if (CV < 64) {
+    for (int off = 32; off >= CV; off >>= 1) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] += __shfl_xor(v[e], off, 64);
+    }
+  }
+  const int span = CV < 64 ? CV : 64;
+  __syncthreads();
+  if (lane < span) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[(wave * 64 + lane) * VEC + e] = v[e];
+  }
+  __syncthreads();
+  if (tid < CV) {
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      if (CV > 64 && ((w * 64) % CV) != (tid & ~63)) continue;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s[e] += red[(w * 64 + (tid & 63)) * VEC + e];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = s[e];
+  }
+}
+
+// VEC consecutive per-channel coefficients as 16-byte loads (arrays are 16-byte aligned, c0 is a multiple of VEC)
+template <int VEC>
+__device__ __forceinline__ void ldcoef(const float* __restrict__ p, int c0, float (&o)[VEC], float dflt) {
+  if (!p) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = dflt;
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < VEC / 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(p + c0 + 4 * q);
+    o[4 * q] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
+  }
+}
+
 __device__ __forceinline__ float act_fwd(float v, int act, float slope) { return act == 0 ? v : (v > 0.f ? v : v * slope); }
 __device__ __forceinline__ float act_grad(float pre, int act, float slope) { return act == 0 ? 1.f : (pre > 0.f ? 1.f : slope); }
 
@@ -63,14 +118,20 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
 
 // ---------------------------------------------------------------- BatchNorm statistics
 // partial[rows][nsums][C] (fp32, from the conv epilogue) -> accum[nsums][C] (fp64)
-__global__ void partial_reduce_kernel(const float* __restrict__ partial, int rows, int nsums, int C, double* __restrict__ accum, int rows_per_block) {
-  const int cols = nsums * C;
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-    double s = 0.0;
-    for (int r = r0; r < r1; ++r) s += (double)partial[(size_t)r * cols + c];
-    atomicAdd(&accum[c], s);
+// block = 64 columns x 4 row lanes, each block covers 128 rows: coalesced 256-byte row reads, one atomic per column per block
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int rows, int cols, double* __restrict__ accum) {
+  __shared__ double red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const int r0 = blockIdx.y * 128;
+  double s = 0.0;
+  if (c < cols) {
+    const int r1 = min(rows, r0 + 128);
+    for (int r = r0 + ry; r < r1; r += 4) s += (double)partial[(size_t)r * cols + c];
   }
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < cols) atomicAdd(&accum[c], red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
 }
 
 // accum[0]=sum, accum[1]=sumsq over `count` samples per channel -> batch mean / biased var -> scale, shift ; running stats
@@ -121,36 +182,47 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs a) {
   if (tid >= a.PPI * a.CV) return;
   const int cv = tid % a.CV, pi = tid / a.CV;
   float s1[VEC], b1[VEC], s2[VEC], b2[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    const int c = cv * VEC + e;
-    s1[e] = a.s1 ? a.s1[c] : 1.f; b1[e] = a.s1 ? a.b1[c] : 0.f;
-    s2[e] = a.y2 ? a.s2[c] : 0.f; b2[e] = a.y2 ? a.b2[c] : 0.f;
-  }
+  ldcoef<VEC>(a.s1, cv * VEC, s1, 1.f); ldcoef<VEC>(a.s1 ? a.b1 : nullptr, cv * VEC, b1, 0.f);
+  ldcoef<VEC>(a.y2 ? a.s2 : nullptr, cv * VEC, s2, 0.f); ldcoef<VEC>(a.y2 ? a.b2 : nullptr, cv * VEC, b2, 0.f);
   const long long p0 = (long long)blockIdx.x * a.PB;
   const long long p1 = min((long long)a.M, p0 + a.PB);
   const T* y1 = reinterpret_cast<const T*>(a.y1);
   const T* y2 = reinterpret_cast<const T*>(a.y2);
   const T* rs = reinterpret_cast<const T*>(a.resid);
   T* out = reinterpret_cast<T*>(a.out);
-  for (long long p = p0 + pi; p < p1; p += a.PPI) {
-    float v[VEC], w[VEC];
-    ET<T>::unpack(*reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC), v);
+  for (long long pb = p0 + pi; pb < p1; pb += 4 * a.PPI) {
+    uint4 q1[4], q2[4], qr[4];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = v[e] * s1[e] + b1[e];
-    if (y2) {
-      ET<T>::unpack(*reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC), w);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] += w[e] * s2[e] + b2[e];
+    for (int u = 0; u < 4; ++u) {
+      const long long p = pb + (long long)u * a.PPI;
+      if (p < p1) {
+        q1[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
+        if (y2) q2[u] = *reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC);
+        if (rs) qr[u] = *reinterpret_cast<const uint4*>(rs + p * a.ldr + cv * VEC);
+      }
     }
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = act_fwd(v[e], a.act, a.slope);
-    if (rs) {
-      ET<T>::unpack(*reinterpret_cast<const uint4*>(rs + p * a.ldr + cv * VEC), w);
+    for (int u = 0; u < 4; ++u) {
+      const long long p = pb + (long long)u * a.PPI;
+      if (p >= p1) break;
+      float v[VEC], w[VEC];
+      ET<T>::unpack(q1[u], v);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] += w[e];
+      for (int e = 0; e < VEC; ++e) v[e] = v[e] * s1[e] + b1[e];
+      if (y2) {
+        ET<T>::unpack(q2[u], w);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += w[e] * s2[e] + b2[e];
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = act_fwd(v[e], a.act, a.slope);
+      if (rs) {
+        ET<T>::unpack(qr[u], w);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += w[e];
+      }
+      *reinterpret_cast<uint4*>(out + p * a.ldo + cv * VEC) = ET<T>::pack(v);
     }
-    *reinterpret_cast<uint4*>(out + p * a.ldo + cv * VEC) = ET<T>::pack(v);
   }
 }
 
@@ -160,25 +232,22 @@ struct BnBwdArgs {
   const float* s1; const float* b1; const float* m1; const float* is1;
   const float* s2; const float* b2; const float* m2; const float* is2;
   const float* cA1; const float* cB1; const float* cC1; const float* cA2; const float* cB2; const float* cC2;
-  double* accum;
+  double* accum; float* partial;
   int ldd, ld1, ld2, ldy1, ldy2, M, C, act, PB, CV, PPI;
   float slope;
 };
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdArgs a) {
   constexpr int VEC = ET<T>::VEC;
-  __shared__ float red[256 * 12];
+  __shared__ float red[256 * VEC];
   const int tid = threadIdx.x;
   const bool active = tid < a.PPI * a.CV;
   const int cv = active ? tid % a.CV : 0, pi = active ? tid / a.CV : 0;
   const int nsum = a.y2 ? 3 : 2;
   float s1[VEC], b1[VEC], m1[VEC], i1[VEC], s2[VEC], b2[VEC], m2[VEC], i2[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    const int c = cv * VEC + e;
-    s1[e] = a.s1[c]; b1[e] = a.b1[c]; m1[e] = a.m1[c]; i1[e] = a.is1[c];
-    s2[e] = a.y2 ? a.s2[c] : 0.f; b2[e] = a.y2 ? a.b2[c] : 0.f; m2[e] = a.y2 ? a.m2[c] : 0.f; i2[e] = a.y2 ? a.is2[c] : 0.f;
-  }
+  ldcoef<VEC>(a.s1, cv * VEC, s1, 1.f); ldcoef<VEC>(a.b1, cv * VEC, b1, 0.f); ldcoef<VEC>(a.m1, cv * VEC, m1, 0.f); ldcoef<VEC>(a.is1, cv * VEC, i1, 0.f);
+  ldcoef<VEC>(a.y2 ? a.s2 : nullptr, cv * VEC, s2, 0.f); ldcoef<VEC>(a.y2 ? a.b2 : nullptr, cv * VEC, b2, 0.f);
+  ldcoef<VEC>(a.y2 ? a.m2 : nullptr, cv * VEC, m2, 0.f); ldcoef<VEC>(a.y2 ? a.is2 : nullptr, cv * VEC, i2, 0.f);
   float sg[VEC], sx1[VEC], sx2[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { sg[e] = 0.f; sx1[e] = 0.f; sx2[e] = 0.f; }
@@ -188,11 +257,24 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdArgs a) {
   const T* y1 = reinterpret_cast<const T*>(a.y1);
   const T* y2 = reinterpret_cast<const T*>(a.y2);
   if (active)
-    for (long long p = p0 + pi; p < p1; p += a.PPI) {
+    for (long long pb = p0 + pi; pb < p1; pb += 4 * a.PPI) {
+      uint4 qd[4], qv[4], qw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                     // issue all loads of 4 pixels before touching any
+        const long long p = pb + (long long)u * a.PPI;
+        if (p < p1) {
+          qd[u] = *reinterpret_cast<const uint4*>(dout + p * a.ldd + cv * VEC);
+          qv[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
+          if (y2) qw[u] = *reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+      if (pb + (long long)u * a.PPI >= p1) break;
       float d[VEC], v[VEC], w[VEC];
-      ET<T>::unpack(*reinterpret_cast<const uint4*>(dout + p * a.ldd + cv * VEC), d);
-      ET<T>::unpack(*reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC), v);
-      if (y2) ET<T>::unpack(*reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC), w);
+      ET<T>::unpack(qd[u], d);
+      ET<T>::unpack(qv[u], v);
+      if (y2) ET<T>::unpack(qw[u], w);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float pre = v[e] * s1[e] + b1[e];
@@ -202,42 +284,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdArgs a) {
         sx1[e] += g * (v[e] - m1[e]) * i1[e];
         if (y2) sx2[e] += g * (w[e] - m2[e]) * i2[e];
       }
-    }
-  // fold the PPI pixel-lanes that share a channel vector
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    red[tid * 12 + e] = sg[e];
-    if (VEC == 4) { red[tid * 12 + 4 + e] = sx1[e]; red[tid * 12 + 8 + e] = sx2[e]; }
-  }
-  __syncthreads();
-  if (VEC == 4) {
-    if (active && pi == 0) {
-      for (int k = 0; k < nsum; ++k)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float s = 0.f;
-          for (int q = 0; q < a.PPI; ++q) s += red[(q * a.CV + cv) * 12 + k * 4 + e];
-          atomicAdd(&a.accum[(size_t)k * a.C + cv * VEC + e], (double)s);
-        }
-    }
-  } else {
-    // VEC == 8: three rounds through the 12-float slots (8 used)
-    for (int k = 0; k < nsum; ++k) {
-      if (k > 0) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) red[tid * 12 + e] = k == 1 ? sx1[e] : sx2[e];
-        __syncthreads();
-      }
-      if (active && pi == 0) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float s = 0.f;
-          for (int q = 0; q < a.PPI; ++q) s += red[(q * a.CV + cv) * 12 + e];
-          atomicAdd(&a.accum[(size_t)k * a.C + cv * VEC + e], (double)s);
-        }
       }
     }
+  // fold the PPI pixel-lanes that share a channel vector; one partial row [nsum][C] per block (summed by partial_reduce)
+  float* prow = a.partial + (size_t)blockIdx.x * nsum * a.C;
+  block_fold<VEC>(sg, a.CV, red, tid);
+  if (tid < a.CV) *reinterpret_cast<uint4*>(prow + tid * VEC) = ET<float>::pack(sg), (VEC == 8 ? (void)(*reinterpret_cast<uint4*>(prow + tid * VEC + 4) = ET<float>::pack(sg + 4)) : (void)0);
+  block_fold<VEC>(sx1, a.CV, red, tid);
+  if (tid < a.CV) *reinterpret_cast<uint4*>(prow + a.C + tid * VEC) = ET<float>::pack(sx1), (VEC == 8 ? (void)(*reinterpret_cast<uint4*>(prow + a.C + tid * VEC + 4) = ET<float>::pack(sx1 + 4)) : (void)0);
+  if (nsum == 3) {
+    block_fold<VEC>(sx2, a.CV, red, tid);
+    if (tid < a.CV) *reinterpret_cast<uint4*>(prow + 2 * a.C + tid * VEC) = ET<float>::pack(sx2), (VEC == 8 ? (void)(*reinterpret_cast<uint4*>(prow + 2 * a.C + tid * VEC + 4) = ET<float>::pack(sx2 + 4)) : (void)0);
   }
 }
 
@@ -268,13 +325,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnBwdArgs a) {
   if (tid >= a.PPI * a.CV) return;
   const int cv = tid % a.CV, pi = tid / a.CV;
   float s1[VEC], b1[VEC], s2[VEC], b2[VEC], A1[VEC], B1[VEC], C1[VEC], A2[VEC], B2[VEC], C2[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    const int c = cv * VEC + e;
-    s1[e] = a.s1[c]; b1[e] = a.b1[c]; A1[e] = a.cA1[c]; B1[e] = a.cB1[c]; C1[e] = a.cC1[c];
-    s2[e] = a.y2 ? a.s2[c] : 0.f; b2[e] = a.y2 ? a.b2[c] : 0.f;
-    A2[e] = a.y2 ? a.cA2[c] : 0.f; B2[e] = a.y2 ? a.cB2[c] : 0.f; C2[e] = a.y2 ? a.cC2[c] : 0.f;
-  }
+  ldcoef<VEC>(a.s1, cv * VEC, s1, 1.f); ldcoef<VEC>(a.b1, cv * VEC, b1, 0.f);
+  ldcoef<VEC>(a.cA1, cv * VEC, A1, 0.f); ldcoef<VEC>(a.cB1, cv * VEC, B1, 0.f); ldcoef<VEC>(a.cC1, cv * VEC, C1, 0.f);
+  ldcoef<VEC>(a.y2 ? a.s2 : nullptr, cv * VEC, s2, 0.f); ldcoef<VEC>(a.y2 ? a.b2 : nullptr, cv * VEC, b2, 0.f);
+  ldcoef<VEC>(a.y2 ? a.cA2 : nullptr, cv * VEC, A2, 0.f); ldcoef<VEC>(a.y2 ? a.cB2 : nullptr, cv * VEC, B2, 0.f);
+  ldcoef<VEC>(a.y2 ? a.cC2 : nullptr, cv * VEC, C2, 0.f);
   const long long p0 = (long long)blockIdx.x * a.PB;
   const long long p1 = min((long long)a.M, p0 + a.PB);
   const T* dout = reinterpret_cast<const T*>(a.dout);
@@ -282,21 +337,36 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnBwdArgs a) {
   const T* y2 = reinterpret_cast<const T*>(a.y2);
   T* dy1 = reinterpret_cast<T*>(a.dy1);
   T* dy2 = reinterpret_cast<T*>(a.dy2);
-  for (long long p = p0 + pi; p < p1; p += a.PPI) {
-    float d[VEC], v[VEC], w[VEC], o1[VEC], o2[VEC];
-    ET<T>::unpack(*reinterpret_cast<const uint4*>(dout + p * a.ldd + cv * VEC), d);
-    ET<T>::unpack(*reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC), v);
-    if (y2) ET<T>::unpack(*reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC), w);
+  for (long long pb = p0 + pi; pb < p1; pb += 4 * a.PPI) {
+    uint4 qd[4], qv[4], qw[4];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float pre = v[e] * s1[e] + b1[e];
-      if (y2) pre += w[e] * s2[e] + b2[e];
-      const float g = d[e] * act_grad(pre, a.act, a.slope);
-      o1[e] = A1[e] * g + B1[e] * v[e] + C1[e];
-      if (y2) o2[e] = A2[e] * g + B2[e] * w[e] + C2[e];
+    for (int u = 0; u < 4; ++u) {
+      const long long p = pb + (long long)u * a.PPI;
+      if (p < p1) {
+        qd[u] = *reinterpret_cast<const uint4*>(dout + p * a.ldd + cv * VEC);
+        qv[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
+        if (y2) qw[u] = *reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC);
+      }
     }
-    *reinterpret_cast<uint4*>(dy1 + p * a.ldy1 + cv * VEC) = ET<T>::pack(o1);
-    if (y2) *reinterpret_cast<uint4*>(dy2 + p * a.ldy2 + cv * VEC) = ET<T>::pack(o2);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long p = pb + (long long)u * a.PPI;
+      if (p >= p1) break;
+      float d[VEC], v[VEC], w[VEC], o1[VEC], o2[VEC];
+      ET<T>::unpack(qd[u], d);
+      ET<T>::unpack(qv[u], v);
+      if (y2) ET<T>::unpack(qw[u], w);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float pre = v[e] * s1[e] + b1[e];
+        if (y2) pre += w[e] * s2[e] + b2[e];
+        const float g = d[e] * act_grad(pre, a.act, a.slope);
+        o1[e] = A1[e] * g + B1[e] * v[e] + C1[e];
+        if (y2) o2[e] = A2[e] * g + B2[e] * w[e] + C2[e];
+      }
+      *reinterpret_cast<uint4*>(dy1 + p * a.ldy1 + cv * VEC) = ET<T>::pack(o1);
+      if (y2) *reinterpret_cast<uint4*>(dy2 + p * a.ldy2 + cv * VEC) = ET<T>::pack(o2);
+    }
   }
 }
 
@@ -417,8 +487,9 @@ int mdcv_nhwc_to_nchw(int dtype, const void* src, int ldc, float* dst, int B, in
 
 int mdcv_partial_reduce(const float* partial, int rows, int nsums, int C, double* accum, void* stream) {
   if (!partial || !accum || rows < 1) return MDCV_EARG;
-  const int rpb = 64;
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, partial, rows, nsums, C, accum, rpb);
+  const int cols = nsums * C;
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(cols, 64), (unsigned)cdiv(rows, 128)), dim3(256), 0, (hipStream_t)stream,
+                     partial, rows, cols, accum);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -449,11 +520,11 @@ int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const f
   a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr; a.ldo = ldo; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MDCV_BF16) {
-    Strip s = make_strip<bf16_t>(M, C, 4096); if (s.CV > 256) return MDCV_EARG;
+    Strip s = make_strip<bf16_t>(M, C, 2048); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
     hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
-    Strip s = make_strip<float>(M, C, 4096); if (s.CV > 256) return MDCV_EARG;
+    Strip s = make_strip<float>(M, C, 2048); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
     hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else return MDCV_EARG;
@@ -461,24 +532,36 @@ int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const f
   return MDCV_OK;
 }
 
+// floats of scratch mdcv_bn_act_bwd_reduce needs (one [nsums][C] partial row per block)
+int mdcv_bn_act_bwd_reduce_ws_floats(int dtype, int M, int C, int nsums) {
+  const Strip s = dtype == MDCV_BF16 ? make_strip<bf16_t>(M, C, reduce_blocks(C, nsums)) : make_strip<float>(M, C, reduce_blocks(C, nsums));
+  return cdiv(M, s.PB) * nsums * C;
+}
+
 // pass 1 of the BN(+act) backward: accum[0] += sum g ; accum[1] += sum g*xhat1 ; accum[2] += sum g*xhat2 (if y2)
 int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,
                            const float* mean1, const float* invstd1, const void* y2, int ld2, const float* s2, const float* b2,
-                           const float* mean2, const float* invstd2, double* accum, int M, int C, int act, float slope, void* stream) {
-  if (!dout || !y1 || !accum || (C & 7)) return MDCV_EARG;
+                           const float* mean2, const float* invstd2, double* accum, float* partial_ws, int M, int C, int act, float slope,
+                           void* stream) {
+  if (!dout || !y1 || !accum || !partial_ws || (C & 7)) return MDCV_EARG;
   BnBwdArgs a = {};
   a.dout = dout; a.y1 = y1; a.y2 = y2; a.s1 = s1; a.b1 = b1; a.m1 = mean1; a.is1 = invstd1; a.s2 = s2; a.b2 = b2; a.m2 = mean2; a.is2 = invstd2;
-  a.accum = accum; a.ldd = ldd; a.ld1 = ld1; a.ld2 = ld2; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
+  a.accum = accum; a.partial = partial_ws; a.ldd = ldd; a.ld1 = ld1; a.ld2 = ld2; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
   hipStream_t st = (hipStream_t)stream;
+  const int nsums = y2 ? 3 : 2;
+  int rows = 0;
   if (dtype == MDCV_BF16) {
-    Strip s = make_strip<bf16_t>(M, C, 1024); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
-    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+    Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, nsums)); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
+    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
-    Strip s = make_strip<float>(M, C, 1024); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
-    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+    Strip s = make_strip<float>(M, C, reduce_blocks(C, nsums)); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
+    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, a);
   } else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  const int cols = nsums * C;
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(cols, 64), (unsigned)cdiv(rows, 128)), dim3(256), 0, st, partial_ws, rows, cols, accum);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -503,11 +586,11 @@ int mdcv_bn_act_bwd_apply(int dtype, const void* dout, int ldd, const void* y1, 
   a.ldd = ldd; a.ld1 = ld1; a.ld2 = ld2; a.ldy1 = ldy1; a.ldy2 = ldy2; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MDCV_BF16) {
-    Strip s = make_strip<bf16_t>(M, C, 4096); if (s.CV > 256) return MDCV_EARG;
+    Strip s = make_strip<bf16_t>(M, C, 2048); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
-    Strip s = make_strip<float>(M, C, 4096); if (s.CV > 256) return MDCV_EARG;
+    Strip s = make_strip<float>(M, C, 2048); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else return MDCV_EARG;
@@ -519,10 +602,10 @@ int mdcv_colsum(int dtype, const void* x, int ldc, int M, int C, double* accum, 
   if (!x || !accum || (C & 7)) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MDCV_BF16) {
-    Strip s = make_strip<bf16_t>(M, C, 1024); if (s.CV > 256) return MDCV_EARG;
+    Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, 1)); if (s.CV > 256) return MDCV_EARG;
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, (const bf16_t*)x, ldc, M, C, accum, s.PB, s.CV, s.PPI);
   } else if (dtype == MDCV_F32) {
-    Strip s = make_strip<float>(M, C, 1024); if (s.CV > 256) return MDCV_EARG;
+    Strip s = make_strip<float>(M, C, reduce_blocks(C, 1)); if (s.CV > 256) return MDCV_EARG;
     hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, (const float*)x, ldc, M, C, accum, s.PB, s.CV, s.PPI);
   } else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();

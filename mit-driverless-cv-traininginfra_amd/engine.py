@@ -234,6 +234,7 @@ class Plan:
                                   x.B, x.H, x.W, cs.cin_pad, cs.cin, dy.H, dy.W, cs.cout_pad, cs.cout, cs.kh, cs.kw,
                                   cs.stride, cs.pad, cs.dil, stream)
         wgrad.__name__ = "conv2d_wgrad"
+        wgrad.info = (x.B, x.H, x.W, cs.cin_pad, dy.H, dy.W, cs.cout_pad, cs.kh, cs.stride, splits)
         self.bwd.append((wgrad, ()))
         if xnode.needs_grad:
             out, add = self.grad_target(xnode)
@@ -289,10 +290,11 @@ class Plan:
         dy1 = self._alloc_like(y1)
         dy2 = self._alloc_like(y2) if y2 is not None else None
         n = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        pws = self.f32(L.bn_act_bwd_reduce_ws_floats(dt, y1.M, y1.C, 3 if y2 is not None else 2), zero=False)
         self.call(self.bwd, L.bn_act_bwd_reduce, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.mean),
                   n(bs1.invstd), y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
                   n(bs2.scale) if bs2 else None, n(bs2.shift) if bs2 else None, n(bs2.mean) if bs2 else None,
-                  n(bs2.invstd) if bs2 else None, bs1.accum.data_ptr(), y1.M, y1.C, act, float(slope))
+                  n(bs2.invstd) if bs2 else None, bs1.accum.data_ptr(), pws.data_ptr(), y1.M, y1.C, act, float(slope))
         nsums = 3 if y2 is not None else 2
         g1, b1 = self.param_grad(bs1.bn.weight), self.param_grad(bs1.bn.bias)
         if y2 is not None:
@@ -349,7 +351,7 @@ def run_timed(plan, lst, stream=None):
     for i, (fn, args) in enumerate(lst):
         ms = ctypes.c_float()
         L.check(L.event_elapsed_ms(evs[i], evs[i + 1], ctypes.byref(ms)))
-        out.append((getattr(fn, "__name__", str(fn)), ms.value, args))
+        out.append((getattr(fn, "__name__", str(fn)), ms.value, args if args else getattr(fn, "info", ())))
     for e in evs:
         L.event_destroy(e)
     return out

@@ -237,9 +237,10 @@ def test_bn_act_fwd_bwd(dt, C, act, dual, resid):
     np.testing.assert_allclose(to_nchw(out, dt, C).numpy(), z.detach().numpy(), **tol)
     # backward
     db = to_nhwc(dout, dt)
+    pws = torch.empty(L.bn_act_bwd_reduce_ws_floats(dt, M, C, 3 if dual else 2), device="cuda")
     L.check(L.bn_act_bwd_reduce(dt, db.data_ptr(), C, y1b.data_ptr(), C, s1.data_ptr(), b1.data_ptr(), m1.data_ptr(), i1.data_ptr(),
                                 P(y2b) if dual else None, C, P(s2) if dual else None, P(b2) if dual else None, P(m2) if dual else None,
-                                P(i2) if dual else None, acc.data_ptr(), M, C, act, slope, st()))
+                                P(i2) if dual else None, acc.data_ptr(), pws.data_ptr(), M, C, act, slope, st()))
     outs = {}
     nsums = 3 if dual else 2
     order = [(2, gam2, m2, i2, 0)] if dual else []
