@@ -35,6 +35,7 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
                 int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
                 int KH, int KW, int stride, int pad, int dil, void* stream);
 int mdcv_conv2d_stats_rows(int M);
+int mdcv_conv2d_set_variant(int v);   /* tuning hook: force a tile configuration for Nout > 64 (-1 = heuristic) */
 
 /* weight gradient: dW (OIHW fp32, real channel counts) = dY^T * im2col(X).  ws = splits*Cout*KH*KW*Cin floats of scratch. */
 int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot);

@@ -19,43 +19,47 @@
 
 namespace {
 
-constexpr int ROWB = 80;  // LDS bytes per tile row (64 payload + 16 pad)
+constexpr int ROWB = 80;  // LDS bytes per tile row of the wgrad kernel (64 payload + 16 pad)
 
 struct ConvArgs {
   const void* in; const void* w; void* out; const float* bias; const void* addsrc; float* stats;
   int in_ldc, out_ldc, add_ldc;
   int Hin, Win, Cin, Hout, Wout, Nout;
   int KH, KW, stride, pad, dil;
-  int M, Ktot, tiles_n, sshift;
+  int M, Ktot, tiles_n, sshift, tiles_total, xcd_chunk;
 };
 
+// One K tile of MFMAs for a wave: FM x FN fragments of 16x16, KT k-steps of 64 bytes per LDS row (row pitch RB bytes).
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
-  template <int FM, int FN>
+  template <int FM, int FN, int KT, int RB>
   __device__ static __forceinline__ void mma(const unsigned char* sa, const unsigned char* sb, int lane, f32x4_t (&acc)[FM][FN]) {
-    bf16x8_t a[FM], b[FN];
-    const int off = (lane & 15) * ROWB + (lane >> 4) * 16;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 16 * ROWB + off);
+    for (int ks = 0; ks < KT; ++ks) {
+      bf16x8_t a[FM], b[FN];
+      const int off = (lane & 15) * RB + ks * 64 + (lane >> 4) * 16;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 16 * ROWB + off);
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 16 * RB + off);
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 16 * RB + off);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
   }
 };
 template <> struct Frag<float> {
-  template <int FM, int FN>
+  template <int FM, int FN, int KT, int RB>
   __device__ static __forceinline__ void mma(const unsigned char* sa, const unsigned char* sb, int lane, f32x4_t (&acc)[FM][FN]) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 4 * KT; ++ks) {
       float a[FM], b[FN];
-      const int off = (lane & 15) * ROWB + (ks * 4 + (lane >> 4)) * 4;
+      const int off = (lane & 15) * RB + (ks * 4 + (lane >> 4)) * 4;
 #pragma unroll
-      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const float*>(sa + i * 16 * ROWB + off);
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const float*>(sa + i * 16 * RB + off);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const float*>(sb + j * 16 * ROWB + off);
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const float*>(sb + j * 16 * RB + off);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -66,22 +70,32 @@ template <> struct Frag<float> {
 
 // MODE 0: forward gather  hi = ho*stride - pad + kh*dil
 // MODE 1: data gradient   hi = (h + pad - kh*dil) / stride when divisible   (stride is 1 or 2)
-template <typename T, int MODE, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+// Block = WM x WN waves, tile BM x BN, K tile = KT*64 bytes per row.
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int KT>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int NT = WM * WN * 64;
   constexpr int VEC = ET<T>::VEC;
-  constexpr int BK = 4 * VEC;
+  constexpr int VPR = 4 * KT;                 // 16-byte vectors per LDS row
+  constexpr int BK = VPR * VEC;
+  constexpr int RB = 64 * KT + 16;            // LDS row pitch (bytes): +16 keeps ds_read_b128 fragments conflict-light
+  constexpr int RPP = NT / VPR;               // tile rows staged per pass
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-  constexpr int NPA = BM / 64, NPB = (BN + 63) / 64;
-  constexpr int PIPE = 2 * (BM + BN) * ROWB;
+  constexpr int NPA = BM / RPP, NPB = (BN + RPP - 1) / RPP;
+  constexpr int PIPE = 2 * (BM + BN) * RB;
   constexpr int SROW = BN * (int)sizeof(T) + 16;
   constexpr int STAGE = BM * SROW;
   constexpr int STAT_OFF = PIPE > STAGE ? PIPE : STAGE;
+  static_assert(BM % RPP == 0, "tile rows must be a multiple of the staging pass");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+  // XCD-aware tile order: block b runs on XCD b%8 (observed dispatch); give every XCD one contiguous run of tiles so
+  // that the tile_n variants of a row panel and its halo neighbours share that XCD's L2.  Pure speed, not correctness.
+  const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
+  if (logical >= a.tiles_total) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = blockIdx.x / a.tiles_n, tile_n = blockIdx.x % a.tiles_n;
-  const int arow = tid >> 2, kv = tid & 3;
+  const int tile_m = logical / a.tiles_n, tile_n = logical % a.tiles_n;
+  const int arow = tid / VPR, kv = tid % VPR;
   const T* __restrict__ in = reinterpret_cast<const T*>(a.in);
   const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
 
@@ -91,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int HWo = a.Hout * a.Wout;
 #pragma unroll
   for (int p = 0; p < NPA; ++p) {
-    const int m = tile_m * BM + arow + p * 64;
+    const int m = tile_m * BM + arow + p * RPP;
     rv[p] = m < a.M;
     const int mm = rv[p] ? m : 0;
     const int img = mm / HWo, rem = mm - img * HWo;
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int k = kt * BK + kv * VEC;
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
-      const int brow = arow + p * 64;
+      const int brow = arow + p * RPP;
       const int n = tile_n * BN + brow;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (brow < BN && n < a.Nout && k < a.Ktot) v = *reinterpret_cast<const uint4*>(w + ((size_t)n * a.Ktot + k));
@@ -140,14 +154,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
   };
   auto store_tile = [&](int buf) {
-    unsigned char* sA = smem + buf * (BM + BN) * ROWB;
-    unsigned char* sB = sA + BM * ROWB;
+    unsigned char* sA = smem + buf * (BM + BN) * RB;
+    unsigned char* sB = sA + BM * RB;
 #pragma unroll
-    for (int p = 0; p < NPA; ++p) *reinterpret_cast<uint4*>(sA + (arow + p * 64) * ROWB + kv * 16) = ra[p];
+    for (int p = 0; p < NPA; ++p) *reinterpret_cast<uint4*>(sA + (arow + p * RPP) * RB + kv * 16) = ra[p];
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
-      const int brow = arow + p * 64;
-      if (brow < BN) *reinterpret_cast<uint4*>(sB + brow * ROWB + kv * 16) = rb[p];
+      const int brow = arow + p * RPP;
+      if (brow < BN) *reinterpret_cast<uint4*>(sB + brow * RB + kv * 16) = rb[p];
     }
   };
 
@@ -164,9 +178,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) { advance(); load_tile(kt + 1); }
-    const unsigned char* sA = smem + cur * (BM + BN) * ROWB + wm * TM * ROWB;
-    const unsigned char* sB = smem + cur * (BM + BN) * ROWB + BM * ROWB + wn * TN * ROWB;
-    Frag<T>::template mma<FM, FN>(sA, sB, lane, acc);
+    const unsigned char* sA = smem + cur * (BM + BN) * RB + wm * TM * RB;
+    const unsigned char* sB = smem + cur * (BM + BN) * RB + BM * RB + wn * TN * RB;
+    Frag<T>::template mma<FM, FN, KT, RB>(sA, sB, lane, acc);
     if (kt + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
   }
@@ -216,21 +230,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         ET<T>::st(reinterpret_cast<T*>(smem + row * SROW) + col, acc[i][j][r]);
       }
   __syncthreads();
-  if (a.stats && tid < BN) {
-    const int n = tile_n * BN + tid;
-    if (n < a.Nout) {
+  // statistics rows are per 128 pixels regardless of the tile height (one row per group of wave-rows)
+  constexpr int G = BM / 128, WPG = WM / G;
+  if (a.stats && tid < BN * G) {
+    const int g = tid / BN, col = tid - g * BN;
+    const int n = tile_n * BN + col, srow = tile_m * G + g;
+    if (n < a.Nout && srow * 128 < a.M) {
       float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int r = 0; r < WM; ++r) { s += sstat[(r * 2 + 0) * BN + tid]; q += sstat[(r * 2 + 1) * BN + tid]; }
-      a.stats[((size_t)tile_m * 2 + 0) * a.Nout + n] = s;
-      a.stats[((size_t)tile_m * 2 + 1) * a.Nout + n] = q;
+      for (int r = 0; r < WPG; ++r) { s += sstat[((g * WPG + r) * 2 + 0) * BN + col]; q += sstat[((g * WPG + r) * 2 + 1) * BN + col]; }
+      a.stats[((size_t)srow * 2 + 0) * a.Nout + n] = s;
+      a.stats[((size_t)srow * 2 + 1) * a.Nout + n] = q;
     }
   }
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
   const T* __restrict__ addsrc = reinterpret_cast<const T*>(a.addsrc);
-  constexpr int VPR = BN / VEC;
-  for (int v = tid; v < BM * VPR; v += 256) {
-    const int row = v / VPR, cv = v - row * VPR;
+  constexpr int VPRO = BN / VEC;
+  for (int v = tid; v < BM * VPRO; v += NT) {
+    const int row = v / VPRO, cv = v - row * VPRO;
     const int m = tile_m * BM + row, n = tile_n * BN + cv * VEC;
     if (m < a.M && n < a.Nout) {
       uint4 d = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
@@ -247,32 +264,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int KT>
 int launch_conv(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
-  constexpr int PIPE = 2 * (BM + BN) * ROWB;
+  constexpr int RB = 64 * KT + 16;
+  constexpr int PIPE = 2 * (BM + BN) * RB;
   constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
   constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;
+  static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<T, MODE, BM, BN, WM, WN>;
+  auto kern = conv_igemm_kernel<T, MODE, BM, BN, WM, WN, KT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   a.tiles_n = cdiv(a.Nout, BN);
-  const int tiles_m = cdiv(a.M, BM);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * a.tiles_n)), dim3(256), LDS, st, a);
+  a.tiles_total = cdiv(a.M, BM) * a.tiles_n;
+  a.xcd_chunk = cdiv(a.tiles_total, 8);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(WM * WN * 64), LDS, st, a);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
 
+int g_conv_variant = -1;   // -1: heuristic ; >= 0: forced tile configuration for wide layers (tuning / A-B benchmarking)
+
 template <typename T, int MODE>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
-  if (a.Nout > 64) return launch_conv<T, MODE, 128, 128, 2, 2>(a, st);
-  if (a.Nout > 32) return launch_conv<T, MODE, 128, 64, 2, 2>(a, st);
-  if (a.Nout > 16) return launch_conv<T, MODE, 128, 32, 4, 1>(a, st);
-  return launch_conv<T, MODE, 128, 16, 4, 1>(a, st);
+  constexpr bool BF = sizeof(T) == 2;
+  if (a.Nout > 64) {
+    int v = g_conv_variant;
+    if (v < 0) {   // measured on MI355X (scripts/bench_conv.py): tall tiles once the grid is >= 4 waves of CUs, half-width tiles
+      const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);   // when 128x128 would leave CUs idle
+      v = t128 >= 1024 ? 2 : (t128 >= 300 ? 0 : 4);
+    }
+    if (BF) {   // 8-wave / deep-K tiles only exist in the production dtype
+      if (v == 1) return launch_conv<T, MODE, 128, 128, 2, 2, (BF ? 2 : 1)>(a, st);
+      if (v == 2) return launch_conv<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, 1>(a, st);
+      if (v == 3) return launch_conv<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, (BF ? 2 : 1)>(a, st);
+      if (v == 4) return launch_conv<T, MODE, 128, 64, 2, 2, (BF ? 2 : 1)>(a, st);
+      if (v == 5) return launch_conv<T, MODE, 128, 64, 2, 2, 1>(a, st);
+    } else if (v == 4 || v == 5) {
+      return launch_conv<T, MODE, 128, 64, 2, 2, 1>(a, st);
+    }
+    return launch_conv<T, MODE, 128, 128, 2, 2, 1>(a, st);
+  }
+  if (a.Nout > 32) return launch_conv<T, MODE, 128, 64, 2, 2, (BF ? 2 : 1)>(a, st);
+  if (a.Nout > 16) return launch_conv<T, MODE, 128, 32, 4, 1, (BF ? 2 : 1)>(a, st);
+  return launch_conv<T, MODE, 128, 16, 4, 1, (BF ? 2 : 1)>(a, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -286,27 +325,35 @@ struct WgradArgs {
   int dy_ldc, x_ldc;
   int Hin, Win, Cin, Hout, Wout, Cout;
   int KH, KW, stride, pad, dil;
-  int M, Ktot, tiles_k, tiles_ck, pix_per_split;
+  int M, Ktot, tiles_k, tiles_ck, pix_per_split, blocks_total, xcd_chunk;
 };
 
+// 128(co) x 128(k) output tile per block, 4 waves of 64x64.  One step = 128 pixels (bf16; 64 in fp32) = 256 bytes per LDS row:
+// every thread issues the 16 global loads of the NEXT step before the 64 MFMAs of the current one (HBM latency is ~2 us under
+// load, a 32-pixel step could not cover it), then the tile is transposed into the single LDS buffer between two barriers.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int VEC = ET<T>::VEC;
-  constexpr int BP = 4 * VEC;          // pixels per reduction tile (64 bytes per LDS row)
+  constexpr int NP = 4;                // staging passes per step
+  constexpr int BP = NP * 4 * VEC;     // pixels per step
   constexpr int OQ = 128 / VEC;        // 16-byte vectors per pixel across the 128-wide tile
+  constexpr int PPP = 2 * (256 / OQ);  // pixels covered by one pass (two per thread)
+  constexpr int RB = 64 * NP + 16;     // LDS row pitch in bytes
   constexpr int FM = 4, FN = 4;        // 2x2 waves, 64x64 per wave
-  constexpr int PIPE = 2 * 256 * ROWB;
   constexpr int OROW = 132;            // fp32 staging pitch
+  static_assert(PPP * NP == BP, "pass geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);   // XCD-contiguous block order
+  if (logical >= a.blocks_total) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int split = blockIdx.x / a.tiles_ck;
-  const int tck = blockIdx.x - split * a.tiles_ck;
+  const int split = logical / a.tiles_ck;
+  const int tck = logical - split * a.tiles_ck;
   const int tile_co = tck / a.tiles_k, tile_k = tck - tile_co * a.tiles_k;
   const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
 
-  const int oct = tid % OQ, pp = tid / OQ;           // this thread stages pixels 2pp, 2pp+1 of each tile
+  const int oct = tid % OQ, pp = tid / OQ;           // this thread stages pixels 2pp, 2pp+1 of every pass
   const int co0 = tile_co * 128 + oct * VEC;
   const bool a_ok = co0 < a.Cout;
   const int kcol0 = tile_k * 128 + oct * VEC;
@@ -321,55 +368,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
   const int p_begin = split * a.pix_per_split;
   const int p_end = min(a.M, p_begin + a.pix_per_split);
-  // running (img, ho, wo) of pixel  p_begin + 2pp  ; advanced by BP per tile
-  int m_cur = p_begin + 2 * pp;
-  int img, ho, wo;
-  {
-    const int HWo = a.Hout * a.Wout;
-    img = m_cur / HWo; const int rem = m_cur - img * HWo;
-    ho = rem / a.Wout; wo = rem - ho * a.Wout;
-  }
-  uint4 ra[2], rb[2];
-  auto load_tile = [&]() {
-    int i2 = img, h2 = ho, w2 = wo;
+  const int HWo = a.Hout * a.Wout;
+
+  uint4 ra[2 * NP], rb[2 * NP];
+  auto load_step = [&](int m0) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int m = m_cur + e;
-      const bool pv = m < p_end;
-      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-      if (pv && a_ok) va = *reinterpret_cast<const uint4*>(dy + ((size_t)m * a.dy_ldc + co0));
-      const int hi = h2 * a.stride + dh, wi = w2 * a.stride + dw;
-      if (pv && b_ok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win)
-        vb = *reinterpret_cast<const uint4*>(x + ((size_t)((i2 * a.Hin + hi) * a.Win + wi) * a.x_ldc + ci));
-      ra[e] = va; rb[e] = vb;
-      if (++w2 == a.Wout) { w2 = 0; if (++h2 == a.Hout) { h2 = 0; ++i2; } }
+    for (int ps = 0; ps < NP; ++ps) {
+      const int m = m0 + ps * PPP + 2 * pp;
+      int img = m / HWo, rem = m - img * HWo;
+      int ho = rem / a.Wout, wo = rem - ho * a.Wout;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool pv = m + e < p_end;
+        uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+        if (pv && a_ok) va = *reinterpret_cast<const uint4*>(dy + ((size_t)(m + e) * a.dy_ldc + co0));
+        const int hi = ho * a.stride + dh, wi = wo * a.stride + dw;
+        if (pv && b_ok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win)
+          vb = *reinterpret_cast<const uint4*>(x + ((size_t)((img * a.Hin + hi) * a.Win + wi) * a.x_ldc + ci));
+        ra[2 * ps + e] = va; rb[2 * ps + e] = vb;
+        if (++wo == a.Wout) { wo = 0; if (++ho == a.Hout) { ho = 0; ++img; } }
+      }
     }
   };
-  auto advance = [&]() {
-    m_cur += BP;
-    wo += BP;
-    while (wo >= a.Wout) { wo -= a.Wout; if (++ho == a.Hout) { ho = 0; ++img; } }
-  };
-  auto store_tile = [&](int buf) {
-    unsigned char* sA = smem + buf * 256 * ROWB;
-    unsigned char* sB = sA + 128 * ROWB;
-    if (sizeof(T) == 2) {
-      const unsigned a0[4] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w}, a1[4] = {ra[1].x, ra[1].y, ra[1].z, ra[1].w};
-      const unsigned b0[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, b1[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+  auto store_step = [&]() {
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + 128 * RB;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {   // channels 2q, 2q+1 of the octet ; word = (pixel 2pp | pixel 2pp+1 << 16)
-        *reinterpret_cast<unsigned*>(sA + ((2 * q) * OQ + oct) * ROWB + pp * 4) = (a0[q] & 0xffffu) | (a1[q] << 16);
-        *reinterpret_cast<unsigned*>(sA + ((2 * q + 1) * OQ + oct) * ROWB + pp * 4) = (a0[q] >> 16) | (a1[q] & 0xffff0000u);
-        *reinterpret_cast<unsigned*>(sB + ((2 * q) * OQ + oct) * ROWB + pp * 4) = (b0[q] & 0xffffu) | (b1[q] << 16);
-        *reinterpret_cast<unsigned*>(sB + ((2 * q + 1) * OQ + oct) * ROWB + pp * 4) = (b0[q] >> 16) | (b1[q] & 0xffff0000u);
-      }
-    } else {
-      const unsigned a0[4] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w}, a1[4] = {ra[1].x, ra[1].y, ra[1].z, ra[1].w};
-      const unsigned b0[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, b1[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
+    for (int ps = 0; ps < NP; ++ps) {
+      const unsigned a0[4] = {ra[2 * ps].x, ra[2 * ps].y, ra[2 * ps].z, ra[2 * ps].w}, a1[4] = {ra[2 * ps + 1].x, ra[2 * ps + 1].y, ra[2 * ps + 1].z, ra[2 * ps + 1].w};
+      const unsigned b0[4] = {rb[2 * ps].x, rb[2 * ps].y, rb[2 * ps].z, rb[2 * ps].w}, b1[4] = {rb[2 * ps + 1].x, rb[2 * ps + 1].y, rb[2 * ps + 1].z, rb[2 * ps + 1].w};
+      if (sizeof(T) == 2) {
+        const int cb = ps * 64 + pp * 4;      // byte column of pixels (2pp, 2pp+1) of this pass
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {   // channel q of the quad ; two fp32 pixels side by side
-        *reinterpret_cast<uint2*>(sA + (q * OQ + oct) * ROWB + pp * 8) = make_uint2(a0[q], a1[q]);
-        *reinterpret_cast<uint2*>(sB + (q * OQ + oct) * ROWB + pp * 8) = make_uint2(b0[q], b1[q]);
+        for (int q = 0; q < 4; ++q) {         // channels 2q, 2q+1 of the octet ; word = (pixel 2pp | pixel 2pp+1 << 16)
+          *reinterpret_cast<unsigned*>(sA + ((2 * q) * OQ + oct) * RB + cb) = (a0[q] & 0xffffu) | (a1[q] << 16);
+          *reinterpret_cast<unsigned*>(sA + ((2 * q + 1) * OQ + oct) * RB + cb) = (a0[q] >> 16) | (a1[q] & 0xffff0000u);
+          *reinterpret_cast<unsigned*>(sB + ((2 * q) * OQ + oct) * RB + cb) = (b0[q] & 0xffffu) | (b1[q] << 16);
+          *reinterpret_cast<unsigned*>(sB + ((2 * q + 1) * OQ + oct) * RB + cb) = (b0[q] >> 16) | (b1[q] & 0xffff0000u);
+        }
+      } else {
+        const int cb = ps * 64 + pp * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {         // channel q of the quad ; two fp32 pixels side by side
+          *reinterpret_cast<uint2*>(sA + (q * OQ + oct) * RB + cb) = make_uint2(a0[q], a1[q]);
+          *reinterpret_cast<uint2*>(sB + (q * OQ + oct) * RB + cb) = make_uint2(b0[q], b1[q]);
+        }
       }
     }
   };
@@ -381,17 +424,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nt = (p_end - p_begin + BP - 1) / BP;
   if (nt > 0) {
-    load_tile();
-    store_tile(0);
+    load_step(p_begin);
+    store_step();
   }
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) { advance(); load_tile(); }
-    const unsigned char* sA = smem + cur * 256 * ROWB + wm * 64 * ROWB;
-    const unsigned char* sB = smem + cur * 256 * ROWB + 128 * ROWB + wn * 64 * ROWB;
-    Frag<T>::template mma<FM, FN>(sA, sB, lane, acc);
-    if (t + 1 < nt) store_tile(cur ^ 1);
+    if (t + 1 < nt) load_step(p_begin + (t + 1) * BP);
+    Frag<T>::template mma<FM, FN, NP, RB>(smem + wm * 64 * RB, smem + 128 * RB + wn * 64 * RB, lane, acc);
+    __syncthreads();                              // everyone is done reading the buffer
+    if (t + 1 < nt) store_step();
     __syncthreads();
   }
   // stage fp32 tile [co_local][k_local] (undo the row permutation), then coalesced rows into the slab
@@ -416,7 +457,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     if (co < a.Cout && k < a.Ktot)   // Ktot is a multiple of 8, so a float4 never straddles the edge
       *reinterpret_cast<float4*>(ws + (size_t)co * a.Ktot + k) = *reinterpret_cast<const float4*>(so + row * OROW + c4);
   }
-  (void)PIPE;
 }
 
 // slabs -> OIHW fp32 gradient (real Cin, i.e. without channel padding).
@@ -490,7 +530,7 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
   a.in_ldc = in_ldc; a.out_ldc = out_ldc; a.add_ldc = add_ldc;
   a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Nout = Nout;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;
-  a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin; a.tiles_n = 0; a.sshift = stride == 2 ? 1 : 0;
+  a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin; a.tiles_n = 0; a.sshift = stride == 2 ? 1 : 0; a.tiles_total = 0; a.xcd_chunk = 0;
   if (a.M <= 0) return MDCV_OK;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MDCV_BF16) return mode == 0 ? dispatch_conv<bf16_t, 0>(a, st) : dispatch_conv<bf16_t, 1>(a, st);
@@ -498,15 +538,19 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
   return MDCV_EARG;
 }
 
-// number of rows of the [tiles_m][2][Nout] BatchNorm partial-statistics buffer mdcv_conv2d writes
+// number of rows of the [rows][2][Nout] BatchNorm partial-statistics buffer mdcv_conv2d writes (one per 128 output pixels)
 int mdcv_conv2d_stats_rows(int M) { return cdiv(M, 128); }
 
-// choose the pixel split of the weight-gradient kernel; returns the number of fp32 slabs
+// tuning hook: force the tile configuration of wide (Nout > 64) layers; -1 restores the heuristic
+int mdcv_conv2d_set_variant(int v) { g_conv_variant = v; return MDCV_OK; }
+
+// choose the pixel split of the weight-gradient kernel; returns the number of fp32 slabs.
+// ~2 blocks per CU in flight, but never less than 4 steps (512 bf16 pixels) per split so the fp32 epilogue stays amortised.
 int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot) {
-  const int bp = dtype == MDCV_BF16 ? 32 : 16;
+  const int bp = dtype == MDCV_BF16 ? 128 : 64;
   const int tiles = cdiv(Cout, 128) * cdiv(Ktot, 128);
-  int s = cdiv(768, tiles);
-  const int max_s = cdiv(M, bp * 8);
+  int s = cdiv(512, tiles);
+  const int max_s = cdiv(M, bp * 4);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   int pps = cdiv(cdiv(M, s), bp) * bp;
@@ -523,13 +567,15 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin;
-  const int bp = dtype == MDCV_BF16 ? 32 : 16;
+  const int bp = dtype == MDCV_BF16 ? 128 : 64;
   a.pix_per_split = cdiv(cdiv(a.M, splits), bp) * bp;
   if (cdiv(a.M, a.pix_per_split) != splits) return MDCV_EARG;
   a.tiles_k = cdiv(a.Ktot, 128);
   a.tiles_ck = a.tiles_k * cdiv(Cout, 128);
+  a.blocks_total = a.tiles_ck * splits;
+  a.xcd_chunk = cdiv(a.blocks_total, 8);
   hipStream_t st = (hipStream_t)stream;
-  const int lds = 128 * 132 * 4;   // fp32 staging (67584 B) > pipeline (40960 B)
+  const int lds = 256 * (64 * 4 + 16);   // 69632 B: one transposed step; the fp32 epilogue staging (67584 B) reuses it
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -538,7 +584,7 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
     if (e2 != hipSuccess) return (int)e2;
     attr_set = true;
   }
-  const unsigned grid = (unsigned)(a.tiles_ck * splits);
+  const unsigned grid = (unsigned)(a.xcd_chunk * 8);
   if (dtype == MDCV_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
   else if (dtype == MDCV_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3(grid), dim3(256), lds, st, a);
   else return MDCV_EARG;
