@@ -287,18 +287,276 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   return MDCV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant: tiles go HBM -> LDS directly (buffer_load_dwordx4 ... lds), no VGPR staging and no ds_write pass.
+// An LDS-DMA writes lane-linear: 64 lanes x 16 B = one 1 KiB chunk = 16 tile rows of 64 B (4 lanes per row), so rows are NOT
+// padded; bank conflicts of the ds_read_b128 fragment reads are removed by swizzling on the SOURCE side instead: the lane that
+// fills 16-byte slot s of row r fetches logical k-vector  s ^ f(r),  f(r) = (-(r >> 2)) & 3, and the fragment read of
+// k-vector q goes to slot q ^ f(r).  With this f every 16-lane service group of ds_read_b128 touches 16 distinct slots.
+// Out-of-image taps / tail rows use an out-of-range buffer offset: the hardware range check returns zeros into LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
+
+template <typename T> struct FragSwz;
+template <> struct FragSwz<bf16_t> {
+  template <int FM, int FN>
+  __device__ static __forceinline__ void mma(const unsigned char* sa, const unsigned char* sb, int lane, f32x4_t (&acc)[FM][FN]) {
+    bf16x8_t a[FM], b[FN];
+    const int r = lane & 15;
+    const int off = r * 64 + (((lane >> 4) ^ swz(r)) << 4);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 1024 + off);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 1024 + off);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+};
+template <> struct FragSwz<float> {
+  template <int FM, int FN>
+  __device__ static __forceinline__ void mma(const unsigned char* sa, const unsigned char* sb, int lane, f32x4_t (&acc)[FM][FN]) {
+    const int r = lane & 15;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float a[FM], b[FN];
+      const int off = r * 64 + ((ks ^ swz(r)) << 4) + (lane >> 4) * 4;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const float*>(sa + i * 1024 + off);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const float*>(sb + j * 1024 + off);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <typename T, int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, unsigned in_bytes, unsigned w_bytes) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int VEC = ET<T>::VEC;
+  constexpr int BK = 4 * VEC;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int CA = BM / 16, CB = BN / 16;               // 1 KiB chunks per operand tile
+  constexpr int NPA = (CA + NW - 1) / NW, NPB = (CB + NW - 1) / NW;
+  constexpr int PIPE = 2 * (BM + BN) * 64;
+  constexpr int SROW = BN * (int)sizeof(T) + 16;
+  constexpr int STAGE = BM * SROW;
+  constexpr int STAT_OFF = PIPE > STAGE ? PIPE : STAGE;
+  constexpr unsigned OOB = 0x80000000u;                   // >= num_records of any descriptor we build (sizes are < 2 GiB)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
+  if (logical >= a.tiles_total) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = logical / a.tiles_n, tile_n = logical % a.tiles_n;
+  const int lrow = lane >> 2;                              // row inside a chunk this lane fills
+  const int kv = (lane & 3) ^ swz(lrow);                   // logical k-vector it fetches for that slot
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, w_bytes, 0x00020000);
+
+  int bh[NPA], bw[NPA], ib[NPA];
+  bool rv[NPA];
+  const int HWo = a.Hout * a.Wout;
+#pragma unroll
+  for (int p = 0; p < NPA; ++p) {
+    const int chunk = wave + p * NW;
+    const int m = tile_m * BM + chunk * 16 + lrow;
+    rv[p] = chunk < CA && m < a.M;
+    const int mm = rv[p] ? m : 0;
+    const int img = mm / HWo, rem = mm - img * HWo;
+    const int ho = rem / a.Wout, wo = rem - ho * a.Wout;
+    ib[p] = img * a.Hin * a.Win;
+    if (MODE == 0) { bh[p] = ho * a.stride - a.pad; bw[p] = wo * a.stride - a.pad; }
+    else           { bh[p] = ho + a.pad;            bw[p] = wo + a.pad; }
+  }
+  int kc, kh, kw;
+  {
+    const int k0 = kv * VEC, tap = k0 / a.Cin;
+    kc = k0 - tap * a.Cin; kh = tap / a.KW; kw = tap - kh * a.KW;
+  }
+  const int smask = a.stride - 1;
+
+  auto issue_tile = [&](int kt, int buf) {
+    unsigned char* sA = smem + buf * (BM + BN) * 64;
+    unsigned char* sB = sA + BM * 64;
+    const bool kvalid = kh < a.KH;
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) {
+      const int chunk = wave + p * NW;
+      if (chunk < CA) {
+        int hi, wi; bool ok = rv[p] && kvalid;
+        if (MODE == 0) { hi = bh[p] + kh * a.dil; wi = bw[p] + kw * a.dil; }
+        else {
+          const int th = bh[p] - kh * a.dil, tw = bw[p] - kw * a.dil;
+          ok = ok && th >= 0 && tw >= 0 && (((th | tw) & smask) == 0);
+          hi = th >> a.sshift; wi = tw >> a.sshift;
+        }
+        ok = ok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
+        const unsigned off = ok ? (unsigned)(((ib[p] + hi * a.Win + wi) * a.in_ldc + kc) * (int)sizeof(T)) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_t*)(sA + chunk * 1024), 16, off, 0, 0, 0);
+      }
+    }
+    const int k = kt * BK + kv * VEC;
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+      const int chunk = wave + p * NW;
+      if (chunk < CB) {
+        const int n = tile_n * BN + chunk * 16 + lrow;
+        const unsigned off = (n < a.Nout && k < a.Ktot) ? (unsigned)((n * a.Ktot + k) * (int)sizeof(T)) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(sB + chunk * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+  auto advance = [&]() {
+    kc += BK;
+    while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (a.Ktot + BK - 1) / BK;
+  issue_tile(0, 0);
+  __syncthreads();                                   // (the compiler drains the LDS-DMA queue, vmcnt(0), ahead of the barrier)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) { advance(); issue_tile(kt + 1, cur ^ 1); }
+    const unsigned char* sA = smem + cur * (BM + BN) * 64 + wm * TM * 64;
+    const unsigned char* sB = smem + cur * (BM + BN) * 64 + BM * 64 + wn * TN * 64;
+    FragSwz<T>::template mma<FM, FN>(sA, sB, lane, acc);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue (same as the register-staged kernel) ----------------
+  const int n0 = tile_n * BN + wn * TN, m0 = tile_m * BM + wm * TM;
+  if (a.bias) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + j * 16 + (lane & 15);
+      const float bv = n < a.Nout ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += bv;
+    }
+  }
+  float* sstat = reinterpret_cast<float*>(smem + STAT_OFF);
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + i * 16 + (lane >> 4) * 4 + r;
+          const float v = m < a.M ? acc[i][j][r] : 0.f;
+          s += v; q += v * v;
+        }
+      s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+      if (lane < 16) {
+        sstat[(wm * 2 + 0) * BN + wn * TN + j * 16 + lane] = s;
+        sstat[(wm * 2 + 1) * BN + wn * TN + j * 16 + lane] = q;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * TM + i * 16 + (lane >> 4) * 4 + r, col = wn * TN + j * 16 + (lane & 15);
+        ET<T>::st(reinterpret_cast<T*>(smem + row * SROW) + col, acc[i][j][r]);
+      }
+  __syncthreads();
+  constexpr int G = BM / 128 > 0 ? BM / 128 : 1, WPG = WM / G;
+  if (a.stats && tid < BN * G) {
+    const int g = tid / BN, col = tid - g * BN;
+    const int n = tile_n * BN + col, srow = tile_m * G + g;
+    if (n < a.Nout && srow * 128 < a.M) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int r = 0; r < WPG; ++r) { s += sstat[((g * WPG + r) * 2 + 0) * BN + col]; q += sstat[((g * WPG + r) * 2 + 1) * BN + col]; }
+      a.stats[((size_t)srow * 2 + 0) * a.Nout + n] = s;
+      a.stats[((size_t)srow * 2 + 1) * a.Nout + n] = q;
+    }
+  }
+  T* __restrict__ out = reinterpret_cast<T*>(a.out);
+  const T* __restrict__ addsrc = reinterpret_cast<const T*>(a.addsrc);
+  constexpr int VPRO = BN / VEC;
+  for (int v = tid; v < BM * VPRO; v += NT) {
+    const int row = v / VPRO, cv = v - row * VPRO;
+    const int m = tile_m * BM + row, n = tile_n * BN + cv * VEC;
+    if (m < a.M && n < a.Nout) {
+      uint4 d = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
+      if (addsrc) {
+        float x[VEC], y[VEC];
+        ET<T>::unpack(d, x);
+        ET<T>::unpack(*reinterpret_cast<const uint4*>(addsrc + ((size_t)m * a.add_ldc + n)), y);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x[e] += y[e];
+        d = ET<T>::pack(x);
+      }
+      *reinterpret_cast<uint4*>(out + ((size_t)m * a.out_ldc + n)) = d;
+    }
+  }
+}
+
+template <typename T, int MODE, int BM, int BN, int WM, int WN>
+int launch_conv_glds(const ConvArgs& a0, hipStream_t st, int B) {
+  ConvArgs a = a0;
+  constexpr int PIPE = 2 * (BM + BN) * 64;
+  constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
+  constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;
+  static bool attr_set = false;
+  auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  a.tiles_n = cdiv(a.Nout, BN);
+  a.tiles_total = cdiv(a.M, BM) * a.tiles_n;
+  a.xcd_chunk = cdiv(a.tiles_total, 8);
+  const unsigned in_bytes = (unsigned)((long long)B * a.Hin * a.Win * a.in_ldc * (long long)sizeof(T));
+  const unsigned w_bytes = (unsigned)((long long)a.Nout * a.Ktot * (long long)sizeof(T));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(WM * WN * 64), LDS, st, a, in_bytes, w_bytes);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
 int g_conv_variant = -1;   // -1: heuristic ; >= 0: forced tile configuration for wide layers (tuning / A-B benchmarking)
 
 template <typename T, int MODE>
-int dispatch_conv(const ConvArgs& a, hipStream_t st) {
+int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
   constexpr bool BF = sizeof(T) == 2;
+  // the LDS-DMA kernels address operands through 32-bit buffer offsets: both operands must be < 2 GiB
+  const bool small = (long long)B * a.Hin * a.Win * a.in_ldc * (long long)sizeof(T) < (1LL << 31) &&
+                     (long long)a.Nout * a.Ktot * (long long)sizeof(T) < (1LL << 31);
   if (a.Nout > 64) {
     int v = g_conv_variant;
     if (v < 0) {   // measured on MI355X (scripts/bench_conv.py): tall tiles once the grid is >= 4 waves of CUs, half-width tiles
       const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);   // when 128x128 would leave CUs idle
-      v = t128 >= 1024 ? 2 : (t128 >= 300 ? 0 : 4);
+      v = t128 >= 1024 ? 8 : (t128 >= 300 ? 6 : 7);
     }
+    if (v >= 6 && !small) v = v == 8 ? 2 : (v == 6 ? 0 : 4);
+    if (v == 6) return launch_conv_glds<T, MODE, 128, 128, 2, 2>(a, st, B);
+    if (v == 7) return launch_conv_glds<T, MODE, 128, 64, 2, 2>(a, st, B);
     if (BF) {   // 8-wave / deep-K tiles only exist in the production dtype
+      if (v == 8) return launch_conv_glds<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2>(a, st, B);
       if (v == 1) return launch_conv<T, MODE, 128, 128, 2, 2, (BF ? 2 : 1)>(a, st);
       if (v == 2) return launch_conv<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, 1>(a, st);
       if (v == 3) return launch_conv<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, (BF ? 2 : 1)>(a, st);
@@ -309,9 +567,10 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     }
     return launch_conv<T, MODE, 128, 128, 2, 2, 1>(a, st);
   }
-  if (a.Nout > 32) return launch_conv<T, MODE, 128, 64, 2, 2, (BF ? 2 : 1)>(a, st);
-  if (a.Nout > 16) return launch_conv<T, MODE, 128, 32, 4, 1, (BF ? 2 : 1)>(a, st);
-  return launch_conv<T, MODE, 128, 16, 4, 1, (BF ? 2 : 1)>(a, st);
+  const bool dma = small && g_conv_variant != 0;      // variant 0 forces the register-staged kernels everywhere (A/B)
+  if (a.Nout > 32) return dma ? launch_conv_glds<T, MODE, 128, 64, 2, 2>(a, st, B) : launch_conv<T, MODE, 128, 64, 2, 2, (BF ? 2 : 1)>(a, st);
+  if (a.Nout > 16) return dma ? launch_conv_glds<T, MODE, 128, 32, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 32, 4, 1, (BF ? 2 : 1)>(a, st);
+  return dma ? launch_conv_glds<T, MODE, 128, 16, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 16, 4, 1, (BF ? 2 : 1)>(a, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -533,8 +792,8 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
   a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin; a.tiles_n = 0; a.sshift = stride == 2 ? 1 : 0; a.tiles_total = 0; a.xcd_chunk = 0;
   if (a.M <= 0) return MDCV_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MDCV_BF16) return mode == 0 ? dispatch_conv<bf16_t, 0>(a, st) : dispatch_conv<bf16_t, 1>(a, st);
-  if (dtype == MDCV_F32) return mode == 0 ? dispatch_conv<float, 0>(a, st) : dispatch_conv<float, 1>(a, st);
+  if (dtype == MDCV_BF16) return mode == 0 ? dispatch_conv<bf16_t, 0>(a, st, B) : dispatch_conv<bf16_t, 1>(a, st, B);
+  if (dtype == MDCV_F32) return mode == 0 ? dispatch_conv<float, 0>(a, st, B) : dispatch_conv<float, 1>(a, st, B);
   return MDCV_EARG;
 }
 

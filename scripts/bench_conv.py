@@ -36,7 +36,7 @@ def run(shape, variant, iters=10):
     t = ms.value / iters
     fl = 2.0 * B * Ho * Ho * Co * k * k * Ci
     return t, fl / t / 1e9
-names = {-1: "auto", 0: "128x128k1", 1: "128x128k2", 2: "256x128k1", 3: "256x128k2", 4: "128x64k2", 5: "128x64k1"}
+names = {-1: "auto", 0: "128x128k1", 2: "256x128k1", 4: "128x64k2", 6: "g128x128", 7: "g128x64", 8: "g256x128"}
 print("shape".ljust(40), "  ".join(n.rjust(12) for n in names.values()))
 for sh in SHAPES:
     row = []

@@ -142,6 +142,55 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-4 if dt == F32 else 2e-2, atol=(1e-4 if dt == F32 else 2e-2) * scale)
 
 
+VARIANT_CASES = [(2, 72, 15, 17, 255, 3, 1, 1, 1, True), (2, 136, 14, 14, 144, 3, 2, 1, 1, False), (3, 256, 9, 9, 160, 1, 1, 0, 1, False),
+                 (2, 96, 12, 12, 192, 3, 1, 2, 2, True)]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("dt", [F32, BF16], ids=["fp32", "bf16"])
+def test_conv_tile_variants(variant, dt):
+    """Every tile configuration of the wide-layer dispatch (register-staged and LDS-DMA kernels) on fwd + dgrad."""
+    L = _lib.lib()
+    L.conv2d_set_variant(variant)
+    try:
+        for case in VARIANT_CASES:
+            B, Ci, H, W, Co, k, s, p, d, has_bias = case
+            g = torch.Generator().manual_seed(11 + Ci)
+            x = torch.randn(B, Ci, H, W, generator=g)
+            w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+            b = torch.randn(Co, generator=g) if has_bias else None
+            xr, wr = rnd(dt, x).requires_grad_(True), rnd(dt, w)
+            yref = F.conv2d(xr, wr, b, stride=s, padding=p, dilation=d)
+            Ho, Wo = yref.shape[2], yref.shape[3]
+            cip, cop = pad8(Ci), pad8(Co)
+            xb = to_nhwc(x, dt)
+            wf, wd = pack(dt, w)
+            y = torch.empty(B, Ho, Wo, cop, dtype=TD[dt], device="cuda")
+            stats = torch.zeros(L.conv2d_stats_rows(B * Ho * Wo), 2, cop, dtype=torch.float32, device="cuda")
+            bp = None
+            if has_bias:
+                bp = torch.zeros(cop, device="cuda")
+                bp[:Co] = b.cuda()
+            L.check(L.conv2d(dt, 0, xb.data_ptr(), cip, wf.data_ptr(), y.data_ptr(), cop, bp.data_ptr() if bp is not None else None, None, 0,
+                             stats.data_ptr(), B, H, W, cip, Ho, Wo, cop, k, k, s, p, d, st()), "conv fwd")
+            tol = dict(rtol=1e-4, atol=1e-4) if dt == F32 else dict(rtol=2e-2, atol=2e-2)
+            np.testing.assert_allclose(to_nchw(y, dt, Co).numpy(), yref.detach().numpy(), **tol)
+            np.testing.assert_allclose(stats[:, 0, :Co].sum(0).cpu().numpy(), yref.detach().sum((0, 2, 3)).numpy(), rtol=2e-3,
+                                       atol=2e-2 * (B * Ho * Wo) ** 0.5)
+            dy = torch.randn(B, Co, Ho, Wo, generator=g)
+            yref.backward(rnd(dt, dy))
+            dyb = to_nhwc(dy, dt)
+            add = torch.randn(B, Ci, H, W, generator=g)
+            addb = to_nhwc(add, dt)
+            dx = torch.empty(B, H, W, cip, dtype=TD[dt], device="cuda")
+            L.check(L.conv2d(dt, 1, dyb.data_ptr(), cop, wd.data_ptr(), dx.data_ptr(), cip, None, addb.data_ptr(), cip, None,
+                             B, Ho, Wo, cop, H, W, cip, k, k, s, p, d, st()), "conv dgrad")
+            np.testing.assert_allclose(to_nchw(dx, dt, Ci).numpy(), (xr.grad + rnd(dt, add)).numpy(),
+                                       **(dict(rtol=1e-4, atol=1e-4) if dt == F32 else dict(rtol=3e-2, atol=3e-2)))
+    finally:
+        L.conv2d_set_variant(-1)
+
+
 def test_conv_wgrad_many_splits_and_tiles():
     """M large enough for many pixel splits; Ktot > 128 and Cout > 128 -> several output tiles."""
     L = _lib.lib()
