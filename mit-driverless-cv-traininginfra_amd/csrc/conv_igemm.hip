@@ -27,6 +27,7 @@ struct ConvArgs {
   int Hin, Win, Cin, Hout, Wout, Nout;
   int KH, KW, stride, pad, dil;
   int M, Ktot, tiles_n, sshift, tiles_total, xcd_chunk;
+  int ph, pw, Hs, Ws, kh0, kw0, nkh, nkw;     // MODE 2 (stride-2 data gradient, one output-parity class per launch)
 };
 
 // One K tile of MFMAs for a wave: FM x FN fragments of 16x16, KT k-steps of 64 bytes per LDS row (row pitch RB bytes).
@@ -335,8 +336,9 @@ template <> struct FragSwz<float> {
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+int g_conv_no_ut = 0;    // tuning/A-B: 1 disables the uniform-tap address path
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT>
 __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, unsigned in_bytes, unsigned w_bytes) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int VEC = ET<T>::VEC;
@@ -344,7 +346,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int CA = BM / 16, CB = BN / 16;               // 1 KiB chunks per operand tile
   constexpr int NPA = (CA + NW - 1) / NW, NPB = (CB + NW - 1) / NW;
-  constexpr int PIPE = 2 * (BM + BN) * 64;
+  constexpr int PIPE = STAGES * (BM + BN) * 64;
+  constexpr int GD = NPA + NPB;                           // LDS-DMA instructions every wave issues per K tile (deep pipeline: exact)
+  static_assert(STAGES == 2 || (CA % NW == 0 && CB % NW == 0), "counted vmcnt needs the same DMA count in every wave");
   constexpr int SROW = BN * (int)sizeof(T) + 16;
   constexpr int STAGE = BM * SROW;
   constexpr int STAT_OFF = PIPE > STAGE ? PIPE : STAGE;
@@ -364,7 +368,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
 
   int bh[NPA], bw[NPA], ib[NPA];
   bool rv[NPA];
-  const int HWo = a.Hout * a.Wout;
+  // MODE 2 enumerates only the output pixels (h,w) = (ph + 2a, pw + 2b) of one parity class and only the taps whose
+  // parity matches (kh = kh0 + 2i, kw = kw0 + 2j): every tap it visits is a real MAC.
+  const int HWo = MODE == 2 ? a.Hs * a.Ws : a.Hout * a.Wout;
+  const int Wrow = MODE == 2 ? a.Ws : a.Wout;
+  const int KWn = MODE == 2 ? a.nkw : a.KW, KHn = MODE == 2 ? a.nkh : a.KH;
 #pragma unroll
   for (int p = 0; p < NPA; ++p) {
     const int chunk = wave + p * NW;
@@ -372,53 +380,112 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
     rv[p] = chunk < CA && m < a.M;
     const int mm = rv[p] ? m : 0;
     const int img = mm / HWo, rem = mm - img * HWo;
-    const int ho = rem / a.Wout, wo = rem - ho * a.Wout;
+    const int ho = rem / Wrow, wo = rem - ho * Wrow;
     ib[p] = img * a.Hin * a.Win;
     if (MODE == 0) { bh[p] = ho * a.stride - a.pad; bw[p] = wo * a.stride - a.pad; }
-    else           { bh[p] = ho + a.pad;            bw[p] = wo + a.pad; }
+    else if (MODE == 1) { bh[p] = ho + a.pad;       bw[p] = wo + a.pad; }
+    else { bh[p] = 2 * ho + a.ph + a.pad - a.kh0;   bw[p] = 2 * wo + a.pw + a.pad - a.kw0; }   // always even
   }
   int kc, kh, kw;
   {
     const int k0 = kv * VEC, tap = k0 / a.Cin;
-    kc = k0 - tap * a.Cin; kh = tap / a.KW; kw = tap - kh * a.KW;
+    kc = k0 - tap * a.Cin; kh = tap / KWn; kw = tap - kh * KWn;
   }
   const int smask = a.stride - 1;
 
-  auto issue_tile = [&](int kt, int buf) {
-    unsigned char* sA = smem + buf * (BM + BN) * 64;
-    unsigned char* sB = sA + BM * 64;
-    const bool kvalid = kh < a.KH;
+  // ---- UT (uniform tap): Cin % BK == 0, so a K tile never straddles a tap and the whole wave walks the taps together.
+  // The tap cursor then lives in SGPRs and each DMA needs only: 2 adds + 2 unsigned compares + 1 select per pixel row.
+  int rowoff[NPA], rowh[NPA], roww[NPA], nboff[NPB];
+  bool nv[NPB];
+  if (UT) {
 #pragma unroll
     for (int p = 0; p < NPA; ++p) {
-      const int chunk = wave + p * NW;
-      if (chunk < CA) {
-        int hi, wi; bool ok = rv[p] && kvalid;
-        if (MODE == 0) { hi = bh[p] + kh * a.dil; wi = bw[p] + kw * a.dil; }
-        else {
-          const int th = bh[p] - kh * a.dil, tw = bw[p] - kw * a.dil;
-          ok = ok && th >= 0 && tw >= 0 && (((th | tw) & smask) == 0);
-          hi = th >> a.sshift; wi = tw >> a.sshift;
-        }
-        ok = ok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
-        const unsigned off = ok ? (unsigned)(((ib[p] + hi * a.Win + wi) * a.in_ldc + kc) * (int)sizeof(T)) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_t*)(sA + chunk * 1024), 16, off, 0, 0, 0);
-      }
+      rowh[p] = MODE == 2 ? (bh[p] >> 1) : bh[p];
+      roww[p] = MODE == 2 ? (bw[p] >> 1) : bw[p];
+      rowoff[p] = ((ib[p] + rowh[p] * a.Win + roww[p]) * a.in_ldc + kv * VEC) * (int)sizeof(T);
     }
-    const int k = kt * BK + kv * VEC;
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
       const int chunk = wave + p * NW;
-      if (chunk < CB) {
-        const int n = tile_n * BN + chunk * 16 + lrow;
-        const unsigned off = (n < a.Nout && k < a.Ktot) ? (unsigned)((n * a.Ktot + k) * (int)sizeof(T)) : OOB;
+      const int n = tile_n * BN + chunk * 16 + lrow;
+      nv[p] = chunk < CB && n < a.Nout;
+      nboff[p] = (n * (a.KH * a.KW * a.Cin) + kv * VEC) * (int)sizeof(T);
+    }
+  }
+  int s_c0 = 0, s_kh = 0, s_kw = 0;       // wave-uniform tap cursor (UT)
+  auto issue_tile_ut = [&](int kt, int buf) {
+    unsigned char* sA = smem + buf * (BM + BN) * 64;
+    unsigned char* sB = sA + BM * 64;
+    const bool kvalid = s_kh < KHn;
+    // tap displacement of the source pixel (in pixels) and in bytes
+    const int dh = MODE == 0 ? s_kh * a.dil : -(MODE == 1 ? s_kh * a.dil : s_kh);
+    const int dw = MODE == 0 ? s_kw * a.dil : -(MODE == 1 ? s_kw * a.dil : s_kw);
+    const int tapoff = ((dh * a.Win + dw) * a.in_ldc + s_c0) * (int)sizeof(T);
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) {
+      const int chunk = wave + p * NW;
+      if (CA % NW == 0 || chunk < CA) {
+        const int hi = rowh[p] + dh, wi = roww[p] + dw;
+        const bool ok = rv[p] & kvalid & ((unsigned)hi < (unsigned)a.Hin) & ((unsigned)wi < (unsigned)a.Win);
+        const unsigned off = ok ? (unsigned)(rowoff[p] + tapoff) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_t*)(sA + chunk * 1024), 16, off, 0, 0, 0);
+      }
+    }
+    const int kw_full = MODE == 2 ? ((a.kh0 + 2 * s_kh) * a.KW + a.kw0 + 2 * s_kw) * a.Cin + s_c0 : kt * BK;
+    const int koff = kw_full * (int)sizeof(T);
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+      const int chunk = wave + p * NW;
+      if (CB % NW == 0 || chunk < CB) {
+        const unsigned off = (nv[p] & kvalid) ? (unsigned)(nboff[p] + koff) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(sB + chunk * 1024), 16, off, 0, 0, 0);
       }
     }
   };
-  auto advance = [&]() {
-    kc += BK;
-    while (kc >= a.Cin) { kc -= a.Cin; if (++kw == a.KW) { kw = 0; ++kh; } }
+  auto advance_ut = [&]() {
+    s_c0 += BK;
+    if (s_c0 >= a.Cin) { s_c0 = 0; if (++s_kw == KWn) { s_kw = 0; ++s_kh; } }
   };
+  auto issue_tile_gen = [&](int kt, int buf) {
+    unsigned char* sA = smem + buf * (BM + BN) * 64;
+    unsigned char* sB = sA + BM * 64;
+    const bool kvalid = kh < KHn;
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) {
+      const int chunk = wave + p * NW;
+      if (CA % NW == 0 || chunk < CA) {
+        int hi, wi; bool ok = rv[p] & kvalid;
+        if (MODE == 0) { hi = bh[p] + kh * a.dil; wi = bw[p] + kw * a.dil; }
+        else if (MODE == 2) { hi = (bh[p] >> 1) - kh; wi = (bw[p] >> 1) - kw; }
+        else {
+          const int th = bh[p] - kh * a.dil, tw = bw[p] - kw * a.dil;
+          ok = ok & (th >= 0) & (tw >= 0) & (((th | tw) & smask) == 0);
+          hi = th >> a.sshift; wi = tw >> a.sshift;
+        }
+        ok = ok & ((unsigned)hi < (unsigned)a.Hin) & ((unsigned)wi < (unsigned)a.Win);
+        const unsigned off = ok ? (unsigned)(((ib[p] + hi * a.Win + wi) * a.in_ldc + kc) * (int)sizeof(T)) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_t*)(sA + chunk * 1024), 16, off, 0, 0, 0);
+      }
+    }
+    // weight row = [KH][KW][Cin] of the FULL kernel; MODE 2 visits the sub-lattice of taps
+    const int k = MODE == 2 ? ((a.kh0 + 2 * kh) * a.KW + a.kw0 + 2 * kw) * a.Cin + kc : kt * BK + kv * VEC;
+    const int wrow = a.KH * a.KW * a.Cin;
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+      const int chunk = wave + p * NW;
+      if (CB % NW == 0 || chunk < CB) {
+        const int n = tile_n * BN + chunk * 16 + lrow;
+        const unsigned off = ((n < a.Nout) & kvalid & (k < wrow)) ? (unsigned)((n * wrow + k) * (int)sizeof(T)) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(sB + chunk * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+  auto advance_gen = [&]() {
+    kc += BK;
+    while (kc >= a.Cin) { kc -= a.Cin; if (++kw == KWn) { kw = 0; ++kh; } }
+  };
+  auto issue_tile = [&](int kt, int buf) { if (UT) issue_tile_ut(kt, buf); else issue_tile_gen(kt, buf); };
+  auto advance = [&]() { if (UT) advance_ut(); else advance_gen(); };
 
   f32x4_t acc[FM][FN];
 #pragma unroll
@@ -427,15 +494,43 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (a.Ktot + BK - 1) / BK;
-  issue_tile(0, 0);
-  __syncthreads();                                   // (the compiler drains the LDS-DMA queue, vmcnt(0), ahead of the barrier)
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) { advance(); issue_tile(kt + 1, cur ^ 1); }
-    const unsigned char* sA = smem + cur * (BM + BN) * 64 + wm * TM * 64;
-    const unsigned char* sB = smem + cur * (BM + BN) * 64 + BM * 64 + wn * TN * 64;
-    FragSwz<T>::template mma<FM, FN>(sA, sB, lane, acc);
-    __syncthreads();
+  if (STAGES == 2) {
+    issue_tile(0, 0);
+    __syncthreads();                                 // (the compiler drains the LDS-DMA queue, vmcnt(0), ahead of the barrier)
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) { advance(); issue_tile(kt + 1, cur ^ 1); }
+      const unsigned char* sA = smem + cur * (BM + BN) * 64 + wm * TM * 64;
+      const unsigned char* sB = smem + cur * (BM + BN) * 64 + BM * 64 + wn * TN * 64;
+      FragSwz<T>::template mma<FM, FN>(sA, sB, lane, acc);
+      __syncthreads();
+    }
+  } else {
+    // STAGES-deep ring: tiles kt+1 .. kt+STAGES-2 stay in flight ACROSS the barrier.  Only counted waits (never vmcnt(0) in
+    // steady state) and a raw s_barrier, because __syncthreads() would drain the DMA queue.  Order per iteration:
+    //   wait(tile kt landed for THIS wave) -> barrier (landed for ALL waves; everyone is done reading the slot reused next)
+    //   -> issue tile kt+STAGES-1 into the slot read at iteration kt-1 -> MFMAs on tile kt.
+    int issued = 0;
+    for (; issued < STAGES - 1 && issued < nk; ++issued) { if (issued) advance(); issue_tile(issued, issued); }
+    int slot = 0, islot = issued % STAGES;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int newer = issued - 1 - kt;               // tiles issued after tile kt
+      if (newer >= STAGES - 2 && STAGES > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD * (STAGES - 2)) : "memory");
+      else if (newer == 1 && STAGES > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (issued < nk) {
+        advance();
+        issue_tile(issued, islot);
+        ++issued;
+        islot = islot + 1 == STAGES ? 0 : islot + 1;
+      }
+      const unsigned char* sA = smem + slot * (BM + BN) * 64 + wm * TM * 64;
+      const unsigned char* sB = smem + slot * (BM + BN) * 64 + BM * 64 + wn * TN * 64;
+      FragSwz<T>::template mma<FM, FN>(sA, sB, lane, acc);
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+    __syncthreads();                                   // the epilogue reuses the ring as staging
   }
 
   // ---------------- epilogue (same as the register-staged kernel) ----------------
@@ -501,28 +596,34 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
     const int row = v / VPRO, cv = v - row * VPRO;
     const int m = tile_m * BM + row, n = tile_n * BN + cv * VEC;
     if (m < a.M && n < a.Nout) {
+      size_t pix = (size_t)m;
+      if (MODE == 2) {                                   // class-local index -> full-resolution output pixel
+        const int img = m / HWo, rem = m - img * HWo;
+        const int ha = rem / Wrow, wb = rem - ha * Wrow;
+        pix = ((size_t)img * a.Hout + (a.ph + 2 * ha)) * a.Wout + (a.pw + 2 * wb);
+      }
       uint4 d = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
       if (addsrc) {
         float x[VEC], y[VEC];
         ET<T>::unpack(d, x);
-        ET<T>::unpack(*reinterpret_cast<const uint4*>(addsrc + ((size_t)m * a.add_ldc + n)), y);
+        ET<T>::unpack(*reinterpret_cast<const uint4*>(addsrc + (pix * a.add_ldc + n)), y);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) x[e] += y[e];
         d = ET<T>::pack(x);
       }
-      *reinterpret_cast<uint4*>(out + ((size_t)m * a.out_ldc + n)) = d;
+      *reinterpret_cast<uint4*>(out + (pix * a.out_ldc + n)) = d;
     }
   }
 }
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN>
-int launch_conv_glds(const ConvArgs& a0, hipStream_t st, int B) {
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT>
+int launch_conv_glds_ut(const ConvArgs& a0, hipStream_t st, int B) {
   ConvArgs a = a0;
-  constexpr int PIPE = 2 * (BM + BN) * 64;
+  constexpr int PIPE = STAGES * (BM + BN) * 64;
   constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
   constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;
   static bool attr_set = false;
-  auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN>;
+  auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN, STAGES, UT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
@@ -532,10 +633,19 @@ int launch_conv_glds(const ConvArgs& a0, hipStream_t st, int B) {
   a.tiles_total = cdiv(a.M, BM) * a.tiles_n;
   a.xcd_chunk = cdiv(a.tiles_total, 8);
   const unsigned in_bytes = (unsigned)((long long)B * a.Hin * a.Win * a.in_ldc * (long long)sizeof(T));
-  const unsigned w_bytes = (unsigned)((long long)a.Nout * a.Ktot * (long long)sizeof(T));
+  const unsigned w_bytes = (unsigned)((long long)a.Nout * a.KH * a.KW * a.Cin * (long long)sizeof(T));
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(WM * WN * 64), LDS, st, a, in_bytes, w_bytes);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
+}
+
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES = 2>
+int launch_conv_glds(const ConvArgs& a, hipStream_t st, int B) {
+  constexpr int BK = 4 * ET<T>::VEC;
+  // uniform-tap fast path: K tiles never straddle a tap; the generic stride-2 dgrad (MODE 1, stride 2) keeps the per-lane cursor
+  const bool ut = (a.Cin % BK == 0) && !(MODE == 1 && a.stride != 1) && g_conv_no_ut == 0;
+  if (ut) return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, true>(a, st, B);
+  return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, false>(a, st, B);
 }
 
 int g_conv_variant = -1;   // -1: heuristic ; >= 0: forced tile configuration for wide layers (tuning / A-B benchmarking)
@@ -550,13 +660,19 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
     int v = g_conv_variant;
     if (v < 0) {   // measured on MI355X (scripts/bench_conv.py): tall tiles once the grid is >= 4 waves of CUs, half-width tiles
       const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);   // when 128x128 would leave CUs idle
-      v = t128 >= 1024 ? 8 : (t128 >= 300 ? 6 : 7);
+      const int nk = a.Ktot / (4 * ET<T>::VEC);      // long K loops profit from the 3-stage DMA ring (scripts/bench_conv.py)
+      v = t128 >= 1024 ? 11 : (nk >= 100 ? 9 : (t128 >= 300 ? 6 : 7));
     }
-    if (v >= 6 && !small) v = v == 8 ? 2 : (v == 6 ? 0 : 4);
+    if (v >= 6 && !small) v = (v == 8 || v == 11 || v == 13) ? 2 : ((v == 7 || v == 10) ? 4 : 0);
     if (v == 6) return launch_conv_glds<T, MODE, 128, 128, 2, 2>(a, st, B);
     if (v == 7) return launch_conv_glds<T, MODE, 128, 64, 2, 2>(a, st, B);
+    if (v == 9) return launch_conv_glds<T, MODE, 128, 128, 2, 2, 3>(a, st, B);
+    if (v == 10) return launch_conv_glds<T, MODE, 128, 64, 2, 2, 3>(a, st, B);
+    if (v == 12) return launch_conv_glds<T, MODE, 128, 128, 2, 2, 4>(a, st, B);
     if (BF) {   // 8-wave / deep-K tiles only exist in the production dtype
       if (v == 8) return launch_conv_glds<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2>(a, st, B);
+      if (v == 11) return launch_conv_glds<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, 3>(a, st, B);
+      if (v == 13) return launch_conv_glds<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, 4>(a, st, B);
       if (v == 1) return launch_conv<T, MODE, 128, 128, 2, 2, (BF ? 2 : 1)>(a, st);
       if (v == 2) return launch_conv<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, 1>(a, st);
       if (v == 3) return launch_conv<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, (BF ? 2 : 1)>(a, st);
@@ -571,6 +687,19 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
   if (a.Nout > 32) return dma ? launch_conv_glds<T, MODE, 128, 64, 2, 2>(a, st, B) : launch_conv<T, MODE, 128, 64, 2, 2, (BF ? 2 : 1)>(a, st);
   if (a.Nout > 16) return dma ? launch_conv_glds<T, MODE, 128, 32, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 32, 4, 1, (BF ? 2 : 1)>(a, st);
   return dma ? launch_conv_glds<T, MODE, 128, 16, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 16, 4, 1, (BF ? 2 : 1)>(a, st);
+}
+
+template <typename T>
+int dispatch_dgrad_s2(const ConvArgs& a, hipStream_t st, int B) {
+  if (a.Nout > 64) {
+    const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
+    if (sizeof(T) == 2 && t128 >= 1024) return launch_conv_glds<T, 2, (sizeof(T) == 2 ? 256 : 128), 128, (sizeof(T) == 2 ? 4 : 2), 2>(a, st, B);
+    if (t128 >= 300) return launch_conv_glds<T, 2, 128, 128, 2, 2>(a, st, B);
+    return launch_conv_glds<T, 2, 128, 64, 2, 2>(a, st, B);
+  }
+  if (a.Nout > 32) return launch_conv_glds<T, 2, 128, 64, 2, 2>(a, st, B);
+  if (a.Nout > 16) return launch_conv_glds<T, 2, 128, 32, 4, 1>(a, st, B);
+  return launch_conv_glds<T, 2, 128, 16, 4, 1>(a, st, B);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -718,6 +847,146 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient, bf16 production kernel: LDS-DMA + hardware transpose reads.
+// Operand tiles are DMA'ed in their natural HBM order [pixel][128 channels] (256-byte rows, 4 pixel rows per 1 KiB chunk);
+// MFMA fragments need 8 consecutive PIXELS per channel, which ds_read_b64_tr_b16 delivers for free: a 16-lane group reads a
+// 4(pixel) x 16(channel) block and lane i receives column i (verified on MI355X, scripts/probe_tr.py).  Two such reads make one
+// 16x16x32 fragment.  Bank conflicts between the 4 pixel rows of a block (256 B apart = same banks) are removed by a
+// source-side XOR of the 16-byte column index with 2*(pixel & 7).  No ds_write, no VGPR staging, one barrier per 64-pixel step.
+// ------------------------------------------------------------------------------------------------
+// q = n / d, r = n % d for 0 <= n < 2^24 via one float multiply and a +-1 fix-up (an integer divide costs ~35 VALU ops)
+__device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int& r) {
+  q = (int)((float)n * inv);
+  r = n - q * d;
+  if (r < 0) { --q; r += d; }
+  else if (r >= d) { ++q; r -= d; }
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsigned dy_bytes, unsigned x_bytes) {
+  constexpr int BP = 64;                 // pixels per step
+  constexpr int TILE = BP * 256;         // bytes per operand tile
+  constexpr int OROW = 132;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
+  if (logical >= a.blocks_total) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int split = logical / a.tiles_ck;
+  const int tck = logical - split * a.tiles_ck;
+  const int tile_co = tck / a.tiles_k, tile_k = tck - tile_co * a.tiles_k;
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, x_bytes, 0x00020000);
+
+  // DMA role of this lane: wave w fills chunks w, w+4, w+8, w+12 (4 pixel rows each); inside a chunk the lane fills row
+  // r = lane>>4, 16-byte slot q = lane&15, with the data of logical column q ^ 2*(pixel&7); pixel&7 = r + 4*(w&1) for all its chunks
+  const int r = lane >> 4, q = lane & 15;
+  const int lcol = q ^ (2 * (r + 4 * (wave & 1)));
+  const int co0 = tile_co * 128 + lcol * 8;
+  const bool a_ok = co0 < a.Cout;
+  const int kcol0 = tile_k * 128 + lcol * 8;
+  const bool b_ok = kcol0 < a.Ktot;
+  int dh, dw, ci;
+  {
+    const int kk = b_ok ? kcol0 : 0;
+    const int tap = kk / a.Cin;
+    ci = kk - tap * a.Cin;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    dh = kh * a.dil - a.pad; dw = kw * a.dil - a.pad;
+  }
+  const int p_begin = split * a.pix_per_split;
+  const int p_end = min(a.M, p_begin + a.pix_per_split);
+  const int HWo = a.Hout * a.Wout;
+  const bool fastdiv = a.M + 256 < (1 << 24);
+  const float inv_hw = 1.0f / (float)HWo, inv_w = 1.0f / (float)a.Wout;
+
+  auto issue = [&](int m0, int buf) {
+    unsigned char* sA = smem + buf * 2 * TILE;
+    unsigned char* sB = sA + TILE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int chunk = wave + 4 * j;
+      const int m = m0 + chunk * 4 + r;
+      const bool pv = m < p_end;
+      const unsigned offa = (pv && a_ok) ? (unsigned)((m * a.dy_ldc + co0) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t*)(sA + chunk * 1024), 16, offa, 0, 0, 0);
+      int img, rem, ho, wo;                      // m -> (img, ho, wo): float-reciprocal divide + fix-up (exact for m < 2^24)
+      if (fastdiv) { fast_divmod(m, HWo, inv_hw, img, rem); fast_divmod(rem, a.Wout, inv_w, ho, wo); }
+      else { img = m / HWo; rem = m - img * HWo; ho = rem / a.Wout; wo = rem - ho * a.Wout; }
+      const int hi = ho * a.stride + dh, wi = wo * a.stride + dw;
+      const bool ok = pv && b_ok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
+      const unsigned offb = ok ? (unsigned)((((img * a.Hin + hi) * a.Win + wi) * a.x_ldc + ci) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(sB + chunk * 1024), 16, offb, 0, 0, 0);
+    }
+  };
+
+  // fragment read offsets of this lane inside an operand tile (k-step ks adds ks*32 pixel rows, fragment F adds 32 bytes of columns)
+  const int t = lane & 15, kq = lane >> 4;
+  const int prow = kq * 8 + (t >> 2);                       // pixel row of the first transpose read (second: +4)
+  const int sub = (t & 1) * 8;                              // 8-byte half of the 16-byte column
+  const int qlo = (t & 3) >> 1;                             // which 16-byte column of the fragment's pair
+  const int g0 = 2 * (t >> 2), g1 = 2 * ((t >> 2) + 4);     // swizzle of the two reads (pixel&7 = t>>2 and t>>2 + 4)
+  auto frag = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {
+    const int row0 = ks * 32 + prow;
+    const int c = 2 * F + qlo;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 256 + ((c ^ g0) << 4) + sub));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 4) * 256 + ((c ^ g1) << 4) + sub));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nt = (p_end - p_begin + BP - 1) / BP;
+  if (nt > 0) issue(p_begin, 0);
+  __syncthreads();
+  for (int st = 0; st < nt; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nt) issue(p_begin + (st + 1) * BP, cur ^ 1);
+    const unsigned char* sA = smem + cur * 2 * TILE;
+    const unsigned char* sB = sA + TILE;
+#pragma unroll
+    for (int ks = 0; ks < BP / 32; ++ks) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag(sA, ks, wm * 4 + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = frag(sB, ks, wn * 4 + j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // fp32 tile -> LDS -> coalesced rows of the split's slab
+  float* so = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        so[((wm * 4 + i) * 16 + (lane >> 4) * 4 + rr) * OROW + (wn * 4 + j) * 16 + (lane & 15)] = acc[i][j][rr];
+  __syncthreads();
+  float* __restrict__ ws = a.ws + (size_t)split * a.Cout * a.Ktot;
+  for (int v = tid; v < 128 * 32; v += 256) {
+    const int row = v >> 5, c4 = (v & 31) * 4;
+    const int co = tile_co * 128 + row, k = tile_k * 128 + c4;
+    if (co < a.Cout && k < a.Ktot)
+      *reinterpret_cast<float4*>(ws + (size_t)co * a.Ktot + k) = *reinterpret_cast<const float4*>(so + row * OROW + c4);
+  }
+}
+
 // slabs -> OIHW fp32 gradient (real Cin, i.e. without channel padding).
 // One block per (co, chunk of 64 input channels): slab rows [tap][ci] are read coalesced along ci and summed over the
 // splits, transposed through LDS, and written as the contiguous OIHW run [ci0..ci0+63][tap].
@@ -790,8 +1059,31 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
   a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Nout = Nout;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin; a.tiles_n = 0; a.sshift = stride == 2 ? 1 : 0; a.tiles_total = 0; a.xcd_chunk = 0;
+  a.ph = a.pw = a.kh0 = a.kw0 = 0; a.Hs = Hout; a.Ws = Wout; a.nkh = KH; a.nkw = KW;
   if (a.M <= 0) return MDCV_OK;
   hipStream_t st = (hipStream_t)stream;
+  // stride-2 data gradient: 4 launches, one per output-parity class, each visiting only its live taps (no masked MACs)
+  const bool small = (long long)B * Hin * Win * in_ldc * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31) &&
+                     (long long)Nout * KH * KW * Cin * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31);
+  if (mode == 1 && stride == 2 && dil == 1 && small && g_conv_variant != 0) {
+    for (int cls = 0; cls < 4; ++cls) {
+      ConvArgs c = a;
+      c.ph = cls >> 1; c.pw = cls & 1;
+      c.Hs = (Hout - c.ph + 1) / 2; c.Ws = (Wout - c.pw + 1) / 2;
+      c.kh0 = (c.ph + pad) & 1; c.kw0 = (c.pw + pad) & 1;
+      c.nkh = (KH - c.kh0 + 1) / 2; c.nkw = (KW - c.kw0 + 1) / 2;
+      c.M = B * c.Hs * c.Ws;
+      c.Ktot = c.nkh * c.nkw * Cin;
+      if (c.M <= 0) continue;
+      int rc;
+      if (c.nkh <= 0 || c.nkw <= 0) { c.nkh = c.nkh > 0 ? c.nkh : 0; c.nkw = c.nkw > 0 ? c.nkw : 0; c.Ktot = 0; }
+      if (dtype == MDCV_BF16) rc = dispatch_dgrad_s2<bf16_t>(c, st, B);
+      else if (dtype == MDCV_F32) rc = dispatch_dgrad_s2<float>(c, st, B);
+      else return MDCV_EARG;
+      if (rc) return rc;
+    }
+    return MDCV_OK;
+  }
   if (dtype == MDCV_BF16) return mode == 0 ? dispatch_conv<bf16_t, 0>(a, st, B) : dispatch_conv<bf16_t, 1>(a, st, B);
   if (dtype == MDCV_F32) return mode == 0 ? dispatch_conv<float, 0>(a, st, B) : dispatch_conv<float, 1>(a, st, B);
   return MDCV_EARG;
@@ -801,14 +1093,18 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
 int mdcv_conv2d_stats_rows(int M) { return cdiv(M, 128); }
 
 // tuning hook: force the tile configuration of wide (Nout > 64) layers; -1 restores the heuristic
-int mdcv_conv2d_set_variant(int v) { g_conv_variant = v; return MDCV_OK; }
+int mdcv_conv2d_set_variant(int v) {
+  if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
+  g_conv_variant = v == 99 ? -1 : v;
+  return MDCV_OK;
+}
 
 // choose the pixel split of the weight-gradient kernel; returns the number of fp32 slabs.
 // ~2 blocks per CU in flight, but never less than 4 steps (512 bf16 pixels) per split so the fp32 epilogue stays amortised.
 int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot) {
   const int bp = dtype == MDCV_BF16 ? 128 : 64;
   const int tiles = cdiv(Cout, 128) * cdiv(Ktot, 128);
-  int s = cdiv(512, tiles);
+  int s = 512 / tiles;                    // 2 resident blocks per CU x 256 CUs: never spill into a second, nearly empty round
   const int max_s = cdiv(M, bp * 4);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -829,6 +1125,8 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   const int bp = dtype == MDCV_BF16 ? 128 : 64;
   a.pix_per_split = cdiv(cdiv(a.M, splits), bp) * bp;
   if (cdiv(a.M, a.pix_per_split) != splits) return MDCV_EARG;
+  const long long dyb = (long long)a.M * dy_ldc * 2, xb = (long long)B * Hin * Win * x_ldc * 2;
+  const bool use_dma = dtype == MDCV_BF16 && dyb < (1LL << 31) && xb < (1LL << 31) && g_conv_variant != 0;
   a.tiles_k = cdiv(a.Ktot, 128);
   a.tiles_ck = a.tiles_k * cdiv(Cout, 128);
   a.blocks_total = a.tiles_ck * splits;
@@ -844,7 +1142,16 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
     attr_set = true;
   }
   const unsigned grid = (unsigned)(a.xcd_chunk * 8);
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
+  if (use_dma) {
+    static bool attr2 = false;
+    const int lds2 = 128 * 132 * 4;     // fp32 epilogue staging (67584 B) >= 2 double-buffered steps (65536 B)
+    if (!attr2) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+      if (e != hipSuccess) return (int)e;
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3(grid), dim3(256), lds2, st, a, (unsigned)dyb, (unsigned)xb);
+  } else if (dtype == MDCV_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
   else if (dtype == MDCV_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3(grid), dim3(256), lds, st, a);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();

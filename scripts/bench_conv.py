@@ -36,7 +36,7 @@ def run(shape, variant, iters=10):
     t = ms.value / iters
     fl = 2.0 * B * Ho * Ho * Co * k * k * Ci
     return t, fl / t / 1e9
-names = {-1: "auto", 0: "128x128k1", 2: "256x128k1", 4: "128x64k2", 6: "g128x128", 7: "g128x64", 8: "g256x128"}
+names = {106: "g128x128gen", 6: "g128x128UT", 9: "g128x128s3UT", 107: "g128x64gen", 7: "g128x64UT", 108: "g256x128gen", 8: "g256x128UT", 11: "g256x128s3UT"}
 print("shape".ljust(40), "  ".join(n.rjust(12) for n in names.values()))
 for sh in SHAPES:
     row = []

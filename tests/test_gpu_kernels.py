@@ -146,7 +146,7 @@ VARIANT_CASES = [(2, 72, 15, 17, 255, 3, 1, 1, 1, True), (2, 136, 14, 14, 144, 3
                  (2, 96, 12, 12, 192, 3, 1, 2, 2, True)]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("dt", [F32, BF16], ids=["fp32", "bf16"])
 def test_conv_tile_variants(variant, dt):
     """Every tile configuration of the wide-layer dispatch (register-staged and LDS-DMA kernels) on fwd + dgrad."""
