@@ -251,7 +251,7 @@ def main():
             os.chdir(cwd)
         net = net.to(device).train()
         opt = FusedAdam(net, lr=1e-3)
-        red = GradAllReducer(lambda: net.flat_parameters()[1], bucket_mb=64.0)
+        red = GradAllReducer.attach(net, bucket_mb=32.0)       # RCCL all-reduce of finished buckets overlaps the rest of backward
         g = torch.Generator().manual_seed(1000 + rank)         # rank-seeded shard of the global batch
         B = a.yolo_batch
         x = torch.rand(B, 3, 416, 416, generator=g).to(device)
@@ -261,7 +261,7 @@ def main():
             opt.zero_grad()
             out = net(x, tg)
             out[0].sum().backward()
-            red.allreduce()
+            red.finish()
             opt.step()
             return out
         dt = timed_region(yolo_step, a.steps, a.warmup, device, world)
@@ -292,7 +292,7 @@ def main():
         kp = KeypointNet(7, (80, 80), precision=a.precision).to(device).train()
         crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
         opt = FusedAdam(kp, lr=0.1)
-        red = GradAllReducer(lambda: kp.flat_parameters()[1], bucket_mb=64.0)
+        red = GradAllReducer.attach(kp, bucket_mb=32.0)
         g = torch.Generator().manual_seed(2000 + rank)
         B = a.rekt_batch
         x = torch.rand(B, 3, 80, 80, generator=g).to(device)
@@ -303,7 +303,7 @@ def main():
             hm, pts = kp(x)
             loss = crit(hm, pts, None, tp)[2]
             loss.backward()
-            red.allreduce()
+            red.finish()
             opt.step()
             return loss
         dt = timed_region(rekt_step, a.steps, a.warmup, device, world)

@@ -39,6 +39,7 @@ int mdcv_conv2d_set_variant(int v);   /* tuning hook: force a tile configuration
 
 /* weight gradient: dW (OIHW fp32, real channel counts) = dY^T * im2col(X).  ws = splits*Cout*KH*KW*Cin floats of scratch. */
 int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot);
+int mdcv_conv2d_wgrad_set_variant(int v);   /* tuning hook: step size / ring depth of the bf16 weight-gradient kernel */
 int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits,
                       float* dw_oihw, int accumulate, int B, int Hin, int Win, int Cin, int Cin_real,
                       int Hout, int Wout, int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream);
@@ -46,6 +47,10 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
 /* OIHW fp32 parameters -> GEMM operand layouts (w_dgrad may be NULL) */
 int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,
                       int Cout_pad, int Cin_pad, void* stream);
+
+/* all convs of a network in ONE launch; table = nlayers device-resident 64-byte records
+ *   { const float* w_oihw; void* w_fwd; void* w_dgrad|NULL; int Cout, Cin, KH*KW, Cout_pad, Cin_pad; int reserved[3]; } */
+int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, void* stream);
 
 /* ---- layout conversion at the API edge (reference tensors are NCHW fp32: train.py:60, train_eval.py:60) */
 int mdcv_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int ldc, int Cpad, void* stream);

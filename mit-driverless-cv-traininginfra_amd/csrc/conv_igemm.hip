@@ -866,8 +866,10 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
+template <int BP, int STAGES>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsigned dy_bytes, unsigned x_bytes) {
-  constexpr int BP = 64;                 // pixels per step
+  constexpr int NJ = BP / 16;            // chunks (of 4 pixel rows) per operand per wave per step
+  constexpr int GD = 2 * NJ;             // LDS-DMA instructions per wave per step
   constexpr int TILE = BP * 256;         // bytes per operand tile
   constexpr int OROW = 132;
   constexpr unsigned OOB = 0x80000000u;
@@ -909,7 +911,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsign
     unsigned char* sA = smem + buf * 2 * TILE;
     unsigned char* sB = sA + TILE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int chunk = wave + 4 * j;
       const int m = m0 + chunk * 4 + r;
       const bool pv = m < p_end;
@@ -947,12 +949,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsign
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nt = (p_end - p_begin + BP - 1) / BP;
-  if (nt > 0) issue(p_begin, 0);
-  __syncthreads();
-  for (int st = 0; st < nt; ++st) {
-    const int cur = st & 1;
-    if (st + 1 < nt) issue(p_begin + (st + 1) * BP, cur ^ 1);
-    const unsigned char* sA = smem + cur * 2 * TILE;
+  auto compute = [&](int slot) {
+    const unsigned char* sA = smem + slot * 2 * TILE;
     const unsigned char* sB = sA + TILE;
 #pragma unroll
     for (int ks = 0; ks < BP / 32; ++ks) {
@@ -965,6 +963,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsign
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  if (STAGES == 2) {
+    if (nt > 0) issue(p_begin, 0);
+    __syncthreads();
+    for (int st = 0; st < nt; ++st) {
+      const int cur = st & 1;
+      if (st + 1 < nt) issue(p_begin + (st + 1) * BP, cur ^ 1);
+      compute(cur);
+      __syncthreads();
+    }
+  } else {       // STAGES-deep DMA ring, counted vmcnt + raw barrier (see conv_glds_kernel)
+    int issued = 0;
+    for (; issued < STAGES - 1 && issued < nt; ++issued) issue(p_begin + issued * BP, issued);
+    int slot = 0, islot = issued % STAGES;
+    for (int st = 0; st < nt; ++st) {
+      const int newer = issued - 1 - st;
+      if (newer >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD * (STAGES - 2)) : "memory");
+      else if (newer == 1 && STAGES > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (issued < nt) {
+        issue(p_begin + issued * BP, islot);
+        ++issued;
+        islot = islot + 1 == STAGES ? 0 : islot + 1;
+      }
+      compute(slot);
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
     __syncthreads();
   }
@@ -1038,6 +1064,56 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   }
 }
 
+int g_wgrad_variant = 0;    // 0: 64-pixel steps x 2 stages ; 1: 32 x 3 ; 2: 32 x 4 ; 3: 64 x 3 (one block per CU)
+
+template <int BP, int STAGES>
+static int launch_wgrad_dma_t(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
+  constexpr int RING = STAGES * 2 * BP * 256, EPI = 128 * 132 * 4;
+  constexpr int LDS = RING > EPI ? RING : EPI;
+  static bool attr = false;
+  auto kern = conv_wgrad_dma_kernel<BP, STAGES>;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, a, dyb, xb);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+static int launch_wgrad_dma(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
+  switch (g_wgrad_variant) {
+    case 1: return launch_wgrad_dma_t<32, 3>(a, grid, st, dyb, xb);
+    case 2: return launch_wgrad_dma_t<32, 4>(a, grid, st, dyb, xb);
+    case 3: return launch_wgrad_dma_t<64, 3>(a, grid, st, dyb, xb);
+    default: return launch_wgrad_dma_t<64, 2>(a, grid, st, dyb, xb);
+  }
+}
+
+// all layers in one launch: blockIdx.y selects the layer descriptor, blockIdx.x grid-strides inside it
+struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, KK, Cout_pad, Cin_pad; int pad_[3]; };   // 64 bytes
+template <typename T>
+__global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ table) {
+  const PackDesc d = table[blockIdx.y];
+  const float* __restrict__ w = d.w;
+  T* __restrict__ wf = reinterpret_cast<T*>(d.wf);
+  T* __restrict__ wd = reinterpret_cast<T*>(d.wd);
+  const int nf = d.Cout_pad * d.KK * d.Cin_pad;
+  const int nd = wd ? d.Cin_pad * d.KK * d.Cout_pad : 0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nf + nd; e += gridDim.x * blockDim.x) {
+    if (e < nf) {
+      const int n = e / (d.KK * d.Cin_pad), rem = e - n * (d.KK * d.Cin_pad);
+      const int t = rem / d.Cin_pad, ci = rem - t * d.Cin_pad;
+      ET<T>::st(wf + e, (n < d.Cout && ci < d.Cin) ? w[((size_t)n * d.Cin + ci) * d.KK + t] : 0.f);
+    } else {
+      const int f = e - nf;
+      const int ci = f / (d.KK * d.Cout_pad), rem = f - ci * (d.KK * d.Cout_pad);
+      const int t = rem / d.Cout_pad, co = rem - t * d.Cout_pad;
+      ET<T>::st(wd + f, (co < d.Cout && ci < d.Cin) ? w[((size_t)co * d.Cin + ci) * d.KK + t] : 0.f);
+    }
+  }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1093,6 +1169,7 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
 int mdcv_conv2d_stats_rows(int M) { return cdiv(M, 128); }
 
 // tuning hook: force the tile configuration of wide (Nout > 64) layers; -1 restores the heuristic
+int mdcv_conv2d_wgrad_set_variant(int v) { g_wgrad_variant = v; return MDCV_OK; }   /* tuning hook */
 int mdcv_conv2d_set_variant(int v) {
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
   g_conv_variant = v == 99 ? -1 : v;
@@ -1143,14 +1220,8 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   }
   const unsigned grid = (unsigned)(a.xcd_chunk * 8);
   if (use_dma) {
-    static bool attr2 = false;
-    const int lds2 = 128 * 132 * 4;     // fp32 epilogue staging (67584 B) >= 2 double-buffered steps (65536 B)
-    if (!attr2) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-      if (e != hipSuccess) return (int)e;
-      attr2 = true;
-    }
-    hipLaunchKernelGGL(conv_wgrad_dma_kernel, dim3(grid), dim3(256), lds2, st, a, (unsigned)dyb, (unsigned)xb);
+    const int rc = launch_wgrad_dma(a, grid, st, (unsigned)dyb, (unsigned)xb);
+    if (rc) return rc;
   } else if (dtype == MDCV_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
   else if (dtype == MDCV_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3(grid), dim3(256), lds, st, a);
   else return MDCV_EARG;
@@ -1173,6 +1244,18 @@ int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad
     hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w_oihw, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, Cout, Cin, KK, Cout_pad, Cin_pad);
   else if (dtype == MDCV_F32)
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, st, w_oihw, (float*)w_fwd, (float*)w_dgrad, Cout, Cin, KK, Cout_pad, Cin_pad);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+// one launch for every conv of a network: `table` = nlayers device-resident 64-byte records
+//   { const float* w_oihw; void* w_fwd; void* w_dgrad (or NULL); int Cout, Cin, KH*KW, Cout_pad, Cin_pad; int reserved[3]; }
+int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, void* stream) {
+  if (!table || nlayers < 1) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(48, (unsigned)nlayers), dim3(256), 0, st, (const PackDesc*)table);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(48, (unsigned)nlayers), dim3(256), 0, st, (const PackDesc*)table);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;

@@ -108,6 +108,11 @@ class Plan:
         self._ws = None
         self.bytes = 0
         self.graph_fwd = self.graph_bwd = None
+        self.pack_list = []
+        self.grad_offset = None            # callable(param) -> offset in the flat gradient buffer
+        self.low_water = 1 << 62
+        self._last_mark = 1 << 62
+        self.on_ready = None               # set per backward by the data-parallel reducer
 
     # ------------------------------------------------------------------ buffers
     def new_act(self, B, H, W, C, zero=False):
@@ -129,7 +134,26 @@ class Plan:
             if g is None:
                 g = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
             self.grad_of[id(p)] = g
+        if self.grad_offset is not None:                 # lowest flat-buffer offset written so far by the backward list
+            self.low_water = min(self.low_water, self.grad_offset(p))
         return g
+
+    def mark_ready(self):
+        """Backward-list marker: every gradient at flat offset >= low_water has been ENQUEUED at this point (layers are
+        processed last-to-first and the flat buffer is in parameter order).  The data-parallel reducer uses it to start
+        all-reducing finished buckets while the rest of backward still runs."""
+        lw = self.low_water
+        if lw >= self._last_mark:
+            return
+        self._last_mark = lw
+        plan = self
+
+        def ready(stream, lw=lw):
+            if plan.on_ready is not None:
+                plan.on_ready(lw)
+            return 0
+        ready.__name__ = "grad_ready"
+        self.bwd.append((ready, ()))
 
     def wgrad_ws(self):
         if self._ws is None or self._ws.numel() < self.ws_floats:
@@ -198,11 +222,11 @@ class Plan:
         return node, holder
 
     def emit_pack(self, cs, need_dgrad):
-        L = self.L
+        """Registers the conv for the per-step weight re-layout; all layers are packed by ONE table-driven launch that
+        `finish_pack()` places at the head of the forward list."""
         if need_dgrad and cs.wd is None:
             cs.wd = torch.zeros(cs.cin_pad * cs.kh * cs.kw * cs.cout_pad, dtype=self.tdtype, device=self.device)
-        self.call(self.fwd, L.pack_weights, self.dtype, cs.weight.data_ptr(), cs.wf.data_ptr(),
-                  cs.wd.data_ptr() if cs.wd is not None else None, cs.cout, cs.cin, cs.kh, cs.kw, cs.cout_pad, cs.cin_pad)
+        self.pack_list.append(cs)
         if cs.bias is not None:
             bp, b = cs.bias_pad, cs.bias
 
@@ -310,6 +334,14 @@ class Plan:
                   n(bs2.cB) if bs2 else None, n(bs2.cC) if bs2 else None,
                   dy2.ptr if dy2 is not None else None, dy2.ldc if dy2 is not None else 0, y1.M, y1.C, act, float(slope))
         return (dy1, dy2) if y2 is not None else dy1
+
+    def finish_pack(self, position=0):
+        import struct
+        rec = b"".join(struct.pack("<QQQiiiiiiii", cs.weight.data_ptr(), cs.wf.data_ptr(), cs.wd.data_ptr() if cs.wd is not None else 0,
+                                   cs.cout, cs.cin, cs.kh * cs.kw, cs.cout_pad, cs.cin_pad, 0, 0, 0) for cs in self.pack_list)
+        table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.device)
+        self.keep.append(table)
+        self.fwd.insert(position, (self.L.pack_weights_batched, (self.dtype, table.data_ptr(), len(self.pack_list))))
 
     # ------------------------------------------------------------------ hipGraph capture of the launch lists
     def capture(self, which, stream=None):

@@ -14,40 +14,116 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, flat_grad_fn, bucket_mb=64.0, average=False, group=None):
-        """flat_grad_fn: callable returning the flat fp32 gradient tensor (e.g. lambda: model.flat_parameters()[1])."""
+    """All-reduce(SUM) of a model's flat gradient buffer.
+
+    Two ways to use it:
+      * `GradAllReducer(lambda: flat)` + `allreduce()` after backward — one exchange, queued on a side stream.
+      * `GradAllReducer.attach(model)` — OVERLAPPED: the backward launch list carries "gradients >= offset are enqueued"
+        markers (engine.Plan.mark_ready); each marker lets the comm stream (ordered behind the compute stream by an event)
+        all-reduce every bucket that lies entirely above the mark, while the rest of backward keeps the CUs busy.
+        Call `finish()` before the optimizer step.
+    """
+
+    def __init__(self, flat_grad_fn=None, bucket_mb=64.0, average=False, group=None, allreduce_fn=None):
         self.flat_grad_fn = flat_grad_fn
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
         self.average = average
         self.group = group
         self._stream = None
+        self._allreduce = allreduce_fn            # injectable for tests; default torch.distributed.all_reduce
+        self._flat = None
+        self._pending_hi = 0
+        self._overlap = False
+        self.log = []
 
+    # ---------------------------------------------------------------- plain use
     def buckets(self, flat):
         n = flat.numel()
         return [flat[i:min(n, i + self.bucket_elems)] for i in range(0, n, self.bucket_elems)]
 
+    def _active(self):
+        return self._allreduce is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1)
+
+    def _reduce(self, t):
+        if self._allreduce is not None:
+            self._allreduce(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def allreduce(self):
-        """Sum the gradient over ranks, in place.  Buckets are queued on a side stream (GPU) so the optimizer on the main stream
-        only waits for the last one; returns after ordering the main stream behind the exchange."""
-        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        """Sum the gradient over ranks, in place, after backward (no overlap)."""
+        if not self._active():
             return
         flat = self.flat_grad_fn()
-        world = dist.get_world_size(self.group)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=flat.device)
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
                 for b in self.buckets(flat):
-                    dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+                    self._reduce(b)
                 if self.average:
                     flat.div_(world)
             torch.cuda.current_stream().wait_stream(self._stream)
         else:
             for b in self.buckets(flat):
-                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+                self._reduce(b)
             if self.average:
                 flat.div_(world)
+
+    # ---------------------------------------------------------------- overlapped use
+    @classmethod
+    def attach(cls, model, **kw):
+        red = cls(lambda: model.flat_parameters()[1], **kw)
+        model._dp_reducer = red
+        return red
+
+    def begin(self, flat, overlap):
+        self._flat = flat
+        self._overlap = overlap and self._active()
+        self._pending_hi = flat.numel()                 # buckets are cut from the END of the buffer (last layers finish first)
+        self.log = []
+        if self._active() and flat.is_cuda and self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat.device)
+
+    def _fire(self, lo):
+        """all-reduce [lo, pending_hi) on the comm stream, ordered after everything enqueued so far on the compute stream"""
+        hi = self._pending_hi
+        if hi <= lo:
+            return
+        seg = self._flat[lo:hi]
+        self.log.append((lo, hi))
+        if seg.is_cuda:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                self._reduce(seg)
+        else:
+            self._reduce(seg)
+        self._pending_hi = lo
+
+    def on_ready(self, low_water):
+        if not self._overlap:
+            return
+        while self._pending_hi - self.bucket_elems >= low_water:
+            self._fire(self._pending_hi - self.bucket_elems)
+
+    def backward_done(self):
+        if not self._active():
+            return
+        self._fire(0)                                    # whatever is left (all of it when overlap is off)
+
+    def finish(self):
+        """Order the compute stream behind the exchange (call before optimizer.step())."""
+        if not self._active() or self._flat is None:
+            return
+        if self._flat.is_cuda and self._stream is not None:
+            if self.average:
+                with torch.cuda.stream(self._stream):
+                    self._flat.div_(dist.get_world_size(self.group) if dist.is_initialized() else 1)
+            torch.cuda.current_stream().wait_stream(self._stream)
+        elif self.average:
+            self._flat.div_(dist.get_world_size(self.group) if dist.is_initialized() else 1)
 
 
 def shard_batch(t, rank, world):

@@ -120,6 +120,7 @@ class KeypointNet(nn.Module, FlatParamsMixin):
 
     def _build_plan(self, device, B, H, W, bn_train, logits_only):
         plan = _KpPlan(device, self.precision, bn_train, grad_sink=self._grad_view)
+        plan.grad_offset = lambda p: self._goff[id(p)][0]
         plan.use_graph = self.use_graph
         plan.graphs_bwd = {}
         plan._dhm = None
@@ -170,6 +171,7 @@ class KeypointNet(nn.Module, FlatParamsMixin):
         plan.emit_conv_fwd(csh, a.act, lg.act)
         if bn_train and nbt:
             plan.call(plan.fwd, _bump_counters, nbt)
+        plan.finish_pack(0)
         if logits_only:
             plan.logits_nchw = torch.empty(B, K, H, W, dtype=torch.float32, device=device)
             plan.call(plan.fwd, L.nhwc_to_nchw, dt, lg.act.ptr, lg.act.ldc, plan.logits_nchw.data_ptr(), B, K, H, W)
@@ -194,6 +196,7 @@ class KeypointNet(nn.Module, FlatParamsMixin):
         plan.emit_bias_grad(csh, dlg)
         plan.emit_conv_bwd(csh, a, lg.act, dlg)
         for r in reversed(recs):
+            plan.mark_ready()
             if r[0] == "block":
                 _, x, cs1, bs1, y1, mid, cs2, bs2, y2, css, bss, ys, out = r
                 dy2, dys = plan.emit_bn_act_bwd(out.grad, y2, bs2, ACT_RELU, 0.0, y2=ys, bs2=bss)
@@ -208,4 +211,5 @@ class KeypointNet(nn.Module, FlatParamsMixin):
                 dy0 = plan.emit_bn_act_bwd(a0.grad, y0, bs0, ACT_RELU, 0.0)
                 plan.emit_conv_bwd(cs0, xin_, y0, dy0)
                 plan.emit_bias_grad(cs0, None, zero_only=True)
+        plan.mark_ready()
         return plan

@@ -281,9 +281,17 @@ class FlatParamsMixin:
         keep = None
         if pl[0].grad is not None:                       # gradients were not reset to None: accumulate semantics
             keep = self._gflat.clone()
+        red = getattr(self, "_dp_reducer", None)
+        overlap = red is not None and keep is None and not plan.use_graph
+        plan.on_ready = red.on_ready if overlap else None
+        if red is not None:
+            red.begin(self._gflat, overlap)
         plan.run_backward(gout)
+        plan.on_ready = None
         if keep is not None:
             self._gflat.add_(keep)
+        if red is not None:
+            red.backward_done()
         for p in pl:
             v = self._grad_view(p)
             if p.grad is None:
@@ -364,6 +372,7 @@ class Darknet(nn.Module, FlatParamsMixin):
         defs, mods = self.module_defs, self.module_list
         n = len(defs)
         plan = _NetPlan(device, self.precision, bn_train, grad_sink=self._grad_view)
+        plan.grad_offset = lambda p: self._goff[id(p)][0]
         plan.use_graph = self.use_graph
         plan.pre = []
         L, dt = plan.L, plan.dtype
@@ -557,10 +566,12 @@ class Darknet(nn.Module, FlatParamsMixin):
                 outs[i] = cur
         if bn_train and nbt:
             plan.call(plan.fwd, _bump_counters, nbt)
+        plan.finish_pack(0)
 
         # ---- backward list: mirror of the records, consumers before producers
         if with_targets:
             for r in reversed(recs):
+                plan.mark_ready()
                 kind = r[0]
                 if kind == "yolo":
                     _, lg, anchors, ws, geo = r
@@ -606,6 +617,7 @@ class Darknet(nn.Module, FlatParamsMixin):
                         continue
                     for sn, off in parts:
                         plan.grad_identity(sn, z.grad.slice(off, sn.act.C))
+            plan.mark_ready()
         plan.outs = outs
         return plan
 

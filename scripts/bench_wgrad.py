@@ -8,6 +8,7 @@ SHAPES = [(32, 52, 128, 256, 3, 1), (32, 26, 256, 512, 3, 1), (32, 13, 512, 1024
           (256, 80, 128, 128, 3, 1), (256, 80, 16, 16, 3, 1), (32, 416, 8, 32, 3, 1)]
 only = int(sys.argv[1]) if len(sys.argv) > 1 else -1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+L.conv2d_wgrad_set_variant(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 def ev():
     e = ctypes.c_void_p(); L.event_create(ctypes.byref(e)); return e
 for idx, (B, H, Ci, Co, k, s) in enumerate(SHAPES):
