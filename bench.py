@@ -280,9 +280,15 @@ def main():
             extra["yolo"]["sum_kernel_ms"] = round(tot, 3)
             if conv[1] > 0:
                 ach = conv[2] / (conv[1] * 1e-3) / 1e12
-                result["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16> (mdcv_conv2d: forward + data-gradient launches)",
+                traffic = None           # HBM bytes per launch of this kernel from rocprofv3 PMC passes of this same command
+                tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_yolo.json")   # (cannot be collected live: see file note)
+                if os.path.exists(tpath) and B == 32 and a.precision == "bf16":
+                    tk = json.load(open(tpath))["kernels"].get("conv_glds_kernel")
+                    if tk:
+                        traffic = tk["fetch_bytes_per_launch"] + tk["write_bytes_per_launch"]
+                result["roofline"] = {"bound": "mfma", "kernel": "conv_glds_kernel<bf16> (all mdcv_conv2d launches: forward + data gradient)",
                                       "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                                      "traffic": None, "launches": conv[0], "avg_launch_ms": conv[1] / conv[0],
+                                      "traffic": traffic, "launches": conv[0], "avg_launch_ms": conv[1] / conv[0],
                                       "flops_per_launch_avg": conv[2] / conv[0]}
         del net, opt
         torch.cuda.empty_cache()
