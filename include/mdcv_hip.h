@@ -50,7 +50,7 @@ int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad
 
 /* all convs of a network in ONE launch; table = nlayers device-resident 64-byte records
  *   { const float* w_oihw; void* w_fwd; void* w_dgrad|NULL; int Cout, Cin, KH*KW, Cout_pad, Cin_pad; int reserved[3]; } */
-int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, void* stream);
+int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, int max_taps, void* stream);   /* max_taps = max KH*KW (times Cin_pad/64 scaling is internal) */
 
 /* ---- layout conversion at the API edge (reference tensors are NCHW fp32: train.py:60, train_eval.py:60) */
 int mdcv_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int ldc, int Cpad, void* stream);

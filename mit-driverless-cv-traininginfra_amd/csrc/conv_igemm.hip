@@ -859,14 +859,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 __device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int& r) {
   q = (int)((float)n * inv);
   r = n - q * d;
-  if (r < 0) { --q; r += d; }
-  else if (r >= d) { ++q; r -= d; }
+  const int lt = r < 0;       q -= lt; r += lt ? d : 0;       // predicated (v_cndmask), no divergent branches
+  const int ge = r >= d;      q += ge; r -= ge ? d : 0;
 }
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
-template <int BP, int STAGES>
+template <int BP, int STAGES, bool SAME>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsigned dy_bytes, unsigned x_bytes) {
   constexpr int NJ = BP / 16;            // chunks (of 4 pixel rows) per operand per wave per step
   constexpr int GD = 2 * NJ;             // LDS-DMA instructions per wave per step
@@ -904,26 +904,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsign
   const int p_begin = split * a.pix_per_split;
   const int p_end = min(a.M, p_begin + a.pix_per_split);
   const int HWo = a.Hout * a.Wout;
-  const bool fastdiv = a.M + 256 < (1 << 24);
   const float inv_hw = 1.0f / (float)HWo, inv_w = 1.0f / (float)a.Wout;
+  // all pixel indices are < 2^24 (checked by the host), so 24-bit multiplies (full rate) address both operands
+  const unsigned ldy2 = (unsigned)a.dy_ldc * 2u, lx2 = (unsigned)a.x_ldc * 2u;
+  const unsigned lane_a = (unsigned)co0 * 2u;
+  // SAME (stride 1, equal input/output size): the source pixel of output pixel m under tap (dh,dw) is simply m + dh*W + dw
+  const int lane_b = SAME ? ((dh * a.Win + dw) * a.x_ldc + ci) * 2 : ci * 2;
+  const bool taps = a.KH * a.KW > 1 || a.pad != 0;        // 1x1 / pad 0: every source pixel is inside the image
 
   auto issue = [&](int m0, int buf) {
     unsigned char* sA = smem + buf * 2 * TILE;
     unsigned char* sB = sA + TILE;
+    int m = m0 + 4 * wave + r;                            // this lane's pixel in chunk j = 0; chunk j adds 16*j
+    int img = 0, ho = 0, wo = 0;
+    if (!SAME || taps) {                                  // (uniform) one reciprocal divmod per step, then +16 increments
+      int rem;
+      fast_divmod(m, HWo, inv_hw, img, rem);
+      fast_divmod(rem, a.Wout, inv_w, ho, wo);
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int chunk = wave + 4 * j;
-      const int m = m0 + chunk * 4 + r;
       const bool pv = m < p_end;
-      const unsigned offa = (pv && a_ok) ? (unsigned)((m * a.dy_ldc + co0) * 2) : OOB;
+      const unsigned offa = (pv & a_ok) ? __umul24((unsigned)m, ldy2) + lane_a : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t*)(sA + chunk * 1024), 16, offa, 0, 0, 0);
-      int img, rem, ho, wo;                      // m -> (img, ho, wo): float-reciprocal divide + fix-up (exact for m < 2^24)
-      if (fastdiv) { fast_divmod(m, HWo, inv_hw, img, rem); fast_divmod(rem, a.Wout, inv_w, ho, wo); }
-      else { img = m / HWo; rem = m - img * HWo; ho = rem / a.Wout; wo = rem - ho * a.Wout; }
-      const int hi = ho * a.stride + dh, wi = wo * a.stride + dw;
-      const bool ok = pv && b_ok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
-      const unsigned offb = ok ? (unsigned)((((img * a.Hin + hi) * a.Win + wi) * a.x_ldc + ci) * 2) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(sB + chunk * 1024), 16, offb, 0, 0, 0);
+      unsigned offb;
+      bool ok = pv & b_ok;
+      if (SAME) {
+        if (taps) ok = ok & ((unsigned)(ho + dh) < (unsigned)a.Hin) & ((unsigned)(wo + dw) < (unsigned)a.Win);
+        offb = __umul24((unsigned)m, lx2) + (unsigned)lane_b;
+      } else {
+        const int hi = ho * a.stride + dh, wi = wo * a.stride + dw;
+        ok = ok & ((unsigned)hi < (unsigned)a.Hin) & ((unsigned)wi < (unsigned)a.Win);
+        offb = __umul24((unsigned)((img * a.Hin + hi) * a.Win + wi), lx2) + (unsigned)lane_b;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(sB + chunk * 1024), 16, ok ? offb : OOB, 0, 0, 0);
+      if (j + 1 < NJ) {
+        m += 16;
+        if (!SAME || taps) {                              // predicated wrap of (wo, ho, img); Wout >= 8 so two wraps cover +16
+          wo += 16;
+          int c = wo >= a.Wout; wo -= c ? a.Wout : 0; ho += c;
+          c = wo >= a.Wout;     wo -= c ? a.Wout : 0; ho += c;
+          c = ho >= a.Hout;     ho -= c ? a.Hout : 0; img += c;
+        }
+      }
     }
   };
 
@@ -1066,12 +1090,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 
 int g_wgrad_variant = 0;    // 0: 64-pixel steps x 2 stages ; 1: 32 x 3 ; 2: 32 x 4 ; 3: 64 x 3 (one block per CU)
 
-template <int BP, int STAGES>
+template <int BP, int STAGES, bool SAME>
 static int launch_wgrad_dma_t(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
   constexpr int RING = STAGES * 2 * BP * 256, EPI = 128 * 132 * 4;
   constexpr int LDS = RING > EPI ? RING : EPI;
   static bool attr = false;
-  auto kern = conv_wgrad_dma_kernel<BP, STAGES>;
+  auto kern = conv_wgrad_dma_kernel<BP, STAGES, SAME>;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
@@ -1082,35 +1106,56 @@ static int launch_wgrad_dma_t(const WgradArgs& a, unsigned grid, hipStream_t st,
   return MDCV_OK;
 }
 static int launch_wgrad_dma(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
+  const bool same = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout;
   switch (g_wgrad_variant) {
-    case 1: return launch_wgrad_dma_t<32, 3>(a, grid, st, dyb, xb);
-    case 2: return launch_wgrad_dma_t<32, 4>(a, grid, st, dyb, xb);
-    case 3: return launch_wgrad_dma_t<64, 3>(a, grid, st, dyb, xb);
-    default: return launch_wgrad_dma_t<64, 2>(a, grid, st, dyb, xb);
+    case 1: return launch_wgrad_dma_t<32, 3, false>(a, grid, st, dyb, xb);
+    case 3: return launch_wgrad_dma_t<64, 3, false>(a, grid, st, dyb, xb);
+    case 4: return launch_wgrad_dma_t<64, 2, false>(a, grid, st, dyb, xb);        // generic address path (A/B)
+    default: return same ? launch_wgrad_dma_t<64, 2, true>(a, grid, st, dyb, xb) : launch_wgrad_dma_t<64, 2, false>(a, grid, st, dyb, xb);
   }
 }
 
 // all layers in one launch: blockIdx.y selects the layer descriptor, blockIdx.x grid-strides inside it
 struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, KK, Cout_pad, Cin_pad; int pad_[3]; };   // 64 bytes
+// Tile = 16 output channels x up to 64 input channels x all taps, read from OIHW as contiguous runs (one run per output
+// channel), transposed through LDS and written as  wf[co][tap][ci .. ci+63]  (128-byte runs) and  wd[ci][tap][co .. co+15].
+// (A plain gather kernel read 17x the parameter bytes: rocprofv3 FETCH_SIZE 4.2 GB for 248 MB of weights.)
 template <typename T>
-__global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ table) {
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* __restrict__ table) {
+  extern __shared__ float tile[];
   const PackDesc d = table[blockIdx.y];
   const float* __restrict__ w = d.w;
   T* __restrict__ wf = reinterpret_cast<T*>(d.wf);
   T* __restrict__ wd = reinterpret_cast<T*>(d.wd);
-  const int nf = d.Cout_pad * d.KK * d.Cin_pad;
-  const int nd = wd ? d.Cin_pad * d.KK * d.Cout_pad : 0;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nf + nd; e += gridDim.x * blockDim.x) {
-    if (e < nf) {
-      const int n = e / (d.KK * d.Cin_pad), rem = e - n * (d.KK * d.Cin_pad);
-      const int t = rem / d.Cin_pad, ci = rem - t * d.Cin_pad;
-      ET<T>::st(wf + e, (n < d.Cout && ci < d.Cin) ? w[((size_t)n * d.Cin + ci) * d.KK + t] : 0.f);
-    } else {
-      const int f = e - nf;
-      const int ci = f / (d.KK * d.Cout_pad), rem = f - ci * (d.KK * d.Cout_pad);
-      const int t = rem / d.Cout_pad, co = rem - t * d.Cout_pad;
-      ET<T>::st(wd + f, (co < d.Cout && ci < d.Cin) ? w[((size_t)co * d.Cin + ci) * d.KK + t] : 0.f);
+  const int KK = d.KK;
+  const int CIT = d.Cin_pad < 64 ? d.Cin_pad : 64;
+  const int tiles_ci = (d.Cin_pad + CIT - 1) / CIT, tiles_co = (d.Cout_pad + 15) / 16;
+  const int cstride = CIT * KK + 1;                       // +1: conflict-free column reads in the wd pass
+  const int per = CIT * KK;
+  for (int tl = blockIdx.x; tl < tiles_ci * tiles_co; tl += gridDim.x) {
+    const int co0 = (tl / tiles_ci) * 16, ci0 = (tl % tiles_ci) * CIT;
+    for (int i = threadIdx.x; i < 16 * per; i += 256) {
+      const int co = i / per, rem = i - co * per;
+      const int c = rem / KK, t = rem - c * KK;
+      const int gco = co0 + co, gci = ci0 + c;
+      tile[co * cstride + rem] = (gco < d.Cout && gci < d.Cin) ? w[((size_t)gco * d.Cin + gci) * KK + t] : 0.f;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * per; i += 256) {   // wf: c fastest
+      const int c = i % CIT, r = i / CIT;
+      const int t = r % KK, co = r / KK;
+      const int gco = co0 + co, gci = ci0 + c;
+      if (gco < d.Cout_pad && gci < d.Cin_pad) ET<T>::st(wf + ((size_t)gco * KK + t) * d.Cin_pad + gci, tile[co * cstride + c * KK + t]);
+    }
+    if (wd) {
+      for (int i = threadIdx.x; i < 16 * per; i += 256) { // wd: co fastest
+        const int co = i & 15, r = i >> 4;
+        const int t = r % KK, c = r / KK;
+        const int gco = co0 + co, gci = ci0 + c;
+        if (gco < d.Cout_pad && gci < d.Cin_pad) ET<T>::st(wd + ((size_t)gci * KK + t) * d.Cout_pad + gco, tile[co * cstride + c * KK + t]);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1203,7 +1248,8 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   a.pix_per_split = cdiv(cdiv(a.M, splits), bp) * bp;
   if (cdiv(a.M, a.pix_per_split) != splits) return MDCV_EARG;
   const long long dyb = (long long)a.M * dy_ldc * 2, xb = (long long)B * Hin * Win * x_ldc * 2;
-  const bool use_dma = dtype == MDCV_BF16 && dyb < (1LL << 31) && xb < (1LL << 31) && g_conv_variant != 0;
+  const bool use_dma = dtype == MDCV_BF16 && dyb < (1LL << 31) && xb < (1LL << 31) && g_conv_variant != 0 &&
+                       (long long)B * Hin * Win + 256 < (1LL << 24) && a.M + 256 < (1 << 24) && Wout >= 8 && x_ldc < (1 << 23) && dy_ldc < (1 << 23);
   a.tiles_k = cdiv(a.Ktot, 128);
   a.tiles_ck = a.tiles_k * cdiv(Cout, 128);
   a.blocks_total = a.tiles_ck * splits;
@@ -1251,11 +1297,21 @@ int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad
 
 // one launch for every conv of a network: `table` = nlayers device-resident 64-byte records
 //   { const float* w_oihw; void* w_fwd; void* w_dgrad (or NULL); int Cout, Cin, KH*KW, Cout_pad, Cin_pad; int reserved[3]; }
-int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, void* stream) {
-  if (!table || nlayers < 1) return MDCV_EARG;
+int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, int max_taps, void* stream) {
+  if (!table || nlayers < 1 || max_taps < 1) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(48, (unsigned)nlayers), dim3(256), 0, st, (const PackDesc*)table);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(48, (unsigned)nlayers), dim3(256), 0, st, (const PackDesc*)table);
+  const int lds = 16 * (64 * max_taps + 1) * 4;          // 16 x (64 ci x taps + 1) floats
+  if (lds > 160 * 1024) return MDCV_EARG;
+  static int lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(pack_weights_batched_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(pack_weights_batched_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e1 != hipSuccess) return (int)e1;
+    if (e2 != hipSuccess) return (int)e2;
+    lds_set = lds;
+  }
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(64, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(64, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;

@@ -341,7 +341,9 @@ class Plan:
                                    cs.cout, cs.cin, cs.kh * cs.kw, cs.cout_pad, cs.cin_pad, 0, 0, 0) for cs in self.pack_list)
         table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.device)
         self.keep.append(table)
-        self.fwd.insert(position, (self.L.pack_weights_batched, (self.dtype, table.data_ptr(), len(self.pack_list))))
+        # LDS tile of the pack kernel: 16 x (min(64, Cin_pad) x taps + 1) floats; express it as "taps at 64 input channels"
+        eq_taps = max(1, max((min(64, cs.cin_pad) * cs.kh * cs.kw + 63) // 64 for cs in self.pack_list))
+        self.fwd.insert(position, (self.L.pack_weights_batched, (self.dtype, table.data_ptr(), len(self.pack_list), eq_taps)))
 
     # ------------------------------------------------------------------ hipGraph capture of the launch lists
     def capture(self, which, stream=None):
