@@ -223,11 +223,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the MDCV hot path has no CPU fallback")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    dev_index = local % ndev                      # (MDCV_DIST_BACKEND=gloo lets several ranks share one GPU for testing)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("MDCV_DIST_BACKEND", "nccl")      # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     os.environ["MDCV_GRAPH"] = str(a.graph)
 
     from mdcv.yolo.models import Darknet
@@ -270,7 +276,13 @@ def main():
         result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
         extra["yolo"] = {"images_per_sec": ips, "ms_per_step": 1e3 * dt / a.steps, "global_batch": B * world, "final_loss": loss,
                          "mfma_frac_step": ips * YOLO_TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_TFLOPS * world)}
-        if rank == 0 and not a.no_breakdown:
+        if world > 1:                 # replicas must hold identical parameters after the reduced-gradient updates
+            chk = net.flat_parameters()[0].double().sum().reshape(1)
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            extra["yolo"]["replicas_in_sync"] = bool((hi - lo).abs().item() <= 1e-6 * max(1.0, abs(hi.item())))
+        if not a.no_breakdown:        # every rank runs the instrumented step (it contains the collective); rank 0 reports
             plan = [p for p in net._plans.values() if p.has_bwd][0]
             rec = kernel_breakdown(net, plan, yolo_step)
             tot = sum(v[1] for v in rec.values())
@@ -318,7 +330,7 @@ def main():
                             "final_loss": float(rekt_step()),
                             "mfma_frac_step": ips * REKT_TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_TFLOPS * world),
                             "hbm_frac_step": ips * REKT_TRAIN_MB_PER_IMG / 1e3 / (PEAK_HBM_GBS * world)}
-        if rank == 0 and not a.no_breakdown:
+        if not a.no_breakdown:
             plan = [p for p in kp._plans.values() if p.has_bwd][0]
             rec = kernel_breakdown(kp, plan, rekt_step)
             extra["rektnet"]["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])}
