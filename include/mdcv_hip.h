@@ -83,6 +83,13 @@ int mdcv_accum_to_f32(double* accum, float* out, int n, int zero_after, void* st
 int mdcv_upsample2x_fwd(int dtype, const void* in, int ldi, void* out, int ldo, int B, int H, int W, int C, void* stream);
 int mdcv_upsample2x_bwd(int dtype, const void* dout, int ldo, void* din, int ldi, int B, int H, int W, int C, void* stream);
 
+/* ---- nn.MaxPool2d(2,2) and nn.ZeroPad2d((0,1,0,1)) + nn.MaxPool2d(2,1) of yolo_baseline_tiny.cfg (models.py:74-84).
+ * H,W = input dims; output is H/2 x W/2 (stride 2) or H x W (stride 1); idx [B,Ho,Wo,C] bytes = winning window slot for backward */
+int mdcv_maxpool2x2_fwd(int dtype, const void* in, int ldi, void* out, int ldo, unsigned char* idx, int B, int H, int W, int C, int stride,
+                        void* stream);
+int mdcv_maxpool2x2_bwd(int dtype, const void* dout, int ldo, const unsigned char* idx, void* din, int ldi, int B, int H, int W, int C, int stride,
+                        void* stream);
+
 /* ---- YOLOLayer.forward (models.py:140-220) + build_targets / bbox_iou (utils/utils.py:163-275)
  * logits NHWC, channel = a*(5+C)+attr.  anchors_scaled = anchors/stride, fp32 [A][2].  targets fp32 [B][T][5].
  * train: out7[0] += loss, out7[1..6] += (x,y,w,h,obj,noobj) parts; dlogits = d loss / d logits (* *gscale if given). */

@@ -453,6 +453,74 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dout, int ldo, T* __
   }
 }
 
+// ---------------------------------------------------------------- 2x2 max-pool (yolo_baseline_tiny.cfg): stride 2, or stride 1 on a
+// bottom/right zero-padded input (nn.ZeroPad2d((0,1,0,1)) + nn.MaxPool2d(2,1), reference models.py:74-84).  idx = winning window
+// position (kh*2+kw; first maximum wins like torch; 4 = the zero padding won) so that backward is a pure gather.
+template <typename T>
+__global__ void maxpool2x2_fwd_kernel(const T* __restrict__ in, int ldi, T* __restrict__ out, int ldo, unsigned char* __restrict__ idx,
+                                      int B, int H, int W, int C, int stride) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = C / VEC;
+  const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
+  const long long total = (long long)B * Ho * Wo * CV;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const long long op = i / CV;
+    const int ow = (int)(op % Wo);
+    const long long t = op / Wo;
+    const int oh = (int)(t % Ho), b = (int)(t / Ho);
+    float best[VEC]; unsigned char bi[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int h = oh * stride + (k >> 1), w = ow * stride + (k & 1);
+      float v[VEC];
+      const bool inside = h < H && w < W;
+      if (inside) ET<T>::unpack(*reinterpret_cast<const uint4*>(in + (((long long)b * H + h) * W + w) * ldi + cv * VEC), v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float x = inside ? v[e] : 0.f;                    // zero padding takes part in the max
+        if (x > best[e]) { best[e] = x; bi[e] = inside ? (unsigned char)k : (unsigned char)4; }
+      }
+    }
+    *reinterpret_cast<uint4*>(out + op * ldo + cv * VEC) = ET<T>::pack(best);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) idx[op * C + cv * VEC + e] = bi[e];
+  }
+}
+template <typename T>
+__global__ void maxpool2x2_bwd_kernel(const T* __restrict__ dout, int ldo, const unsigned char* __restrict__ idx, T* __restrict__ din, int ldi,
+                                      int B, int H, int W, int C, int stride) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = C / VEC;
+  const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
+  const long long total = (long long)B * H * W * CV;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const long long ip = i / CV;
+    const int w = (int)(ip % W);
+    const long long t = ip / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    float g[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+    const int nwin = stride == 2 ? 1 : 4;
+    for (int q = 0; q < nwin; ++q) {
+      int oh, ow, pos;
+      if (stride == 2) { oh = h >> 1; ow = w >> 1; pos = (h & 1) * 2 + (w & 1); }
+      else { oh = h - (q >> 1); ow = w - (q & 1); pos = (q >> 1) * 2 + (q & 1); }
+      if (oh < 0 || ow < 0 || oh >= Ho || ow >= Wo) continue;
+      const long long op = ((long long)b * Ho + oh) * Wo + ow;
+      float d[VEC];
+      ET<T>::unpack(*reinterpret_cast<const uint4*>(dout + op * ldo + cv * VEC), d);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) if (idx[op * C + cv * VEC + e] == pos) g[e] += d[e];
+    }
+    *reinterpret_cast<uint4*>(din + ip * ldi + cv * VEC) = ET<T>::pack(g);
+  }
+}
+
 static unsigned ew_grid(long long total) {
   long long g = (total + 255) / 256;
   if (g > 8192) g = 8192;
@@ -633,6 +701,30 @@ int mdcv_upsample2x_bwd(int dtype, const void* dout, int ldo, void* din, int ldi
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MDCV_BF16) hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(ew_grid((long long)B * H * W * C / 8)), dim3(256), 0, st, (const bf16_t*)dout, ldo, (bf16_t*)din, ldi, B, H, W, C);
   else if (dtype == MDCV_F32) hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(ew_grid((long long)B * H * W * C / 4)), dim3(256), 0, st, (const float*)dout, ldo, (float*)din, ldi, B, H, W, C);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_maxpool2x2_fwd(int dtype, const void* in, int ldi, void* out, int ldo, unsigned char* idx, int B, int H, int W, int C, int stride,
+                        void* stream) {
+  if (!in || !out || !idx || (C & 7) || (stride != 1 && stride != 2)) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * (stride == 2 ? H / 2 : H) * (stride == 2 ? W / 2 : W) * C;
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL(maxpool2x2_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, idx, B, H, W, C, stride);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL(maxpool2x2_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, idx, B, H, W, C, stride);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_maxpool2x2_bwd(int dtype, const void* dout, int ldo, const unsigned char* idx, void* din, int ldi, int B, int H, int W, int C, int stride,
+                        void* stream) {
+  if (!dout || !din || !idx || (C & 7) || (stride != 1 && stride != 2)) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * H * W * C;
+  if (dtype == MDCV_BF16) hipLaunchKernelGGL(maxpool2x2_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)dout, ldo, idx, (bf16_t*)din, ldi, B, H, W, C, stride);
+  else if (dtype == MDCV_F32) hipLaunchKernelGGL(maxpool2x2_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)dout, ldo, idx, (float*)din, ldi, B, H, W, C, stride);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;

@@ -413,7 +413,11 @@ class Darknet(nn.Module, FlatParamsMixin):
             elif k == "upsample":
                 h, w = h * int(d["stride"]), w * int(d["stride"])
             elif k == "maxpool":
-                raise NotImplementedError("maxpool sections (yolo_baseline_tiny.cfg) are not lowered yet (SURVEY §8f-3)")
+                ks, st_ = int(d["size"]), int(d["stride"])
+                if ks != 2 or st_ not in (1, 2):
+                    raise NotImplementedError("only the 2x2 max-pools of yolo_baseline_tiny.cfg (stride 2, or stride 1 + zero pad) are lowered")
+                if st_ == 2:
+                    h, w = h // 2, w // 2
             elif k == "route":
                 src = [res(i, int(t)) for t in d["layers"].split(",")]
                 c = sum(shp[s][0] for s in src)
@@ -433,7 +437,7 @@ class Darknet(nn.Module, FlatParamsMixin):
                     parents[i] = par
                     off = 0
                     for s in src:
-                        if s not in dest and defs[s]["type"] in ("convolutional", "upsample", "shortcut"):
+                        if s not in dest and defs[s]["type"] in ("convolutional", "upsample", "shortcut", "maxpool"):
                             dest[s] = (par, off)
                         off += pad8(shp[s][0])
 
@@ -513,6 +517,16 @@ class Darknet(nn.Module, FlatParamsMixin):
                     recs.append(("shortcut", a, b, z))
                     outs[i] = z
                 cur = outs[i]
+            elif k == "maxpool":
+                st_ = int(d["stride"])
+                z = TNode(out_act(i), name="pool%d" % i)
+                a = cur.act
+                idx = torch.empty(z.act.M * z.act.C, dtype=torch.uint8, device=device)
+                plan.keep.append(idx)
+                plan.call(plan.fwd, L.maxpool2x2_fwd, dt, a.ptr, a.ldc, z.act.ptr, z.act.ldc, idx.data_ptr(), B, a.H, a.W, a.C, st_)
+                recs.append(("maxpool", cur, z, idx, st_))
+                outs[i] = z
+                cur = z
             elif k == "upsample":
                 if int(d["stride"]) != 2:
                     raise NotImplementedError("only x2 nearest upsample is lowered")
@@ -610,6 +624,17 @@ class Darknet(nn.Module, FlatParamsMixin):
                         tmp = plan.new_act(B, xn.act.H, xn.act.W, xn.act.C)
                         plan.call(plan.bwd, L.upsample2x_bwd, dt, z.grad.ptr, z.grad.ldc, tmp.ptr, tmp.ldc, B, xn.act.H, xn.act.W, xn.act.C)
                         plan.call(plan.bwd, L.bn_act_fwd, dt, tmp.ptr, tmp.ldc, None, None, None, 0, None, None, add.ptr, add.ldc,
+                                  out.ptr, out.ldc, out.M, out.C, ACT_NONE, 0.0)
+                elif kind == "maxpool":
+                    _, xn, z, idx, st_ = r
+                    if z.gstate == "none":
+                        continue
+                    out, add = plan.grad_target(xn)
+                    tgt = out if add is None else plan.new_act(B, xn.act.H, xn.act.W, xn.act.C)
+                    plan.call(plan.bwd, L.maxpool2x2_bwd, dt, z.grad.ptr, z.grad.ldc, idx.data_ptr(), tgt.ptr, tgt.ldc, B, xn.act.H, xn.act.W,
+                              xn.act.C, st_)
+                    if add is not None:
+                        plan.call(plan.bwd, L.bn_act_fwd, dt, tgt.ptr, tgt.ldc, None, None, None, 0, None, None, add.ptr, add.ldc,
                                   out.ptr, out.ldc, out.M, out.C, ACT_NONE, 0.0)
                 elif kind == "concat":
                     _, parts, z = r

@@ -377,3 +377,26 @@ def test_device_is_gfx950():
     arch = ctypes.create_string_buffer(64)
     L.check(L.device_info(ctypes.byref(cu), ctypes.byref(wave), ctypes.byref(hbm), arch, 64))
     assert wave.value == 64 and cu.value >= 200 and arch.value.decode().startswith("gfx950")
+
+
+@pytest.mark.parametrize("dt", [F32, BF16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("stride,H,W", [(2, 26, 26), (2, 8, 12), (1, 13, 13), (1, 6, 9)])
+def test_maxpool2x2(dt, stride, H, W):
+    L = _lib.lib()
+    B, C = 2, 24
+    g = torch.Generator().manual_seed(H * 10 + stride)
+    x = torch.randn(B, C, H, W, generator=g)
+    xr = rnd(dt, x).requires_grad_(True)
+    ref = F.max_pool2d(F.pad(xr, (0, 1, 0, 1)), 2, 1, 0) if stride == 1 else F.max_pool2d(xr, 2, 2, 0)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xb = to_nhwc(x, dt)
+    out = torch.empty(B, Ho, Wo, C, dtype=TD[dt], device="cuda")
+    idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device="cuda")
+    L.check(L.maxpool2x2_fwd(dt, xb.data_ptr(), C, out.data_ptr(), C, idx.data_ptr(), B, H, W, C, stride, st()))
+    assert torch.equal(to_nchw(out, dt, C), ref.detach())
+    d = torch.randn(B, C, Ho, Wo, generator=g)
+    ref.backward(rnd(dt, d))
+    db = to_nhwc(d, dt)
+    din = torch.empty(B, H, W, C, dtype=TD[dt], device="cuda")
+    L.check(L.maxpool2x2_bwd(dt, db.data_ptr(), C, idx.data_ptr(), din.data_ptr(), C, B, H, W, C, stride, st()))
+    np.testing.assert_allclose(to_nchw(din, dt, C).numpy(), xr.grad.numpy(), rtol=1e-6 if dt == F32 else 1e-2, atol=1e-6 if dt == F32 else 2e-2)

@@ -405,3 +405,132 @@ def test_overlapped_reducer_covers_every_gradient_once():
     assert all(a[1] == b[0] for a, b in zip(segs, segs[1:]))                      # exact tiling, no overlap
     assert red.log[0][1] == ref.numel() and red.log == sorted(red.log, reverse=True)   # fired from the end of the buffer
     assert relerr(net.flat_parameters()[1].cpu(), (2 * ref).cpu()) < 1e-6
+
+
+def test_bf16_loss_curve_tracks_fp32_over_training():
+    """bf16 is judged statistically — the bf16 run's loss curve must track the fp32-kernel run over >= 30 optimizer steps
+    (same seeds, FusedAdam), and both must actually learn."""
+    from mdcv.optim import FusedAdam
+    z = load("mini_darknet_dp.npz")
+    x, tg = T(z["x"]).cuda(), T(z["targets"]).cuda()
+    curves = {}
+    for prec in ("fp32", "bf16"):
+        net = make_mini(prec)
+        net.train()
+        opt = FusedAdam(net, lr=2e-3)
+        ls = []
+        for _ in range(40):
+            opt.zero_grad()
+            out = net(x, tg)
+            out[0].backward()
+            opt.step()
+            ls.append(float(out[0].detach()))
+        curves[prec] = np.array(ls)
+    a, b = curves["fp32"], curves["bf16"]
+    assert a[-1] < 0.7 * a[0] and b[-1] < 0.7 * b[0], (a[0], a[-1], b[0], b[-1])
+    rel = np.abs(a - b) / a
+    assert rel[:5].max() < 2e-2 and np.median(rel) < 5e-2 and rel.max() < 0.2, rel
+
+
+def test_yolo_baseline_bf16_vs_cpu_oracle_full_size(tmp_path):
+    """Full yolo_baseline@416 (classes=80), B=2: bf16 HIP path vs the fp32 CPU oracle with identical weights:
+    total loss rel <= 5e-3 ... 2e-2, per-part losses <= 10 % (SURVEY §8d tolerances), eval boxes close."""
+    from mdcv.yolo.models import Darknet
+    from oracle import yolo_oracle as yo
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        cfg = write_baseline_cfg(str(tmp_path), 416, 80)
+        torch.manual_seed(5)
+        net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16")
+        wpath = os.path.join(str(tmp_path), "init.weights")
+        net.save_weights(wpath)
+        orc = yo.DarknetOracle(cfg, anchors=yo.VANILLA_ANCHORS)
+        orc.load_weights(wpath, [255, 255, 255])
+    finally:
+        os.chdir(cwd)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 416, 416, generator=g)
+    tg = torch.zeros(2, 6, 5)
+    for b in range(2):
+        n = 3 + b
+        tg[b, :n, 1:3] = torch.rand(n, 2, generator=g) * 0.9 + 0.05
+        tg[b, :n, 3:5] = torch.rand(n, 2, generator=g) * 0.28 + 0.02
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = torch.stack([r for r in orc.forward(x, tg)]).numpy()
+    net = net.cuda().train()
+    with torch.no_grad():
+        got = torch.stack([o for o in net(x.cuda(), tg.cuda())]).cpu().numpy()
+    assert abs(got[0] - ref[0]) <= 2e-2 * abs(ref[0]), (got, ref)
+    assert np.all(np.abs(got[1:] - ref[1:]) <= 0.1 * np.abs(ref[1:]) + 1e-3), (got, ref)
+
+
+# ------------------------------------------------------------------------------------------------ tiny cfg (max-pool sections)
+def write_tiny_cfg(tmp, size, classes, widths=(16, 32, 64, 128, 256, 512, 1024), name="tiny"):
+    """yolo_baseline_tiny topology: 6 max-pools (last one 2/1 + zero pad), 2 heads, route -4, route -1,8."""
+    w = widths
+    head = (f"[net]\nwidth={size}\nheight={size}\nonnx_height={size}\nclasses={classes}\nchannels=3\n"
+            "yolo_masks=3,4,5|0,1,2\nyolo_scales=32,16\nvalidate_uri=dataset/validate.csv\ntrain_uri=dataset/train.csv\n"
+            f"weights_uri=none\nstart_weights_dim={3 * (5 + classes)},{3 * (5 + classes)}\nnum_train_images=-1\nnum_validate_images=-1\nleaky_slope=0.1\n"
+            "conv_activation=leaky\nbuild_targets_ignore_thresh=0.5\nconf_thresh=0.8\nnms_thresh=0.25\niou_thresh=0.5\n\n")
+
+    def conv(f, k):
+        return f"[convolutional]\nfilters={f}\nsize={k}\nstride=1\n\n"
+
+    def mp(s):
+        return f"[maxpool]\nsize=2\nstride={s}\n\n"
+    body = "".join(conv(w[i], 3) + mp(2) for i in range(5)) + conv(w[5], 3) + mp(1) + conv(w[6], 3)
+    body += conv(w[4], 1) + conv(w[5], 3) + conv("preyolo", 1) + "[yolo]\n\n[route]\nlayers = -4\n\n" + conv(w[3], 1)
+    body += "[upsample]\nstride=2\n\n[route]\nlayers = -1, 8\n\n" + conv(w[4], 3) + conv("preyolo", 1) + "[yolo]\n"
+    os.makedirs(os.path.join(tmp, "dataset"), exist_ok=True)
+    with open(os.path.join(tmp, "dataset", "train.csv"), "w") as f:
+        f.write('"10,13|16,30|33,23|30,61|62,45|59,119|116,90|156,198|373,326"\n')
+    path = os.path.join(tmp, f"{name}_{size}_{classes}.cfg")
+    with open(path, "w") as f:
+        f.write(head + body)
+    return path
+
+
+def test_tiny_cfg_structure_and_train_step_vs_oracle(tmp_path):
+    from mdcv.yolo.models import Darknet
+    from oracle import yolo_oracle as yo
+    z = load("yolo_tiny_structure.npz")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        full = Darknet(write_tiny_cfg(str(tmp_path), 416, 80), 2.0, 1.6, 25.0, 0.1, True, precision="bf16")
+        assert sum(p.numel() for p in full.parameters()) == int(z["nparam"]) == 8852366
+        full = full.cuda().eval()
+        with torch.no_grad():
+            ev = full(torch.rand(2, 3, 416, 416).cuda())
+        assert tuple(ev.shape[1:]) == tuple(z["out_shape"][1:]) == (2535, 85)
+        # narrow copy of the same topology at 128^2: full train step in fp32 against the CPU oracle
+        cfg = write_tiny_cfg(str(tmp_path), 128, 1, widths=(8, 16, 16, 32, 32, 64, 64), name="minitiny")
+        torch.manual_seed(11)
+        net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="fp32")
+        wp = os.path.join(str(tmp_path), "mt.weights")
+        net.save_weights(wp)
+        orc = yo.DarknetOracle(cfg, anchors=yo.VANILLA_ANCHORS)
+        orc.load_weights(wp, [18, 18])
+    finally:
+        os.chdir(cwd)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(3, 3, 128, 128, generator=g)
+    tg = torch.zeros(3, 4, 5)
+    for b in range(3):
+        tg[b, :b + 1, 1:3] = torch.rand(b + 1, 2, generator=g) * 0.9 + 0.05
+        tg[b, :b + 1, 3:5] = torch.rand(b + 1, 2, generator=g) * 0.28 + 0.05
+    for k in orc.trainable():
+        orc.params[k].requires_grad_(True)
+    ref = orc.forward(x, tg)
+    ref[0].sum().backward()
+    net = net.cuda().train()
+    out = net(x.cuda(), tg.cuda())
+    out[0].backward()
+    close(torch.stack([o.detach() for o in out]).cpu(), torch.stack([r.detach() for r in ref]), rtol=2e-4)
+    params = dict(net.named_parameters())
+    for n, p in params.items():
+        _, i, mod, leaf = n.split(".")
+        r = orc.params[("conv" if mod.startswith("conv") else "bn") + f"{i}.{leaf}"].grad
+        assert relerr(p.grad.cpu(), r) < 2e-3, (n, relerr(p.grad.cpu(), r))
