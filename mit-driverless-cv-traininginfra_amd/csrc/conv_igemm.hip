@@ -1049,12 +1049,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const float* row = ws + (size_t)co * Ktot;
   for (int i = threadIdx.x; i < KK * 64; i += 256) {
     const int t = i >> 6, c = i & 63;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // 4 independent chains: the loads of 4 splits are in flight together
     if (c < nci) {
       const float* p = row + t * Cin_pad + ci0 + c;
-      for (int sp = 0; sp < splits; ++sp) s += p[sp * slab];
+      int sp = 0;
+      for (; sp + 4 <= splits; sp += 4) {
+        s0 += p[(size_t)sp * slab]; s1 += p[(size_t)(sp + 1) * slab]; s2 += p[(size_t)(sp + 2) * slab]; s3 += p[(size_t)(sp + 3) * slab];
+      }
+      for (; sp < splits; ++sp) s0 += p[(size_t)sp * slab];
     }
-    tile[t * 65 + c] = s;
+    tile[t * 65 + c] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   float* out = dw + ((size_t)co * Cin_real + ci0) * KK;
@@ -1088,6 +1092,173 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   }
 }
 
+// Narrow-output variant (Cout_pad <= 32: first layers, RektNet's 16/32-channel blocks, heads): output tile 32(co) x 128(k).
+// The dY tile is [64 px][32 co] = 64-byte rows, 16 pixel rows per 1 KiB chunk (one chunk per wave), no swizzle needed (the 4 rows
+// of a transpose read sit 64 B apart -> distinct banks).  Each wave owns a 32 x 32 slice: 4 MFMAs per 32-pixel k-step instead of
+// 16 MFMAs on a tile that would be 75-87 % zero padding.  These layers are HBM-bound; the point is to stop wasting issue slots.
+template <bool SAME, int STAGES>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a, unsigned dy_bytes, unsigned x_bytes) {
+  constexpr int BP = 64, NJ = 4, GD = 5;
+  constexpr int TA = BP * 64, TB = BP * 256;   // bytes per operand tile
+  constexpr int OROW = 132;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
+  if (logical >= a.blocks_total) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = logical / a.tiles_ck;
+  const int tile_k = logical - split * a.tiles_ck;          // tiles_co == 1
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, x_bytes, 0x00020000);
+
+  // A (dY) DMA role: chunk = wave; lane fills pixel row ra = lane>>2, channels 8*(lane&3)..+7
+  const int ra = lane >> 2;
+  const int coA = (lane & 3) * 8;
+  const bool a_ok = coA < a.Cout;
+  // B (X) DMA role: as in the wide kernel
+  const int r = lane >> 4, q = lane & 15;
+  const int lcol = q ^ (2 * (r + 4 * (wave & 1)));
+  const int kcol0 = tile_k * 128 + lcol * 8;
+  const bool b_ok = kcol0 < a.Ktot;
+  int dh, dw, ci;
+  {
+    const int kk = b_ok ? kcol0 : 0;
+    const int tap = kk / a.Cin;
+    ci = kk - tap * a.Cin;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    dh = kh * a.dil - a.pad; dw = kw * a.dil - a.pad;
+  }
+  const int p_begin = split * a.pix_per_split;
+  const int p_end = min(a.M, p_begin + a.pix_per_split);
+  const int HWo = a.Hout * a.Wout;
+  const float inv_hw = 1.0f / (float)HWo, inv_w = 1.0f / (float)a.Wout;
+  const unsigned ldy2 = (unsigned)a.dy_ldc * 2u, lx2 = (unsigned)a.x_ldc * 2u;
+  const int lane_b = SAME ? ((dh * a.Win + dw) * a.x_ldc + ci) * 2 : ci * 2;
+  const bool taps = a.KH * a.KW > 1 || a.pad != 0;
+
+  auto issue = [&](int m0, int buf) {
+    unsigned char* sA = smem + buf * (TA + TB);
+    unsigned char* sB = sA + TA;
+    {
+      const int m = m0 + 16 * wave + ra;
+      const unsigned offa = (m < p_end && a_ok) ? __umul24((unsigned)m, ldy2) + (unsigned)coA * 2u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t*)(sA + wave * 1024), 16, offa, 0, 0, 0);
+    }
+    int m = m0 + 4 * wave + r;
+    int img = 0, ho = 0, wo = 0;
+    if (!SAME || taps) {
+      int rem;
+      fast_divmod(m, HWo, inv_hw, img, rem);
+      fast_divmod(rem, a.Wout, inv_w, ho, wo);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int chunk = wave + 4 * j;
+      bool ok = (m < p_end) & b_ok;
+      unsigned offb;
+      if (SAME) {
+        if (taps) ok = ok & ((unsigned)(ho + dh) < (unsigned)a.Hin) & ((unsigned)(wo + dw) < (unsigned)a.Win);
+        offb = __umul24((unsigned)m, lx2) + (unsigned)lane_b;
+      } else {
+        const int hi = ho * a.stride + dh, wi = wo * a.stride + dw;
+        ok = ok & ((unsigned)hi < (unsigned)a.Hin) & ((unsigned)wi < (unsigned)a.Win);
+        offb = __umul24((unsigned)((img * a.Hin + hi) * a.Win + wi), lx2) + (unsigned)lane_b;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(sB + chunk * 1024), 16, ok ? offb : OOB, 0, 0, 0);
+      if (j + 1 < NJ) {
+        m += 16;
+        if (!SAME || taps) {
+          wo += 16;
+          int c = wo >= a.Wout; wo -= c ? a.Wout : 0; ho += c;
+          c = wo >= a.Wout;     wo -= c ? a.Wout : 0; ho += c;
+          c = ho >= a.Hout;     ho -= c ? a.Hout : 0; img += c;
+        }
+      }
+    }
+  };
+
+  const int t = lane & 15, kq = lane >> 4;
+  const int prow = kq * 8 + (t >> 2);
+  const int sub = (t & 1) * 8, qlo = (t & 3) >> 1;
+  const int g0 = 2 * (t >> 2), g1 = 2 * ((t >> 2) + 4);
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  auto fragB = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {
+    const int row0 = ks * 32 + prow, c = 2 * F + qlo;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 256 + ((c ^ g0) << 4) + sub));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 4) * 256 + ((c ^ g1) << 4) + sub));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  auto fragA = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {       // 64-byte rows: F selects the 32-byte half
+    const int row0 = ks * 32 + prow;
+    const int col = F * 32 + (t & 3) * 8;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 64 + col));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 4) * 64 + col));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nt = (p_end - p_begin + BP - 1) / BP;
+  auto compute = [&](int slot) {
+    const unsigned char* sA = smem + slot * (TA + TB);
+    const unsigned char* sB = sA + TA;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = fragA(sA, ks, i);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = fragB(sB, ks, wave * 2 + j);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  // these layers are HBM-latency-bound (tiny per-step work): keep STAGES-1 steps of DMA in flight (counted vmcnt, raw barrier)
+  int issued = 0;
+  for (; issued < STAGES - 1 && issued < nt; ++issued) issue(p_begin + issued * BP, issued);
+  int slot = 0, islot = issued % STAGES;
+  for (int st = 0; st < nt; ++st) {
+    const int newer = issued - 1 - st;
+    if (newer >= 3 && STAGES >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD * 3) : "memory");
+    else if (newer >= 2 && STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD * 2) : "memory");
+    else if (newer >= 1 && STAGES >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (issued < nt) {
+      issue(p_begin + issued * BP, islot);
+      ++issued;
+      islot = islot + 1 == STAGES ? 0 : islot + 1;
+    }
+    compute(slot);
+    slot = slot + 1 == STAGES ? 0 : slot + 1;
+  }
+  __syncthreads();
+  float* so = reinterpret_cast<float*>(smem);          // [32][OROW]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        so[(i * 16 + (lane >> 4) * 4 + rr) * OROW + (wave * 2 + j) * 16 + (lane & 15)] = acc[i][j][rr];
+  __syncthreads();
+  float* __restrict__ ws = a.ws + (size_t)split * a.Cout * a.Ktot;
+  for (int v = tid; v < 32 * 32; v += 256) {
+    const int row = v >> 5, c4 = (v & 31) * 4;
+    const int k = tile_k * 128 + c4;
+    if (row < a.Cout && k < a.Ktot)
+      *reinterpret_cast<float4*>(ws + (size_t)row * a.Ktot + k) = *reinterpret_cast<const float4*>(so + row * OROW + c4);
+  }
+}
+
 int g_wgrad_variant = 0;    // 0: 64-pixel steps x 2 stages ; 1: 32 x 3 ; 2: 32 x 4 ; 3: 64 x 3 (one block per CU)
 
 template <int BP, int STAGES, bool SAME>
@@ -1105,8 +1276,27 @@ static int launch_wgrad_dma_t(const WgradArgs& a, unsigned grid, hipStream_t st,
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
+template <bool SAME, int STAGES>
+static int launch_wgrad_narrow_t(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
+  constexpr int LDS = STAGES * (64 * 64 + 64 * 256);   // 20 KiB per stage (the 32 x 132 fp32 epilogue staging fits inside)
+  static bool attr = false;
+  auto kern = conv_wgrad_dma_narrow_kernel<SAME, STAGES>;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, a, dyb, xb);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
 static int launch_wgrad_dma(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
   const bool same = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout;
+  if (a.Cout <= 32 && g_wgrad_variant != 5) {
+    if (g_wgrad_variant == 6) return same ? launch_wgrad_narrow_t<true, 2>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 2>(a, grid, st, dyb, xb);
+    if (g_wgrad_variant == 7) return same ? launch_wgrad_narrow_t<true, 5>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 5>(a, grid, st, dyb, xb);
+    return same ? launch_wgrad_narrow_t<true, 4>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 4>(a, grid, st, dyb, xb);
+  }
   switch (g_wgrad_variant) {
     case 1: return launch_wgrad_dma_t<32, 3, false>(a, grid, st, dyb, xb);
     case 3: return launch_wgrad_dma_t<64, 3, false>(a, grid, st, dyb, xb);
@@ -1226,7 +1416,8 @@ int mdcv_conv2d_set_variant(int v) {
 int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot) {
   const int bp = dtype == MDCV_BF16 ? 128 : 64;
   const int tiles = cdiv(Cout, 128) * cdiv(Ktot, 128);
-  int s = 512 / tiles;                    // 2 resident blocks per CU x 256 CUs: never spill into a second, nearly empty round
+  const int slots = 512;   // resident blocks: 2 per CU (wide tile 66 KiB; narrow tile 4 x 20 KiB ring)
+  int s = slots / tiles;                  // never spill into a second, nearly empty round
   const int max_s = cdiv(M, bp * 4);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
