@@ -14,23 +14,21 @@ namespace {
 struct Strip {
   int CV, PPI, PB;   // vectors per pixel, pixels per block-iteration, pixels per block
 };
-template <typename T> static Strip make_strip(int M, int C, int target_blocks) {
+template <typename T> static Strip make_strip(int M, int C, int target_blocks, int min_iters = 1) {
   Strip s;
   s.CV = C / ET<T>::VEC;
   s.PPI = 256 / s.CV; if (s.PPI < 1) s.PPI = 1;
   long long pb = ((long long)M + target_blocks - 1) / target_blocks;
   pb = ((pb + s.PPI - 1) / s.PPI) * s.PPI;
-  if (pb < s.PPI) pb = s.PPI;
+  if (pb < (long long)s.PPI * min_iters) pb = (long long)s.PPI * min_iters;   // amortise the per-block prologue / fold
   s.PB = (int)pb;
   return s;
 }
 
 // reduction kernels end in one fp64 atomic per channel per block: keep (blocks x channels x sums) within a budget
 static int reduce_blocks(int C, int nsums) {
-  long long g = 131072LL / ((long long)C * nsums);
-  if (g > 1024) g = 1024;
-  if (g < 16) g = 16;
-  return (int)g;
+  (void)C; (void)nsums;
+  return 1024;     // partial rows are plain stores now (no atomics): cap only the row count the follow-up tree reduce has to read
 }
 
 // fold the per-thread channel-vector sums of a block: lanes that own the same channel vector are CV apart.
@@ -588,11 +586,11 @@ int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const f
   a.ld1 = ld1; a.ld2 = ld2; a.ldr = ldr; a.ldo = ldo; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MDCV_BF16) {
-    Strip s = make_strip<bf16_t>(M, C, 2048); if (s.CV > 256) return MDCV_EARG;
+    Strip s = make_strip<bf16_t>(M, C, 2048, 4); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
     hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
-    Strip s = make_strip<float>(M, C, 2048); if (s.CV > 256) return MDCV_EARG;
+    Strip s = make_strip<float>(M, C, 2048, 4); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
     hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else return MDCV_EARG;
@@ -602,7 +600,7 @@ int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const f
 
 // floats of scratch mdcv_bn_act_bwd_reduce needs (one [nsums][C] partial row per block)
 int mdcv_bn_act_bwd_reduce_ws_floats(int dtype, int M, int C, int nsums) {
-  const Strip s = dtype == MDCV_BF16 ? make_strip<bf16_t>(M, C, reduce_blocks(C, nsums)) : make_strip<float>(M, C, reduce_blocks(C, nsums));
+  const Strip s = dtype == MDCV_BF16 ? make_strip<bf16_t>(M, C, reduce_blocks(C, nsums), 8) : make_strip<float>(M, C, reduce_blocks(C, nsums), 8);
   return cdiv(M, s.PB) * nsums * C;
 }
 
@@ -619,11 +617,11 @@ int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1,
   const int nsums = y2 ? 3 : 2;
   int rows = 0;
   if (dtype == MDCV_BF16) {
-    Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, nsums)); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
+    Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
-    Strip s = make_strip<float>(M, C, reduce_blocks(C, nsums)); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
+    Strip s = make_strip<float>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, a);
   } else return MDCV_EARG;
@@ -654,11 +652,11 @@ int mdcv_bn_act_bwd_apply(int dtype, const void* dout, int ldd, const void* y1, 
   a.ldd = ldd; a.ld1 = ld1; a.ld2 = ld2; a.ldy1 = ldy1; a.ldy2 = ldy2; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MDCV_BF16) {
-    Strip s = make_strip<bf16_t>(M, C, 2048); if (s.CV > 256) return MDCV_EARG;
+    Strip s = make_strip<bf16_t>(M, C, 2048, 4); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
-    Strip s = make_strip<float>(M, C, 2048); if (s.CV > 256) return MDCV_EARG;
+    Strip s = make_strip<float>(M, C, 2048, 4); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else return MDCV_EARG;
