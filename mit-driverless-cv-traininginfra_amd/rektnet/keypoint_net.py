@@ -49,16 +49,10 @@ class _KpPlan(_NetPlan):
         return self._dhm
 
     def run_backward(self, gout):
-        st = torch.cuda.current_stream().cuda_stream
         if self.use_graph:
-            g = self.graphs_bwd.get(self.flags)
-            if g is None:
-                self.run(self.bwd, st)
-                self.graphs_bwd[self.flags] = self.capture("bwd", st)
-            else:
-                self.L.check(self.L.graph_launch(g, st), "graph_launch")
+            self._graphed("bwd")          # one graph per (dpts, dhm) presence combination (self.flags)
         else:
-            self.run(self.bwd, st)
+            self.run(self.bwd, torch.cuda.current_stream().cuda_stream)
 
 
 class KeypointNet(nn.Module, FlatParamsMixin):

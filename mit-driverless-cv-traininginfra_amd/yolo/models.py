@@ -215,23 +215,35 @@ class _NetPlan(Plan):
         st = torch.cuda.current_stream().cuda_stream
         self.run(self.pre, st)
         if self.use_graph:
-            if self.graph_fwd is None:
-                self.run(self.fwd, st)                                 # warm run (function attributes, lazy buffers)
-                self.graph_fwd = self.capture("fwd", st)
-            else:
-                self.L.check(self.L.graph_launch(self.graph_fwd, st), "graph_launch")
+            self._graphed("fwd")
         else:
             self.run(self.fwd, st)
+
+    def _graphed(self, which):
+        """Replay (first call: warm run + capture) a launch list as a hipGraph.  Capture is illegal on the legacy default
+        stream, so graph mode runs on a side stream fenced against the caller's stream on both sides."""
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_gstream", None) is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+            self._graphs = {}
+        gs = self._gstream
+        gs.wait_stream(cur)
+        with torch.cuda.stream(gs):
+            key = (which, getattr(self, "flags", None))
+            g = self._graphs.get(key)
+            lst = self.fwd if which == "fwd" else self.bwd
+            if g is None:
+                self.run(lst, gs.cuda_stream)                          # warm run (function attributes, lazy buffers)
+                self._graphs[key] = self.capture(which, gs.cuda_stream)
+            else:
+                self.L.check(self.L.graph_launch(g, gs.cuda_stream), "graph_launch")
+        cur.wait_stream(gs)
 
     def run_backward(self, gout):
         st = torch.cuda.current_stream().cuda_stream
         self.gscale.copy_(gout.reshape(-1)[:self.gscale.numel()], non_blocking=True)
         if self.use_graph:
-            if self.graph_bwd is None:
-                self.run(self.bwd, st)
-                self.graph_bwd = self.capture("bwd", st)
-            else:
-                self.L.check(self.L.graph_launch(self.graph_bwd, st), "graph_launch")
+            self._graphed("bwd")
         else:
             self.run(self.bwd, st)
 

@@ -534,3 +534,22 @@ def test_tiny_cfg_structure_and_train_step_vs_oracle(tmp_path):
         _, i, mod, leaf = n.split(".")
         r = orc.params[("conv" if mod.startswith("conv") else "bn") + f"{i}.{leaf}"].grad
         assert relerr(p.grad.cpu(), r) < 2e-3, (n, relerr(p.grad.cpu(), r))
+
+
+def test_hipgraph_replay_matches_eager():
+    """MDCV_GRAPH=1: forward/backward launch lists captured into hipGraphs reproduce the eager step bit for bit."""
+    z = load("mini_darknet.npz")
+    x, tg = T(z["x"]).cuda(), T(z["targets"]).cuda()
+    res = {}
+    for graph in (False, True):
+        net = make_mini("fp32")
+        net.use_graph = graph
+        net.train()
+        for it in range(3):                       # it 0: eager warm run + capture ; it 1,2: replays
+            for p in net.parameters():
+                p.grad = None
+            out = net(x, tg)
+            out[0].backward()
+        res[graph] = (torch.stack([o.detach() for o in out]).cpu(), net.flat_parameters()[1].clone().cpu())
+    assert torch.equal(res[False][0], res[True][0])
+    assert relerr(res[True][1], res[False][1]) < 1e-6
