@@ -116,6 +116,29 @@ int mdcv_cross_ratio_loss(const float* hm, const float* pts, const float* thm, c
                           int include_geo, float gamma_horz, float gamma_vert, double* acc_ws, const float* gscale, float* out3,
                           float* dpts, float* dhm, void* stream);
 
+/* ---- detection post-processing: replaces the per-image Python loop validate.py:80-141, the sequential
+ *      greedy NMS utils/nms.py:4-61 and average_precision/compute_ap utils/utils.py:58-119.
+ *      Visiting order: descending score, equal scores by descending index (the reference's ascending sort walked from the
+ *      back, nms.py:25-32; its CPU sort is unstable past 16 elements, so for ties this is the stable-sort behaviour).
+ *      top_k <= MDCV_NMS_MAX_TOPK (the reference always uses 200, nms.py:4 / validate.py:93); larger is MDCV_EARG. */
+#define MDCV_NMS_MAX_TOPK 512
+long long mdcv_nms_workspace_bytes(int n);
+/* boxes [n,4] corner format, scores [n]; keep[0..*count) <- kept indices in visiting order (keep has room for min(n,top_k));
+ * count is a device int.  n == 0 gives *count = 0 (nms.py:17-18). */
+int mdcv_nms(const float* boxes, const float* scores, int n, float overlap, int top_k, long long* keep, int* count, void* workspace,
+             void* stream);
+long long mdcv_detect_post_workspace_bytes(int B, int N);
+/* pred [B,N,5+C] eval-mode rows (cx,cy,w,h,conf,cls...), targets [B,T,5] zero-padded (cls,cx,cy,w,h) or NULL with T = 0.
+ * Per image b: out_count[b] kept detections in descending confidence; out_boxes [B,top_k,4] corner, out_prob, out_cls (first
+ * argmax), out_index (row in N), out_correct [B,top_k]; out_stats [B,4] = (AP, recall, precision, valid) with valid = 0 where the
+ * reference loop `continue`s (no detection kept, validate.py:97, or no real label, validate.py:120). */
+int mdcv_detect_post(const float* pred, int B, int N, int C, const float* targets, int T, float conf_thres, float nms_thres,
+                     float iou_thres, float width, float height, int top_k, float* out_boxes, float* out_prob, int* out_cls,
+                     long long* out_index, unsigned char* out_correct, int* out_count, float* out_stats, void* workspace,
+                     void* stream);
+/* utils.py:58-88 on its own: tp u8[m], conf f32[m], 1 <= m <= MDCV_NMS_MAX_TOPK; out3 = (AP, recall, precision). */
+int mdcv_average_precision(const unsigned char* tp, const float* conf, int m, int n_gt, float* out3, void* stream);
+
 /* ---- optimizer step over the flat fp32 parameter buffer (train.py:180-187,72 ; train_eval.py:263,72) */
 int mdcv_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, void* stream);

@@ -1,7 +1,9 @@
-"""GPU drop-ins for the two hot-path helpers of the reference's CVC-YOLOv3/utils/utils.py:
+"""GPU drop-ins for the helpers of the reference's CVC-YOLOv3/utils/utils.py that sit on the train / validate path:
 
-  bbox_iou       (utils.py:163-193)  — tiny elementwise helper, plain torch on whatever device the boxes live on
-  build_targets  (utils.py:195-275)  — HIP kernel (csrc/yolo_head.hip), bit-exact masks / indices
+  bbox_iou          (utils.py:163-193)  — tiny elementwise helper, plain torch on whatever device the boxes live on
+  build_targets     (utils.py:195-275)  — HIP kernel (csrc/yolo_head.hip), bit-exact masks / indices
+  xywh2xyxy         (utils.py:121-127)  — elementwise helper, plain torch on the boxes' device
+  average_precision (utils.py:58-88) / compute_ap (utils.py:90-119) — HIP kernel (csrc/postprocess.hip)
 
 Return order and dtypes follow the reference: mask, conf_mask (uint8), tx, ty, tw, th, tconf (float32), tcls (uint8).
 """
@@ -55,3 +57,39 @@ def build_targets(target, anchors, num_anchors, num_classes, grid_size_h, grid_s
     if int(err.item()) != 0:
         raise IndexError("build_targets: a target centre falls outside the grid (cx or cy >= 1.0)")
     return mask, conf_mask, tx, ty, tw, th, tconf, tcls
+
+
+def xywh2xyxy(x):
+    """[x, y, w, h] -> [x1, y1, x2, y2] on the tensor's own device (utils.py:121-127)."""
+    y = torch.zeros(x.shape, device=x.device, dtype=x.dtype)
+    half_w, half_h = x[:, 2] / 2, x[:, 3] / 2
+    y[:, 0], y[:, 1] = x[:, 0] - half_w, x[:, 1] - half_h
+    y[:, 2], y[:, 3] = x[:, 0] + half_w, x[:, 1] + half_h
+    return y
+
+
+def average_precision(tp, conf, n_gt):
+    """(ap, recall, precision) as 0-d float32 GPU tensors; tp / conf are 1-D GPU tensors with 1..512 entries.
+
+    Detections are taken by descending confidence, equal confidences in their given order (utils.py:71-72)."""
+    _lib.require_gpu(conf)
+    L = _lib.lib()
+    m = int(conf.shape[0])
+    if not 0 < m <= 512:
+        raise ValueError(f"average_precision: 1..512 detections supported (got {m})")
+    t8 = (tp.detach() != 0).to(torch.uint8).contiguous()
+    cf = conf.detach().to(torch.float32).contiguous()
+    out = torch.empty(3, dtype=torch.float32, device=conf.device)
+    L.check(L.average_precision(t8.data_ptr(), cf.data_ptr(), m, int(n_gt), out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+            "average_precision")
+    return out[0], out[1], out[2]
+
+
+def compute_ap(recall, precision):
+    """Area under the precision envelope (utils.py:90-119), torch ops on the curves' own device."""
+    z, o = recall.new_zeros(1), recall.new_ones(1)
+    mrec = torch.cat((z, recall, o))
+    mpre = torch.cat((z.to(precision.dtype), precision, z.to(precision.dtype)))
+    mpre = torch.flip(torch.cummax(torch.flip(mpre, (0,)), 0)[0], (0,))
+    i = torch.nonzero(mrec[1:] != mrec[:-1])
+    return torch.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])

@@ -5,6 +5,7 @@ Run in the build container only (needs /root/reference, which never travels):
 
     python tests/golden/make_golden.py yolo
     python tests/golden/make_golden.py rektnet
+    python tests/golden/make_golden.py post
 
 Two invocations because CVC-YOLOv3/utils is a package and RektNet/utils.py a module
 (SURVEY.md §8c).  Writes tests/golden/*.npz (+ the mini cfg's .weights / train.csv).
@@ -399,6 +400,169 @@ def gen_rektnet():
     npz("rektnet_dp.npz", **dp)
 
 
+# ----------------------------------------------------------------------------
+# Detection post-processing: utils/nms.py, utils/utils.py AP/IoU.
+def dedup(x, gen):
+    """Make all values distinct.  The reference's `scores.sort(0)` (nms.py:25) is an UNSTABLE sort on
+    CPU for n > 16, so the visiting order of equal scores is implementation-defined there; vectors
+    that pin the tie rule are kept at n <= 16 (where it degenerates to a stable insertion sort) and
+    every larger vector has distinct scores."""
+    x = x.clone()
+    for _ in range(200):
+        _, inv, cnt = torch.unique(x, return_inverse=True, return_counts=True)
+        dup = cnt[inv] > 1
+        if not bool(dup.any()):
+            return x
+        x[dup] = x[dup] + (torch.rand(int(dup.sum()), generator=gen) - 0.5) * 1e-4
+    raise RuntimeError("dedup failed")
+
+
+def synth_boxes(n, gen, span=416.0, clusters=None, quant=None, degenerate=0):
+    """Corner boxes in clusters (so NMS has work to do) + scores; optional score
+    quantisation (forces ties) and zero-area boxes."""
+    k = clusters or max(1, n // 12)
+    cen = torch.rand(k, 2, generator=gen) * span
+    wh = torch.rand(k, 2, generator=gen) * 60 + 8
+    which = torch.randint(0, k, (n,), generator=gen)
+    c = cen[which] + torch.randn(n, 2, generator=gen) * 4
+    s = wh[which] * (1 + 0.15 * torch.randn(n, 2, generator=gen)).clamp(0.3, 2.0)
+    boxes = torch.cat([c - s / 2, c + s / 2], 1).float()
+    scores = torch.rand(n, generator=gen)
+    if quant:
+        assert n <= 16, "tie vectors only where the reference's sort is stable"
+        scores = torch.round(scores * quant) / quant
+    else:
+        scores = dedup(scores, gen)
+    for d in range(min(degenerate, n)):
+        boxes[d * 3 % n, 2:] = boxes[d * 3 % n, :2]       # zero area -> 0/0 IoU with itself only
+    return boxes, scores
+
+
+def synth_eval_output(B, N, C, T, gen, span, conf_lo=0.0, empty_labels=(), no_dets=()):
+    """An eval-mode Darknet output [B,N,5+C] built around padded labels [B,T,5]:
+    a few jittered detections per label with high confidence + clutter."""
+    tg = synth_targets(B, T, gen, min_real=1, cls_hi=max(1, C))
+    out = torch.zeros(B, N, 5 + C)
+    for b in range(B):
+        if b in empty_labels:
+            tg[b] = 0
+        real = tg[b][(tg[b, :, 1:5] > 0).all(1)]
+        out[b, :, 0:2] = torch.rand(N, 2, generator=gen) * span
+        out[b, :, 2:4] = torch.rand(N, 2, generator=gen) * 80 + 4
+        out[b, :, 4] = torch.rand(N, generator=gen) * 0.6 + conf_lo
+        out[b, :, 5:] = torch.rand(N, C, generator=gen)
+        rows = torch.randperm(N, generator=gen)
+        r = 0
+        for lab in real:
+            for _ in range(int(torch.randint(1, 6, (1,), generator=gen))):
+                if r >= N:
+                    break
+                i = rows[r]; r += 1
+                jit = 1 + 0.08 * torch.randn(4, generator=gen)
+                out[b, i, 0:4] = lab[1:5] * span * jit
+                out[b, i, 4] = 0.8 + 0.2 * torch.rand(1, generator=gen)
+        out[b, :, 4] = dedup(out[b, :, 4], gen)
+        if b in no_dets:
+            out[b, :, 4] = 0.01
+    return out.float(), tg.float()
+
+
+def gen_post():
+    sys.path.insert(0, os.path.join(REF, "CVC-YOLOv3"))
+    from utils.nms import nms
+    from utils.utils import average_precision, compute_ap, bbox_iou, xywh2xyxy
+    gen = torch.Generator().manual_seed(4242)
+
+    # --- nms: (n, overlap, top_k, quant, degenerate)
+    cases = [(0, 0.5, 200, None, 0), (1, 0.5, 200, None, 0), (2, 0.25, 200, None, 0), (37, 0.5, 200, None, 0),
+             (200, 0.25, 200, None, 0), (300, 0.5, 200, None, 3), (1000, 0.25, 200, None, 0), (1000, 0.5, 50, None, 0),
+             (5000, 0.45, 200, None, 5), (10647, 0.25, 200, None, 0), (10647, 0.6, 512, None, 0), (64, 0.0, 200, None, 2),
+             (450, 1.0, 200, None, 0), (16, 0.5, 200, 4, 0), (16, 0.3, 5, 2, 1), (12, 0.9, 200, 3, 0), (9, 0.5, 200, 1, 0),
+             (16, 0.5, 200, 8, 0)]
+    arrs = {"n_cases": len(cases)}
+    for ci, (n, ov, tk, q, dg) in enumerate(cases):
+        boxes, scores = synth_boxes(n, gen, quant=q, degenerate=dg) if n else (torch.zeros(0, 4), torch.zeros(0))
+        if ci == 3:                       # exact duplicates
+            boxes[5:10] = boxes[4]
+        keep = nms(boxes, scores, ov, tk)
+        arrs.update({f"boxes{ci}": boxes, f"scores{ci}": scores, f"overlap{ci}": np.float32(ov), f"topk{ci}": tk, f"keep{ci}": keep})
+    npz("post_nms.npz", **arrs)
+
+    # --- average_precision / compute_ap
+    arrs = {}
+    ms = [1, 2, 3, 7, 20, 57, 128, 200, 200, 200, 12, 16, 16]
+    arrs["n_cases"] = len(ms)
+    for ci, m in enumerate(ms):
+        conf = torch.sort(torch.rand(m, generator=gen), descending=True)[0]
+        if ci % 3 == 2 and m <= 16:       # ties: average_precision's sort(-conf) is unstable past 16 elements
+            conf = torch.round(conf * 4) / 4
+        else:
+            conf = torch.sort(dedup(conf, gen), descending=True)[0]
+        tp = (torch.rand(m, generator=gen) < (0.0 if ci == 1 else 1.0 if ci == 2 else 0.55)).to(torch.uint8)
+        n_gt = max(1, int(tp.sum()) + int(torch.randint(0, 9, (1,), generator=gen)))
+        ap, r, p = average_precision(tp=tp, conf=conf, n_gt=n_gt)
+        arrs.update({f"tp{ci}": tp, f"conf{ci}": conf, f"ngt{ci}": n_gt, f"apr{ci}": torch.stack([ap, r, p])})
+    rec = torch.sort(torch.rand(40, generator=gen))[0]
+    pre = torch.rand(40, generator=gen)
+    arrs.update(ca_rec=rec, ca_pre=pre, ca_ap=compute_ap(rec, pre))
+    npz("post_ap.npz", **arrs)
+
+    # --- the per-image loop validate.py:80-141, driven through the reference's own functions
+    def per_image(det, labels, conf_t, nms_t, iou_t, W, H):
+        det = det[det[:, 4] > conf_t]
+        cls = torch.argmax(det[:, 5:], dim=1) if det.shape[0] else torch.zeros(0, dtype=torch.long)
+        half = det[:, 2:4] / 2
+        corner = torch.zeros(det.shape[0], 4)
+        corner[:, 0:2] = det[:, 0:2] - half
+        corner[:, 2:4] = det[:, 0:2] + half
+        prob = det[:, 4]
+        keep = nms(corner, prob, nms_t)
+        res = dict(count=keep.shape[0], boxes=corner[keep], prob=prob[keep], cls=cls[keep], valid=False,
+                   correct=torch.zeros(keep.shape[0], dtype=torch.uint8), apr=torch.zeros(3))
+        if keep.shape[0] == 0:
+            return res
+        order = torch.sort(-res["prob"])[1]
+        for k in ("boxes", "prob", "cls"):
+            res[k] = res[k][order]
+        labels = labels[(labels[:, 1:5] <= 0).sum(dim=1) == 0]
+        if labels.shape[0] == 0:
+            return res
+        tb = xywh2xyxy(labels[:, 1:5])
+        tb[:, (0, 2)] *= W
+        tb[:, (1, 3)] *= H
+        nd, nt = res["boxes"].shape[0], tb.shape[0]
+        ious = bbox_iou(res["boxes"].unsqueeze(1).expand(-1, nt, -1), tb.unsqueeze(0).expand(nd, -1, -1))
+        best = torch.argmax(ious, dim=1)
+        taken = torch.zeros(nt, dtype=torch.uint8)
+        for i in range(nd):
+            if ious[i, best[i]] > iou_t and taken[best[i]] == 0:
+                res["correct"][i] = 1
+                taken[best[i]] = 1
+        res["apr"] = torch.stack(average_precision(tp=res["correct"], conf=res["prob"], n_gt=labels.shape[0]))
+        res["valid"] = True
+        return res
+
+    vcases = [  # name, B, N, C, T, span(W,H), conf, nms, iou, quant, empty_labels, no_dets
+        ("a", 3, 10647, 1, 30, 416, 0.5, 0.25, 0.5, None, (), ()),
+        ("b", 4, 507, 80, 12, 416, 0.3, 0.5, 0.5, 64, (1,), (2,)),
+        ("c", 2, 3000, 1, 50, 608, 0.8, 0.25, 0.5, None, (), ()),
+        ("d", 2, 2028, 3, 20, 416, 0.0, 0.4, 0.25, 32, (), ()),
+    ]
+    for (name, B, N, C, T, span, ct, nt_, it, q, el, nd_) in vcases:
+        out, tg = synth_eval_output(B, N, C, T, gen, float(span), empty_labels=el, no_dets=nd_)
+        arrs = dict(out=out, targets=tg, conf_thres=np.float32(ct), nms_thres=np.float32(nt_), iou_thres=np.float32(it),
+                    width=span, height=span)
+        aps, rs, ps = [], [], []
+        for b in range(B):
+            r = per_image(out[b], tg[b], ct, nt_, it, span, span)
+            arrs.update({f"count{b}": r["count"], f"boxes{b}": r["boxes"], f"prob{b}": r["prob"], f"cls{b}": r["cls"],
+                         f"correct{b}": r["correct"], f"apr{b}": r["apr"], f"valid{b}": r["valid"]})
+            if r["valid"]:
+                aps.append(r["apr"][0]); rs.append(r["apr"][1]); ps.append(r["apr"][2])
+        arrs["means"] = torch.stack([torch.tensor(v, dtype=torch.float).mean() for v in (aps, rs, ps)])
+        npz(f"post_validate_{name}.npz", **arrs)
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"yolo": gen_yolo, "rektnet": gen_rektnet}[which]()
+    {"yolo": gen_yolo, "rektnet": gen_rektnet, "post": gen_post}[which]()

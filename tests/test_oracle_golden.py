@@ -206,3 +206,47 @@ def test_cross_ratio_loss_all_variants():
 def test_oracle_rektnet_init_param_count():
     sd = ro.init_state(0)
     assert sum(v.numel() for k, v in sd.items() if "running" not in k) == 311383
+
+
+# ---------------------------------------------------------------------------
+# Detection post-processing — oracle/postprocess_oracle.py
+from oracle import postprocess_oracle as PO
+
+
+def test_post_nms_golden():
+    g = np.load(os.path.join(G, "post_nms.npz"))
+    for ci in range(int(g["n_cases"])):
+        keep = PO.nms(g[f"boxes{ci}"], g[f"scores{ci}"], float(g[f"overlap{ci}"]), int(g[f"topk{ci}"]))
+        assert keep.dtype == np.int64
+        np.testing.assert_array_equal(keep, g[f"keep{ci}"], err_msg=f"case {ci}")
+
+
+def test_post_average_precision_golden():
+    g = np.load(os.path.join(G, "post_ap.npz"))
+    for ci in range(int(g["n_cases"])):
+        ap, r, p = PO.average_precision(g[f"tp{ci}"], g[f"conf{ci}"], int(g[f"ngt{ci}"]))
+        ref = g[f"apr{ci}"]
+        assert abs(float(ap) - float(ref[0])) <= 1e-6, ci
+        assert float(r) == float(ref[1]) and (float(p) == float(ref[2]) or (np.isnan(p) and np.isnan(ref[2]))), ci
+    assert abs(float(PO.compute_ap(g["ca_rec"], g["ca_pre"])) - float(g["ca_ap"])) <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_post_validate_loop_golden(name):
+    g = np.load(os.path.join(G, f"post_validate_{name}.npz"))
+    out, tg = g["out"], g["targets"]
+    args = (float(g["conf_thres"]), float(g["nms_thres"]), float(g["iou_thres"]), float(g["width"]), float(g["height"]))
+    for b in range(out.shape[0]):
+        r = PO.postprocess_image(out[b], tg[b], *args)
+        assert r["count"] == int(g[f"count{b}"]), b
+        assert bool(r["valid"]) == bool(g[f"valid{b}"]), b
+        np.testing.assert_array_equal(r["boxes"], g[f"boxes{b}"])
+        np.testing.assert_array_equal(r["prob"], g[f"prob{b}"])
+        np.testing.assert_array_equal(r["cls"], g[f"cls{b}"])
+        if r["valid"]:
+            np.testing.assert_array_equal(r["correct"], g[f"correct{b}"])
+            ref = g[f"apr{b}"]
+            assert abs(float(r["ap"]) - float(ref[0])) <= 1e-6
+            assert float(r["r"]) == float(ref[1]) and float(r["p"]) == float(ref[2])
+    m = PO.validate_batches([out], [tg], *args)
+    np.testing.assert_allclose(np.asarray(m[:3], np.float32), g["means"], atol=1e-6)
