@@ -16,6 +16,7 @@ import sys
 import tempfile
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -199,12 +200,53 @@ def cpu_baseline_rektnet(budget_s=12.0):
             "sample": f"RektNet 80^2 fp32 CPU oracle, batch {B}, {len(steady)} timed train steps after 1 warm-up (Adam, l1_softargmax+geo)"}
 
 
+def synth_eval_output(B, N, C, T, seed):
+    """Eval-mode Darknet output rows around synthetic cone labels: 1-5 jittered high-confidence rows per label + clutter
+    below the threshold, like a trained detector's output."""
+    rng = np.random.default_rng(seed)
+    tg = np.zeros((B, T, 5), np.float32)
+    out = np.zeros((B, N, 5 + C), np.float32)
+    for b in range(B):
+        n = int(rng.integers(1, T + 1))
+        tg[b, :n, 0] = rng.integers(0, C, n)
+        tg[b, :n, 1:3] = rng.random((n, 2)) * 0.9 + 0.05
+        tg[b, :n, 3:5] = rng.random((n, 2)) * 0.28 + 0.02
+        out[b, :, 0:2] = rng.random((N, 2)) * 416
+        out[b, :, 2:4] = rng.random((N, 2)) * 80 + 4
+        out[b, :, 4] = rng.random(N) * 0.85
+        out[b, :, 5:] = rng.random((N, C))
+        rows = rng.permutation(N)
+        r = 0
+        for lab in tg[b, :n]:
+            for _ in range(int(rng.integers(1, 6))):
+                i = rows[r]; r += 1
+                out[b, i, 0:4] = lab[1:5] * 416 * (1 + 0.08 * rng.standard_normal(4))
+                out[b, i, 4] = 0.8 + 0.2 * rng.random()
+    return out, tg
+
+
+def cpu_baseline_post(out_np, tg_np, budget_s=10.0):
+    """The numpy oracle of the per-image loop on this host (1 thread), bounded sample of the same batch."""
+    from oracle import postprocess_oracle as PO
+    t0 = time.perf_counter()
+    n = 0
+    for det, lab in zip(out_np, tg_np):
+        PO.postprocess_image(det, lab, 0.8, 0.25, 0.5, 416, 416)
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/sec", "cores": 1, "kind": "port",
+            "sample": f"numpy oracle of validate.py:80-141 on {n} images of the same batch ([10647, 85] rows each)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="both", choices=["both", "yolo", "rektnet"])
+    ap.add_argument("--workload", default="both", choices=["both", "yolo", "rektnet", "postprocess"])
+    ap.add_argument("--post-batch", type=int, default=32, help="images per GPU for the detection post-processing workload")
     ap.add_argument("--yolo-batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--rekt-batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -337,16 +379,42 @@ def main():
         if a.workload == "rektnet":
             result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
 
+    if a.workload in ("both", "postprocess"):
+        # validate.py's per-image loop for one batch of eval outputs [B, 10647, 85] (416^2, 80 classes),
+        # thresholds of yolo_baseline.cfg:17-20.  Images are independent: ranks shard them, no collective.
+        from mdcv.yolo.postprocess import detect_postprocess
+        B, N, C, T = a.post_batch, 10647, 80, 16
+        out_np, tg_np = synth_eval_output(B, N, C, T, 3000 + rank)
+        outp, tgp = torch.from_numpy(out_np).to(device), torch.from_numpy(tg_np).to(device)
+
+        def post_step():
+            return detect_postprocess(outp, tgp, 0.8, 0.25, 0.5, 416, 416)
+        dt = timed_region(post_step, max(a.steps, 50), a.warmup, device, world)
+        nst = max(a.steps, 50)
+        det = post_step()
+        extra["postprocess"] = {"images_per_sec": B * world * nst / dt, "ms_per_batch": 1e3 * dt / nst, "batch_per_gpu": B,
+                                "rows_per_image": N, "classes": C, "kept_mean": float(det.count.float().mean()),
+                                "mean_ap": float(det.stats[det.stats[:, 3] > 0, 0].mean()),
+                                # HBM floor: the confidence column is one 4-byte word out of every 340-byte row, so the
+                                # filter touches every 64-byte sector that holds one -> ~B*N*64 bytes
+                                "hbm_floor_us": B * N * 64 / (PEAK_HBM_GBS * 1e9) * 1e6}
+        if a.workload == "postprocess":
+            result = {"ms_per_step": 1e3 * dt / nst, "value": B * world * nst / dt}
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            extra["postprocess"]["cpu_baseline"] = cpu_baseline_post(out_np, tg_np)
+
     if rank == 0:
-        primary = "rektnet" if a.workload == "rektnet" else "yolo"
+        primary = a.workload if a.workload in ("rektnet", "postprocess") else "yolo"
         line = {
             "metric": "images/sec training (YOLOv3 416^2 + RektNet 80^2)", "value": result["value"], "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": result["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": ("CVC-YOLOv3 yolo_baseline 416x416 classes=80, train step (fwd+bwd+Adam), %d img/GPU" % a.yolo_batch)
-                       if primary == "yolo" else ("RektNet KeypointNet 80x80 train step (l1_softargmax+geo, Adam), %d img/GPU" % a.rekt_batch),
-                       "global_batch": (a.yolo_batch if primary == "yolo" else a.rekt_batch) * world, "parallelism": f"dp{world}",
-                       "hipgraph": bool(a.graph)},
+            "config": {"workload": {"yolo": "CVC-YOLOv3 yolo_baseline 416x416 classes=80, train step (fwd+bwd+Adam), %d img/GPU" % a.yolo_batch,
+                                    "rektnet": "RektNet KeypointNet 80x80 train step (l1_softargmax+geo, Adam), %d img/GPU" % a.rekt_batch,
+                                    "postprocess": "validate.py per-image loop (conf 0.8, NMS 0.25 top-200, AP) on [%d,10647,85] eval outputs"
+                                                   % a.post_batch}[primary],
+                       "global_batch": {"yolo": a.yolo_batch, "rektnet": a.rekt_batch, "postprocess": a.post_batch}[primary] * world,
+                       "parallelism": f"dp{world}", "hipgraph": bool(a.graph)},
             "workloads": extra,
         }
         if "roofline" in result:
@@ -354,7 +422,8 @@ def main():
         else:
             line["roofline"] = None
         if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline_yolo(cfg, tmp) if primary == "yolo" else cpu_baseline_rektnet()
+            cb = (cpu_baseline_yolo(cfg, tmp) if primary == "yolo" else cpu_baseline_rektnet() if primary == "rektnet"
+                  else extra["postprocess"]["cpu_baseline"])
             line["cpu_baseline"] = cb
             if a.workload == "both":
                 line["workloads"]["rektnet"]["cpu_baseline"] = cpu_baseline_rektnet()

@@ -48,11 +48,11 @@ def detect_postprocess(output, targets, conf_thres, nms_thres, iou_thres, width,
             raise ValueError("detect_postprocess: targets must be [B, T, 5]")
         T = int(tg.shape[1])
     k = int(top_k)
-    boxes = torch.zeros(B, k, 4, dtype=torch.float32, device=dev)
-    prob = torch.zeros(B, k, dtype=torch.float32, device=dev)
-    cls = torch.zeros(B, k, dtype=torch.int32, device=dev)
-    index = torch.zeros(B, k, dtype=torch.long, device=dev)
-    correct = torch.zeros(B, k, dtype=torch.uint8, device=dev)
+    boxes = torch.empty(B, k, 4, dtype=torch.float32, device=dev)      # the kernel writes every entry (zeros past count[b])
+    prob = torch.empty(B, k, dtype=torch.float32, device=dev)
+    cls = torch.empty(B, k, dtype=torch.int32, device=dev)
+    index = torch.empty(B, k, dtype=torch.long, device=dev)
+    correct = torch.empty(B, k, dtype=torch.uint8, device=dev)
     count = torch.empty(B, dtype=torch.int32, device=dev)
     stats = torch.empty(B, 4, dtype=torch.float32, device=dev)
     ws = torch.empty(int(L.detect_post_workspace_bytes(B, N)), dtype=torch.uint8, device=dev)

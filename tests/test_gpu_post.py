@@ -153,6 +153,9 @@ def test_detect_postprocess_full_size_vs_oracle(B, N, C, T, span, conf, sat):
     # size-independent properties: kept confidences sorted, every kept box above the threshold, counts bounded
     cnt = det.count.cpu().numpy()
     assert cnt.max() <= 200
+    for b in range(B):                           # entries past count[b] are zeros
+        assert float(det.boxes[b, cnt[b]:].abs().sum()) == 0 and int(det.index[b, cnt[b]:].abs().sum()) == 0
+        assert float(det.prob[b, cnt[b]:].abs().sum()) == 0 and int(det.correct[b, cnt[b]:].sum()) == 0
     for b in range(B):
         p = det.prob[b, :cnt[b]].cpu().numpy()
         assert np.all(p[:-1] >= p[1:]) and np.all(p > conf)
