@@ -139,6 +139,15 @@ int mdcv_detect_post(const float* pred, int B, int N, int C, const float* target
 /* utils.py:58-88 on its own: tp u8[m], conf f32[m], 1 <= m <= MDCV_NMS_MAX_TOPK; out3 = (AP, recall, precision). */
 int mdcv_average_precision(const unsigned char* tp, const float* conf, int m, int n_gt, float* out3, void* stream);
 
+/* ---- detect -> crop -> keypoints glue.  Cuts box k < count[b] of frame b out of frames [B,C,H,W] (fp32) and
+ *      resamples it to out_h x out_w with cv2.resize's default bilinear rule (RektNet/utils.py:73-76 prep_image; layout of
+ *      RektNet/detect.py:33-35: [M,C,out_h,out_w]).  Boxes [B,K,4] are corner boxes in detector coordinates and are mapped to
+ *      frame pixels as x * scale_x + off_x (CVC-YOLOv3/detect.py:98-101), rounded outwards and clamped to the frame.
+ *      Crops are packed image-major: out row m, owner[m] = b, *total = M (device ints; out / owner hold B*K rows).
+ *      out_h, out_w <= 256. */
+int mdcv_crop_resize(const float* frames, int B, int C, int H, int W, const float* boxes, const int* count, int K, float scale_x,
+                     float scale_y, float off_x, float off_y, int out_h, int out_w, float* out, int* owner, int* total, void* stream);
+
 /* ---- optimizer step over the flat fp32 parameter buffer (train.py:180-187,72 ; train_eval.py:263,72) */
 int mdcv_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, void* stream);

@@ -250,3 +250,36 @@ def test_post_validate_loop_golden(name):
             assert float(r["r"]) == float(ref[1]) and float(r["p"]) == float(ref[2])
     m = PO.validate_batches([out], [tg], *args)
     np.testing.assert_allclose(np.asarray(m[:3], np.float32), g["means"], atol=1e-6)
+
+
+# ---------------------------------------------------------------------------
+# detect -> crop -> keypoints glue — oracle/pipeline_oracle.py
+from oracle import pipeline_oracle as PL
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (17, 9), (80, 80), (160, 121), (300, 40)])
+def test_resize_bilinear_matches_independent_implementation(h, w):
+    """cv2 is absent: cross-check the restated INTER_LINEAR against torch's half-pixel bilinear (same convention)."""
+    rng = np.random.default_rng(h * 1000 + w)
+    img = rng.random((3, h, w), dtype=np.float32)
+    got = PL.resize_bilinear(img, 80, 80)
+    ref = torch.nn.functional.interpolate(T(img)[None], size=(80, 80), mode="bilinear", align_corners=False)[0].numpy()
+    np.testing.assert_allclose(got, ref, atol=1e-5, rtol=0)
+    if (h, w) == (80, 80):
+        np.testing.assert_array_equal(got, img)           # identity at scale 1
+
+
+def test_crop_bounds_and_order():
+    H, W = 60, 100
+    assert PL.crop_bounds([10.2, 5.7, 20.1, 30.0], H, W) == (10, 5, 21, 30)
+    assert PL.crop_bounds([-5.0, -3.0, 2.5, 1.5], H, W) == (0, 0, 3, 2)
+    assert PL.crop_bounds([98.5, 58.2, 140.0, 90.0], H, W) == (98, 58, 100, 60)
+    assert PL.crop_bounds([150.0, 70.0, 160.0, 80.0], H, W) == (99, 59, 100, 60)      # fully outside: edge pixel
+    assert PL.crop_bounds([30.0, 20.0, 30.0, 20.0], H, W) == (30, 20, 31, 21)         # empty box: one pixel
+    assert PL.crop_bounds([10.0, 10.0, 20.0, 20.0], H, W, (2.0, 0.5), (-4.0, 3.0)) == (16, 8, 36, 13)
+    rng = np.random.default_rng(0)
+    frames = rng.random((2, 3, H, W), dtype=np.float32)
+    boxes = np.array([[[1, 1, 30, 40], [50, 10, 90, 50]], [[5, 5, 25, 25], [0, 0, 0, 0]]], np.float32)
+    crops, owner = PL.crop_resize(frames, boxes, [2, 1], 16, 8)
+    assert crops.shape == (3, 3, 16, 8) and owner.tolist() == [0, 0, 1]
+    np.testing.assert_array_equal(crops[2], PL.resize_bilinear(frames[1, :, 5:25, 5:25], 16, 8))
