@@ -245,7 +245,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="both", choices=["both", "yolo", "rektnet", "postprocess"])
+    ap.add_argument("--workload", default="both", choices=["both", "yolo", "rektnet", "postprocess", "joint"])
+    ap.add_argument("--joint-batch", type=int, default=32, help="608x608 frames per GPU for the joint detect->keypoints workload")
     ap.add_argument("--post-batch", type=int, default=32, help="images per GPU for the detection post-processing workload")
     ap.add_argument("--yolo-batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--rekt-batch", type=int, default=256, help="images per GPU")
@@ -403,17 +404,95 @@ def main():
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             extra["postprocess"]["cpu_baseline"] = cpu_baseline_post(out_np, tg_np)
 
+    if a.workload == "joint":
+        # BASELINE.json configs[4]: YOLOv3 608x608 detect -> batched RektNet crops; frames are independent, ranks shard them.
+        # A random-init detector in eval mode outputs a near-constant confidence (~0.5), so nothing passes conf 0.8.  The
+        # detector forward is run and timed for real; its output then gets synthetic cone detections written into a few rows
+        # per frame (1-5 jittered rows around each of 16 cones, one tiny scatter inside the timed region), so that NMS, the
+        # crops and KeypointNet all run on a realistic load with the cfg's own thresholds (conf 0.8, NMS 0.25).
+        from mdcv.pipeline import JointPipeline, crop_resize
+        from mdcv.yolo.postprocess import detect_postprocess
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            torch.manual_seed(0)
+            net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision=a.precision)
+        finally:
+            os.chdir(cwd)
+        net = net.to(device).eval()
+        kp = KeypointNet(7, (80, 80), precision=a.precision).to(device).eval()
+        B = a.joint_batch
+        g = torch.Generator().manual_seed(4000 + rank)
+        x = torch.rand(B, 3, 608, 608, generator=g).to(device)
+        rng = np.random.default_rng(4000 + rank)
+        rows, vals = [], []
+        for b in range(B):
+            perm = rng.permutation(22743)
+            r = 0
+            for _ in range(16):
+                cx, cy = rng.random(2) * 540 + 34
+                w, h = rng.random() * 40 + 14, rng.random() * 60 + 20
+                for _ in range(int(rng.integers(1, 6))):
+                    j = 1 + 0.06 * rng.standard_normal(4)
+                    rows.append(b * 22743 + perm[r]); r += 1
+                    vals.append([cx * j[0], cy * j[1], w * j[2], h * j[3], 0.8 + 0.2 * rng.random()])
+        rows_t = torch.tensor(np.asarray(rows), dtype=torch.long, device=device)
+        vals_t = torch.tensor(np.asarray(vals, np.float32), device=device)
+
+        class Seeded(torch.nn.Module):
+            def __init__(self, inner):
+                super().__init__()
+                self.inner = inner
+
+            def get_threshs(self):
+                return self.inner.get_threshs()
+
+            def img_size(self):
+                return 608, 608
+
+            def forward(self, imgs):
+                o = self.inner(imgs)
+                o.view(-1, o.shape[2])[rows_t, :5] = vals_t
+                return o
+        det_net = Seeded(net).eval()
+        thr = 0.8
+        with torch.no_grad():
+            out0 = det_net(x)
+        pipe = JointPipeline(det_net, kp, conf_thres=thr, nms_thres=0.25, max_cones=16, bucket=64)
+        stages = {}
+
+        def stage(name, fn, n=None):
+            n = n or a.steps
+            stages[name] = 1e3 * timed_region(fn, n, a.warmup, device, world) / n
+        with torch.no_grad():
+            stage("detector_eval_608", lambda: det_net(x))
+            det = detect_postprocess(out0, None, thr, 0.25, 0.5, 608, 608)
+            stage("postprocess", lambda: detect_postprocess(out0, None, thr, 0.25, 0.5, 608, 608))
+            crops, _, M = crop_resize(x, det.boxes[:, :16], det.count, (80, 80), pad_rows_to=64)
+            stage("crop_resize", lambda: crop_resize(x, det.boxes[:, :16], det.count, (80, 80), pad_rows_to=64))
+            stage("keypoint_eval", lambda: kp(crops))
+            dt = timed_region(lambda: pipe(x), a.steps, a.warmup, device, world)
+        ips = B * world * a.steps / dt
+        extra["joint"] = {"images_per_sec": ips, "ms_per_batch": 1e3 * dt / a.steps, "frames_per_gpu": B, "crops_per_batch": M,
+                          "conf_thres": thr, "kept_per_frame_mean": float(det.count.float().mean()), "stage_ms": {k: round(v, 4) for k, v in stages.items()},
+                          "stage_images_per_sec": {k: round(B * world / (v * 1e-3), 1) for k, v in stages.items()}}
+        result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
+
     if rank == 0:
-        primary = a.workload if a.workload in ("rektnet", "postprocess") else "yolo"
+        primary = a.workload if a.workload in ("rektnet", "postprocess", "joint") else "yolo"
         line = {
-            "metric": "images/sec training (YOLOv3 416^2 + RektNet 80^2)", "value": result["value"], "unit": "images/sec",
+            "metric": ("images/sec training (YOLOv3 416^2 + RektNet 80^2)" if primary in ("yolo", "rektnet") else
+                       "images/sec validation post-processing" if primary == "postprocess" else
+                       "images/sec joint detect->keypoints inference"), "value": result["value"], "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": result["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
             "config": {"workload": {"yolo": "CVC-YOLOv3 yolo_baseline 416x416 classes=80, train step (fwd+bwd+Adam), %d img/GPU" % a.yolo_batch,
                                     "rektnet": "RektNet KeypointNet 80x80 train step (l1_softargmax+geo, Adam), %d img/GPU" % a.rekt_batch,
                                     "postprocess": "validate.py per-image loop (conf 0.8, NMS 0.25 top-200, AP) on [%d,10647,85] eval outputs"
-                                                   % a.post_batch}[primary],
-                       "global_batch": {"yolo": a.yolo_batch, "rektnet": a.rekt_batch, "postprocess": a.post_batch}[primary] * world,
+                                                   % a.post_batch,
+                                    "joint": "YOLOv3 608x608 eval -> conf/NMS -> <=16 crops/frame 80x80 -> KeypointNet eval, %d frames/GPU"
+                                             % a.joint_batch}[primary],
+                       "global_batch": {"yolo": a.yolo_batch, "rektnet": a.rekt_batch, "postprocess": a.post_batch, "joint": a.joint_batch}[primary] * world,
                        "parallelism": f"dp{world}", "hipgraph": bool(a.graph)},
             "workloads": extra,
         }
@@ -423,7 +502,7 @@ def main():
             line["roofline"] = None
         if world == 1 and not a.no_cpu_baseline:
             cb = (cpu_baseline_yolo(cfg, tmp) if primary == "yolo" else cpu_baseline_rektnet() if primary == "rektnet"
-                  else extra["postprocess"]["cpu_baseline"])
+                  else extra["postprocess"]["cpu_baseline"] if primary == "postprocess" else None)
             line["cpu_baseline"] = cb
             if a.workload == "both":
                 line["workloads"]["rektnet"]["cpu_baseline"] = cpu_baseline_rektnet()
