@@ -34,7 +34,11 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
                 const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
                 int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
                 int KH, int KW, int stride, int pad, int dil, void* stream);
-int mdcv_conv2d_stats_rows(int M);
+int mdcv_conv2d_stats_rows(int M);      /* generic kernels: one row per 128 output pixels */
+/* rows of stats_partial a FORWARD launch with this geometry writes (use this one to size the buffer: the 3x3 / stride-1 /
+ * pad-1 shift kernel walks a padded pixel stream and writes more rows than M / 128; every row it returns is written). */
+int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil,
+                                int in_ldc);
 int mdcv_conv2d_set_variant(int v);   /* tuning hook: force a tile configuration for Nout > 64 (-1 = heuristic) */
 
 /* weight gradient: dW (OIHW fp32, real channel counts) = dY^T * im2col(X).  ws = splits*Cout*KH*KW*Cin floats of scratch. */

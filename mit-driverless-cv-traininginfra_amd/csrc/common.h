@@ -19,12 +19,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
   } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {            // round-to-nearest-even, NaN preserved
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// float -> bf16, round-to-nearest-even, NaN preserved: gfx950 has a packed hardware convert (v_cvt_pk_bf16_f32)
+typedef __bf16 mdcv_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float mdcv_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  const mdcv_f32x2_t v = {lo, hi};
+  const mdcv_bf16x2_t b = __builtin_convertvector(v, mdcv_bf16x2_t);
+  return *reinterpret_cast<const unsigned*>(&b);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, f) & 0xffffu); }
 
 // element traits: VEC = elements per 16-byte vector
 template <typename T> struct ET;
@@ -50,8 +53,7 @@ template <> struct ET<bf16_t> {
     f[6] = __uint_as_float(q.w << 16); f[7] = __uint_as_float(q.w & 0xffff0000u);
   }
   __device__ static __forceinline__ uint4 pack(const float* f) {
-    return make_uint4((unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16), (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16),
-                      (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16), (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16));
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
   }
 };
 

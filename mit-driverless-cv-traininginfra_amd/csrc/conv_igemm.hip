@@ -16,6 +16,7 @@
 // LDS rows padded to 80 bytes; epilogue staged through LDS for 16-byte coalesced stores; BatchNorm batch statistics
 // (sum, sum of squares per output channel) are produced from the fp32 accumulators in the epilogue.
 #include "common.h"
+#include "conv_shift.h"
 
 namespace {
 
@@ -300,6 +301,23 @@ __device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
 
 template <typename T> struct FragSwz;
 template <> struct FragSwz<bf16_t> {
+  // split form: fragment reads first, MFMAs later, so independent work (DMA address arithmetic) can sit under the LDS latency
+  template <int FM, int FN>
+  __device__ static __forceinline__ void load(const unsigned char* sa, const unsigned char* sb, int lane, bf16x8_t (&a)[FM], bf16x8_t (&b)[FN]) {
+    const int r = lane & 15;
+    const int off = r * 64 + (((lane >> 4) ^ swz(r)) << 4);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 1024 + off);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 1024 + off);
+  }
+  template <int FM, int FN>
+  __device__ static __forceinline__ void compute(const bf16x8_t (&a)[FM], const bf16x8_t (&b)[FN], f32x4_t (&acc)[FM][FN]) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
   template <int FM, int FN>
   __device__ static __forceinline__ void mma(const unsigned char* sa, const unsigned char* sb, int lane, f32x4_t (&acc)[FM][FN]) {
     bf16x8_t a[FM], b[FN];
@@ -513,18 +531,34 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
     int issued = 0;
     for (; issued < STAGES - 1 && issued < nk; ++issued) { if (issued) advance(); issue_tile(issued, issued); }
     int slot = 0, islot = issued % STAGES;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int newer = issued - 1 - kt;               // tiles issued after tile kt
-      if (newer >= STAGES - 2 && STAGES > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD * (STAGES - 2)) : "memory");
-      else if (newer == 1 && STAGES > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD) : "memory");
+    int kt = 0;
+    // steady state: every iteration issues exactly one tile, so the wait count is a constant and the body is ONE basic
+    // block (no branches): the DMA address arithmetic can be scheduled into the issue gaps between the MFMAs.
+    for (const int nmain = nk - (STAGES - 1); kt < nmain; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD * (STAGES - 2)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* sA = smem + slot * (BM + BN) * 64 + wm * TM * 64;
+      const unsigned char* sB = smem + slot * (BM + BN) * 64 + BM * 64 + wn * TN * 64;
+      if constexpr (sizeof(T) == 2) {
+        bf16x8_t fa[FM], fb[FN];
+        FragSwz<T>::template load<FM, FN>(sA, sB, lane, fa, fb);
+        advance();
+        issue_tile(kt + STAGES - 1, islot);
+        FragSwz<T>::template compute<FM, FN>(fa, fb, acc);
+      } else {
+        advance();
+        issue_tile(kt + STAGES - 1, islot);
+        FragSwz<T>::template mma<FM, FN>(sA, sB, lane, acc);
+      }
+      islot = islot + 1 == STAGES ? 0 : islot + 1;
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+    for (; kt < nk; ++kt) {                              // drain: no more tiles to issue
+      const int newer = nk - 1 - kt;                     // tiles issued after tile kt (<= STAGES - 2)
+      if (newer >= 2 && STAGES > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD * 2) : "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (issued < nk) {
-        advance();
-        issue_tile(issued, islot);
-        ++issued;
-        islot = islot + 1 == STAGES ? 0 : islot + 1;
-      }
       const unsigned char* sA = smem + slot * (BM + BN) * 64 + wm * TM * 64;
       const unsigned char* sB = smem + slot * (BM + BN) * 64 + BM * 64 + wn * TN * 64;
       FragSwz<T>::template mma<FM, FN>(sA, sB, lane, acc);
@@ -1395,6 +1429,17 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
     }
     return MDCV_OK;
   }
+  // 3x3 / stride 1 / pad 1 on wide layers: nine shifted GEMMs over one LDS-resident activation chunk (conv_shift.hip)
+  const bool shift_ok = Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc);
+  if (shift_ok && g_conv_variant < 0)
+    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, st);
+  if (shift_ok && stats_partial) {   // forced generic kernel on a shift-eligible geometry (A/B runs): the caller sized the partial
+    const int r0 = cdiv(a.M, 128), r1 = mdcv_shift_stats_rows(B, Hout, Wout);   // rows for the shift kernel; zero the unused tail
+    if (r1 > r0) {
+      hipError_t e = hipMemsetAsync(stats_partial + (size_t)r0 * 2 * Nout, 0, (size_t)(r1 - r0) * 2 * Nout * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
   if (dtype == MDCV_BF16) return mode == 0 ? dispatch_conv<bf16_t, 0>(a, st, B) : dispatch_conv<bf16_t, 1>(a, st, B);
   if (dtype == MDCV_F32) return mode == 0 ? dispatch_conv<float, 0>(a, st, B) : dispatch_conv<float, 1>(a, st, B);
   return MDCV_EARG;
@@ -1402,10 +1447,17 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
 
 // number of rows of the [rows][2][Nout] BatchNorm partial-statistics buffer mdcv_conv2d writes (one per 128 output pixels)
 int mdcv_conv2d_stats_rows(int M) { return cdiv(M, 128); }
+// rows for a given forward geometry: the 3x3 stride-1 shift kernel walks a padded position stream and writes more rows
+int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil,
+                                int in_ldc) {
+  if (mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc)) return mdcv_shift_stats_rows(B, Hout, Wout);
+  return cdiv(B * Hout * Wout, 128);
+}
 
 // tuning hook: force the tile configuration of wide (Nout > 64) layers; -1 restores the heuristic
 int mdcv_conv2d_wgrad_set_variant(int v) { g_wgrad_variant = v; return MDCV_OK; }   /* tuning hook */
 int mdcv_conv2d_set_variant(int v) {
+  if (v <= -3 && v >= -10) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
   g_conv_variant = v == 99 ? -1 : v;
   return MDCV_OK;

@@ -1,0 +1,408 @@
+// 3x3 / stride 1 / pad 1 convolution (forward and data gradient) as NINE SHIFTED GEMMs over one LDS-resident activation chunk.
+//
+// Why: the im2col kernel (conv_igemm.hip) fills LDS with a fresh A tile for every tap, i.e. every activation pixel travels
+// L2 -> LDS nine times.  Measured on MI355X that fill path saturates at ~30 GB/s per CU (~12.6 B/clk/CU), which is exactly what
+// holds the 3x3 layers at ~650 TFLOP/s (24 KiB of fill per 256x128x32 MACs).  Here the pixels of a tile are filled ONCE per
+// 32-channel chunk and all nine taps read them at shifted LDS rows, so the fill per K step drops from 24 KiB to 2.6 + 8 KiB.
+//
+// Stream layout.  Output positions run over a 1-D stream with one shared zero column and one shared zero row:
+//   p = img * (H+1)(W+1) + y * (W+1) + x          (x == W or y == H are junk positions, computed and discarded)
+// and the input of tap (kh, kw) at p is the same stream read at p + kh*(W+1) + kw, shifted by one row and one column:
+//   t' = p + kh*(W+1) + kw - (W+2)  ->  pixel (y+kh-1, x+kw-1); t' landing on a junk position IS the zero padding.
+// (The row/column after each image row / image serves as the left/top padding of the next one.)  So the A operand of tap
+// (kh,kw) for stream positions [p0, p0+256) is rows [d, d+256) of ONE LDS chunk holding stream rows [p0, p0+256+2(W+1)+2),
+// d = kh*(W+1)+kw (forward) or (2-kh)*(W+1)+(2-kw) (data gradient).  Junk positions cost (H+1)(W+1)/(HW) - 1 extra MACs
+// (4 % at 52x52, 8 % at 26x26, 16 % at 13x13).
+//
+// Pipeline.  256(M) x 128(N) tile, 8 waves of 64x64, K step = 32 channels of one tap.  The activation chunk (NPA KiB-chunks
+// per wave) is double buffered per 32-channel chunk; the weight tiles (8 KiB per step) go through a 3-slot ring; since
+// 9 % 3 == 0 every slot index and every vmcnt immediate is a compile-time constant of the (unrolled) tap index.
+// All DMA addresses are loop invariant per lane (voffset) + a scalar (soffset): the K loop has no address VALU at all.
+#include "common.h"
+#include "conv_shift.h"
+
+namespace {
+
+constexpr int BN = 128, WM = 4, WN = 2, NW = 8, TN = 64, FN = 4;     // 8 waves: 4 (M) x 2 (N); wave tile (BM/4) x 64
+constexpr int BTILE = BN * 64;                            // one weight tile of the ring: 8 KiB
+constexpr unsigned OOB = 0x80000000u;
+constexpr int SROW = BN * 2 + 16;                          // epilogue staging pitch (bf16)
+
+__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+#if defined(MDCV_SHIFT_TS) || defined(MDCV_SHIFT_WG)
+#include <cstdio>
+__device__ long long g_shift_wg[3 * 4096];   // per workgroup: wall-clock start, end (100 MHz), hardware id
+#endif
+#ifdef MDCV_SHIFT_TS   /* per-step cycle stamps of one wave (scripts/shift_ts.py); never defined in the shipped build */
+__device__ long long g_shift_ts[4 * 512];
+#define STS(k) do { if (ts_on && ts_i < 512) g_shift_ts[(k) * 512 + ts_i] = (long long)clock64(); } while (0)
+#else
+#define STS(k)
+#endif
+
+int g_shift_ring = 3;
+int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row tiles only ; 3: mixed rounds (tuning hook)   // weight-ring depth (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+}  // namespace
+
+template <int MODE, int BM, int NPA, int BRING>
+__global__ __launch_bounds__(NW * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a, unsigned in_bytes, unsigned w_bytes) {
+  constexpr int TM = BM / WM, FM = TM / 16;
+  // LDS: [A0: nca KiB][A1: nca KiB][weight ring: BRING x 8 KiB][1 KiB sink for the surplus chunk DMAs]; the epilogue reuses it
+  // as [bf16 staging BM x SROW][rowpix BM ints][statistics WM*2*BN floats].
+  constexpr int STAGE = BM * SROW;
+  constexpr int PIX_OFF = STAGE;                           // int rowpix[BM]
+  constexpr int STAT_OFF = STAGE + BM * 4;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int ABYTES = a.nca * 1024;
+  const int BBASE = 2 * ABYTES;
+  const int SINK = BBASE + BRING * BTILE;
+
+  const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
+  if (logical >= a.tiles_total) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile_m = logical / a.tiles_n, tile_n = logical % a.tiles_n;
+  const int p0 = a.p_base + tile_m * BM;
+  const int lrow = lane >> 2, kv = (lane & 3) ^ swz(lrow);
+  // (fills past the last K step use a descriptor with num_records = 0: everything is out of range, the DMA writes zeros
+  //  into a slot nobody reads, and the DMA count per step stays constant)
+
+  // ---- loop-invariant DMA offsets
+  unsigned avo[NPA];
+#pragma unroll
+  for (int k = 0; k < NPA; ++k) {
+    const int j = (wave + k * NW) * 16 + lrow;             // LDS row of the activation chunk
+    const int t = p0 + j - (a.Wq + 1);
+    bool ok = t >= 0 && t < a.Mq;
+    const int tt = ok ? t : 0;
+    const int img = tt / a.Sq, rem = tt - img * a.Sq;
+    const int yy = rem / a.Wq, xx = rem - yy * a.Wq;
+    ok = ok && yy < a.H && xx < a.W;
+    avo[k] = ok ? (unsigned)((((img * a.H + yy) * a.W + xx) * a.in_ldc + kv * 8) * 2) : OOB;
+  }
+  unsigned bvo;
+  {
+    const int n = tile_n * BN + wave * 16 + lrow;
+    bvo = n < a.Nout ? (unsigned)((n * a.wrow + kv * 8) * 2) : OOB;
+  }
+  // ---- per-tap fragment offsets (activation rows shifted by the tap displacement)
+  const int r = lane & 15, q = lane >> 4;
+  int offA[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int d = MODE == 0 ? kh * a.Wq + kw : (2 - kh) * a.Wq + (2 - kw);
+    const int row = wm * TM + d + r;
+    offA[tap] = row * 64 + ((q ^ swz(row)) << 4);
+  }
+  const int offB = (wn * TN + r) * 64 + ((q ^ swz(r)) << 4);
+
+  // descriptors live in the kernel body (device builtins inside a lambda make the host pass drop the kernel stub)
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rin0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 0, 0x00020000);
+#define ISSUE_A(RS, CHUNK, BUF)                                                                                       \
+  do {                                                                                                              \
+    const int base__ = (BUF) * ABYTES;                                                                              \
+    const int so__ = (CHUNK) * 64;                                                                                  \
+    _Pragma("unroll") for (int k = 0; k < NPA; ++k) {                                                               \
+      const int ch__ = wave + k * NW;             /* every wave issues NPA DMAs; chunks past the last go to the sink */ \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + (ch__ < a.nca ? base__ + ch__ * 1024 : SINK)), 16, \
+                                               (int)avo[k], so__, 0, 0);                                            \
+    }                                                                                                               \
+  } while (0)
+#define ISSUE_B(RS, TAP, CHUNK, SLOT)                                                                               \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + BBASE + (SLOT) * BTILE + wave * 1024), 16, (int)bvo, \
+                                           ((TAP) * a.Cin + (CHUNK) * 32) * 2, 0, 0)
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // Step s = chunk * 9 + tap.  At step s the weight tile s+LA is issued (LA = BRING-1 tiles of lookahead) and, at tap 0,
+  // the next activation chunk behind it.  DMAs complete in order, so "tile s has landed" = at most LA-1 newer weight tiles
+  // outstanding, plus the chunk (NPA DMAs) while it is younger than tile s, i.e. at taps 1 .. LA.
+  constexpr int LA = BRING - 1;
+  const int nch = a.nchunks;
+#ifdef MDCV_SHIFT_TS
+  const bool ts_on = logical == 300 && tid == 64 * 3;
+  int ts_i = 0;
+#endif
+#if defined(MDCV_SHIFT_TS) || defined(MDCV_SHIFT_WG)
+  if (tid == 0 && logical < 4096) {
+    g_shift_wg[logical] = (long long)wall_clock64();
+    unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_shift_wg[2 * 4096 + logical] = (long long)hwid | ((long long)xcc << 32);
+  }
+#endif
+  ISSUE_A(rin, 0, 0);
+#pragma unroll
+  for (int t = 0; t < LA; ++t) ISSUE_B(rw, t % 9, t / 9, t);
+  // The chunk loop is unrolled over PERIOD chunks so that every ring slot, A buffer and wait count below is a compile-time
+  // constant of (cc, tap): 9 * PERIOD is a multiple of BRING, and PERIOD is even or the A buffer index is taken from c.
+  constexpr int PERIOD = BRING == 3 ? 2 : 4;
+  static_assert((9 * PERIOD) % BRING == 0, "ring period");
+  for (int c0 = 0; c0 < nch; c0 += PERIOD) {
+#pragma unroll
+    for (int cc = 0; cc < PERIOD; ++cc) {
+      const int c = c0 + cc;
+      if (c < nch) {
+        const bool lastc = c == nch - 1;
+        const int abase = (cc & 1) * ABYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int rslot = (cc * 9 + tap) % BRING, wslot = (cc * 9 + tap + LA) % BRING;
+          STS(0);
+          if (tap >= 1 && tap <= LA) wait_vm<LA - 1 + NPA>(); else wait_vm<LA - 1>();
+          STS(1);
+          __builtin_amdgcn_s_barrier();
+          STS(2);
+          bf16x8_t fa[FM], fb[FN];
+          const unsigned char* pa = smem + abase + offA[tap];
+          const unsigned char* pb = smem + BBASE + rslot * BTILE + offB;
+#pragma unroll
+          for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(pa + i * 1024);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 1024);
+          {
+            const int t2 = (tap + LA) % 9, c2 = c + (tap + LA) / 9;
+            if (tap + LA >= 9 && lastc) ISSUE_B(rw0, t2, c2, wslot);   // past the last K step: zero fill, same DMA count
+            else ISSUE_B(rw, t2, c2, wslot);
+          }
+          if (tap == 0) {
+            if (lastc) ISSUE_A(rin0, c + 1, (cc + 1) & 1);
+            else ISSUE_A(rin, c + 1, (cc + 1) & 1);
+          }
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          STS(3);
+#ifdef MDCV_SHIFT_TS
+          ++ts_i;
+#endif
+        }
+      }
+    }
+  }
+  wait_vm<0>();
+  __syncthreads();                                         // the epilogue reuses the pipeline LDS
+
+  // ---------------- epilogue ----------------
+  int* rowpix = reinterpret_cast<int*>(smem + PIX_OFF);
+  if (tid < BM) {
+    const int p = p0 + tid;
+    bool ok = p < a.Mq;
+    const int pp = ok ? p : 0;
+    const int img = pp / a.Sq, rem = pp - img * a.Sq;
+    const int y = rem / a.Wq, x = rem - y * a.Wq;
+    ok = ok && y < a.H && x < a.W;
+    rowpix[tid] = ok ? (img * a.H + y) * a.W + x : -1;
+  }
+  const int n0 = tile_n * BN + wn * TN;
+  if (a.bias) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + j * 16 + (lane & 15);
+      const float bv = n < a.Nout ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[i][j][rr] += bv;
+    }
+  }
+  __syncthreads();
+  float* sstat = reinterpret_cast<float*>(smem + STAT_OFF);
+  if (a.stats) {
+    bool live[FM][4];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) live[i][rr] = rowpix[wm * TM + i * 16 + (lane >> 4) * 4 + rr] >= 0;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float s = 0.f, qq = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float v = live[i][rr] ? acc[i][j][rr] : 0.f;
+          s += v; qq += v * v;
+        }
+      s += __shfl_xor(s, 16, 64); qq += __shfl_xor(qq, 16, 64);
+      s += __shfl_xor(s, 32, 64); qq += __shfl_xor(qq, 32, 64);
+      if (lane < 16) {
+        sstat[(wm * 2 + 0) * BN + wn * TN + j * 16 + lane] = s;
+        sstat[(wm * 2 + 1) * BN + wn * TN + j * 16 + lane] = qq;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; rr += 2) {
+        const int row = wm * TM + i * 16 + (lane >> 4) * 4 + rr, col = wn * TN + j * 16 + (lane & 15);
+        const unsigned pk = pack_bf16x2(acc[i][j][rr], acc[i][j][rr + 1]);     // one v_cvt_pk_bf16_f32 per two rows
+        reinterpret_cast<bf16_t*>(smem + row * SROW)[col] = (bf16_t)(pk & 0xffffu);
+        reinterpret_cast<bf16_t*>(smem + (row + 1) * SROW)[col] = (bf16_t)(pk >> 16);
+      }
+  __syncthreads();
+  constexpr int G = BM / 128, WPG = WM / G;                // groups of 128 stream positions per tile; waves (in M) per group
+  if (a.stats && tid < BN * G) {                           // one partial-statistics row per 128 stream positions
+    const int g = tid / BN, col = tid - g * BN;
+    const int n = tile_n * BN + col;
+    if (n < a.Nout) {
+      float s = 0.f, qq = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < WPG; ++w2) { s += sstat[((g * WPG + w2) * 2 + 0) * BN + col]; qq += sstat[((g * WPG + w2) * 2 + 1) * BN + col]; }
+      const size_t srow = (size_t)(p0 >> 7) + g;
+      a.stats[(srow * 2 + 0) * a.Nout + n] = s;
+      a.stats[(srow * 2 + 1) * a.Nout + n] = qq;
+    }
+  }
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
+  const bf16_t* __restrict__ addsrc = reinterpret_cast<const bf16_t*>(a.addsrc);
+  constexpr int VPRO = BN / 8;
+  for (int v = tid; v < BM * VPRO; v += NW * 64) {
+    const int row = v / VPRO, cv = v - row * VPRO;
+    const int pix = rowpix[row], n = tile_n * BN + cv * 8;
+    if (pix >= 0 && n < a.Nout) {
+      uint4 d = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
+      if (addsrc) {
+        float x[8], y[8];
+        ET<bf16_t>::unpack(d, x);
+        ET<bf16_t>::unpack(*reinterpret_cast<const uint4*>(addsrc + ((size_t)pix * a.add_ldc + n)), y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += y[e];
+        d = ET<bf16_t>::pack(x);
+      }
+      *reinterpret_cast<uint4*>(out + ((size_t)pix * a.out_ldc + n)) = d;
+    }
+  }
+#if defined(MDCV_SHIFT_TS) || defined(MDCV_SHIFT_WG)
+  if (tid == 0 && logical < 4096) g_shift_wg[4096 + logical] = (long long)wall_clock64();
+#endif
+}
+
+namespace {
+
+template <int MODE, int BM, int NPA>
+int launch_shift(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
+  constexpr int BRING = 3;
+  a.p_base = p_base;
+  a.tiles_total = tiles_m * a.tiles_n;
+  a.xcd_chunk = (a.tiles_total + 7) / 8;
+  a.nca = (BM + 2 * a.Wq + 2 + 15) / 16;                   // KiB-chunks (16 stream rows each) of one activation chunk
+  const int pipe = 2 * a.nca * 1024 + BRING * BTILE + 1024;
+  const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;
+  const int lds = pipe > epi ? pipe : epi;
+  static int attr_lds = 0;
+  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING>;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, in_bytes, w_bytes);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+template <int MODE, int BM>
+int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
+  const int nca = (BM + 2 * a.Wq + 2 + 15) / 16;
+  const int npa = (nca + NW - 1) / NW;
+  if (npa <= 2) return launch_shift<MODE, BM, 2>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  if (npa == 3) return launch_shift<MODE, BM, 3>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  return launch_shift<MODE, BM, 4>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+}
+
+// Tile plan (measured, scripts/conv_ab.py + scripts/shift_wg.py): 256-row tiles run two workgroups per CU; a tile that has a
+// CU to itself takes ~0.8x the time of one that shares it, so a short extra round costs less than splitting the remainder
+// into 128-row tiles (their weight fill per MAC doubles).  Only grids that would leave CUs idle (<= 256 tiles) switch to
+// 128-row tiles.  Plan 3 (tuning) runs full rounds as 256-row tiles and a remainder of at most half a round as 128-row tiles.
+template <int MODE>
+int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
+  const int SLOTS = 512;
+  const int big_m = (a.Mq + 255) / 256;
+  const int t_big = big_m * a.tiles_n;
+  int nbig_m;
+  if (g_shift_plan == 1) nbig_m = big_m;                                   // tuning: 256-row tiles only
+  else if (g_shift_plan == 2) nbig_m = 0;                                  //         128-row tiles only
+  else if (t_big <= SLOTS / 2) nbig_m = 0;
+  else if (g_shift_plan == 3) {
+    const int full = t_big / SLOTS * SLOTS, rem = t_big - full;
+    nbig_m = (rem > 0 && rem <= SLOTS / 2) ? full / a.tiles_n : big_m;
+  } else nbig_m = big_m;
+  if (nbig_m > 0) {
+    const int rc = launch_shift_bm<MODE, 256>(a, 0, nbig_m, st, in_bytes, w_bytes);
+    if (rc) return rc;
+  }
+  const int p_base = nbig_m * 256;
+  if (p_base < a.Mq) return launch_shift_bm<MODE, 128>(a, p_base, (a.Mq - p_base + 127) / 128, st, in_bytes, w_bytes);
+  return MDCV_OK;
+}
+
+}  // namespace
+
+// ---- host side (internal linkage across the library's objects: declared in conv_shift.h)
+bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc) {
+  if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || dil != 1) return false;
+  if ((Cin & 31) || Cin < 32 || (Nout & 127)) return false;
+  if (H < 8 || W < 8 || W > 62) return false;                  // chunk rows 256 + 2(W+1) + 2 <= 384: 2 workgroups per CU
+  if ((long long)B * (H + 1) * (W + 1) + 1024 >= (1LL << 30)) return false;
+  if ((long long)B * H * W * in_ldc * 2 >= (1LL << 31) || (long long)Nout * 9 * Cin * 2 >= (1LL << 31)) return false;
+  return true;
+}
+
+int mdcv_shift_stats_rows(int B, int H, int W) { return (int)(((long long)B * (H + 1) * (W + 1) + 127) / 128); }
+
+int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
+                    int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, hipStream_t st) {
+  ShiftArgs a;
+  a.in = in; a.w = w; a.out = out; a.bias = bias; a.addsrc = addsrc; a.stats = stats;
+  a.in_ldc = in_ldc; a.out_ldc = out_ldc; a.add_ldc = add_ldc;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Nout = Nout;
+  a.Wq = W + 1; a.Sq = (H + 1) * (W + 1); a.Mq = B * a.Sq;
+  a.tiles_n = Nout / BN;
+  a.tiles_total = 0; a.xcd_chunk = 0; a.nca = 0; a.p_base = 0;
+  a.nchunks = Cin / 32;
+  a.wrow = 9 * Cin;
+  const unsigned in_bytes = (unsigned)((long long)B * H * W * in_ldc * 2);
+  const unsigned w_bytes = (unsigned)((long long)Nout * 9 * Cin * 2);
+  return mode == 0 ? launch_shift_mode<0>(a, st, in_bytes, w_bytes) : launch_shift_mode<1>(a, st, in_bytes, w_bytes);
+}
+
+void mdcv_shift_set_ring(int ring) { if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+#ifdef MDCV_SHIFT_TS
+extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
+  return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);
+}
+#endif
+#if defined(MDCV_SHIFT_TS) || defined(MDCV_SHIFT_WG)
+extern "C" int mdcv_debug_shift_occ(int lds) {
+  int nb = -1;
+  auto kern = mdcv_conv3x3_shift_kernel<0, 256, 3, 3>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NW * 64, (size_t)lds);
+  hipFuncAttributes fa; hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+  printf("occupancy(lds=%d) = %d blocks/CU (err %d); numRegs %d sharedSizeBytes %zu maxThreadsPerBlock %d\n", lds, nb, (int)e, fa.numRegs,
+         (size_t)fa.sharedSizeBytes, fa.maxThreadsPerBlock);
+  return nb;
+}
+extern "C" int mdcv_debug_shift_wg(long long* host3x4096) {
+  return (int)hipMemcpyFromSymbol(host3x4096, HIP_SYMBOL(g_shift_wg), sizeof(long long) * 3 * 4096);
+}
+#endif

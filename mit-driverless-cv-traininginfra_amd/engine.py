@@ -236,6 +236,11 @@ class Plan:
             copy_bias.__name__ = "copy_bias"
             self.fwd.append((copy_bias, ()))
 
+    def stats_rows(self, cs, x, y):
+        """rows of the BatchNorm partial-statistics buffer the forward conv of this geometry writes"""
+        return int(self.L.conv2d_stats_rows_geom(self.dtype, x.B, y.H, y.W, cs.cin_pad, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad,
+                                                 cs.dil, x.ldc))
+
     def emit_conv_fwd(self, cs, x, y, stats_partial=None):
         """x, y: Act.  y.C == cs.cout_pad."""
         assert x.C == cs.cin_pad and y.C == cs.cout_pad, (x.C, cs.cin_pad, y.C, cs.cout_pad)

@@ -134,7 +134,7 @@ class KeypointNet(nn.Module, FlatParamsMixin):
             bs = BnSpec(plan, bn)
             y = plan.new_act(B, H, W, conv.out_channels)
             if bn_train:
-                rows = L.conv2d_stats_rows(y.M)
+                rows = plan.stats_rows(cs, xnode.act, y)
                 partial = plan.f32(rows * 2 * y.C, zero=False)
                 plan.emit_conv_fwd(cs, xnode.act, y, partial)
                 plan.emit_bn_stats(bs, y, partial, rows)

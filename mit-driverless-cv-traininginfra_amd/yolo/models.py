@@ -491,7 +491,7 @@ class Darknet(nn.Module, FlatParamsMixin):
                     fuse = (i + 1 < n and defs[i + 1]["type"] == "shortcut" and users[i] == [i + 1]
                             and res(i + 1, int(defs[i + 1]["from"])) != i)
                     if bn_train:
-                        rows = L.conv2d_stats_rows(y.M)
+                        rows = plan.stats_rows(cs, cur.act, y)
                         partial = plan.f32(rows * 2 * y.C, zero=False)
                         plan.emit_conv_fwd(cs, cur.act, y, partial)
                         plan.emit_bn_stats(bs, y, partial, rows)

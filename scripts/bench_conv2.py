@@ -13,7 +13,7 @@ def run(shape, variant, iters, nsets, stats=False):
     xs = [torch.randn(B * H * H * Ci, device="cuda").to(torch.bfloat16) for _ in range(nsets)]
     ys = [torch.randn(B * Ho * Ho * Co, device="cuda").to(torch.bfloat16) for _ in range(nsets)]
     wf = (torch.randn(Co * k * k * Ci, device="cuda") * 0.05).to(torch.bfloat16)
-    stt = torch.zeros(L.conv2d_stats_rows(B * Ho * Ho) * 2 * Co, device="cuda") if stats else None
+    stt = torch.zeros(L.conv2d_stats_rows_geom(1, B, Ho, Ho, Ci, Co, k, k, s, pad, 1, Ci) * 2 * Co, device="cuda") if stats else None
     L.conv2d_set_variant(variant)
     def call(i):
         x, y = xs[i % nsets], ys[i % nsets]

@@ -77,7 +77,11 @@ CONV_CASES = [
     (2, 16, 20, 20, 32, 3, 1, 2, 2, True),      # dilated 3x3
     (1, 128, 9, 9, 7, 1, 1, 0, 1, True),        # RektNet head Cout=7
     (2, 48, 11, 11, 136, 3, 1, 1, 1, False),    # Cout > 128 (two N tiles), Cin not a multiple of 32
-    (1, 256, 13, 13, 512, 3, 1, 1, 1, False),   # big K
+    (1, 256, 13, 13, 512, 3, 1, 1, 1, False),   # big K (bf16: shift-GEMM kernel, 8 channel chunks)
+    (3, 64, 26, 20, 128, 3, 1, 1, 1, True),     # shift-GEMM: non-square, bias, tiles straddling images
+    (2, 32, 52, 52, 256, 3, 1, 1, 1, False),    # shift-GEMM: a single channel chunk, two N tiles
+    (5, 96, 8, 9, 128, 3, 1, 1, 1, False),      # shift-GEMM: tiny images (several per tile), 3 chunks
+    (1, 128, 104, 104, 128, 3, 1, 1, 1, False), # shift-GEMM: wide rows (4 KiB-chunks per wave for the halo)
 ]
 
 
@@ -97,7 +101,7 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     xb = to_nhwc(x, dt)
     wf, wd = pack(dt, w)
     y = torch.empty(B, Ho, Wo, cop, dtype=TD[dt], device="cuda")
-    rows = L.conv2d_stats_rows(B * Ho * Wo)
+    rows = L.conv2d_stats_rows_geom(dt, B, Ho, Wo, cip, cop, k, k, s, p, d, cip)
     stats = torch.zeros(rows, 2, cop, dtype=torch.float32, device="cuda")
     bp = None
     if has_bias:
@@ -166,7 +170,7 @@ def test_conv_tile_variants(variant, dt):
             xb = to_nhwc(x, dt)
             wf, wd = pack(dt, w)
             y = torch.empty(B, Ho, Wo, cop, dtype=TD[dt], device="cuda")
-            stats = torch.zeros(L.conv2d_stats_rows(B * Ho * Wo), 2, cop, dtype=torch.float32, device="cuda")
+            stats = torch.zeros(L.conv2d_stats_rows_geom(dt, B, Ho, Wo, cip, cop, k, k, s, p, d, cip), 2, cop, dtype=torch.float32, device="cuda")
             bp = None
             if has_bias:
                 bp = torch.zeros(cop, device="cuda")
