@@ -70,6 +70,17 @@ int mdcv_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const float* b1, const void* y2, int ld2, const float* s2,
                     const float* b2, const void* resid, int ldr, void* out, int ldo, int M, int C, int act, float slope, void* stream);
 int mdcv_bn_act_bwd_reduce_ws_floats(int dtype, int M, int C, int nsums);
+/* partial rows -> statistics -> scale/shift (+ running stats) in ONE launch while rows <= 4096 (a workgroup owns 16 channels and
+ * sums their rows itself; larger buffers fall back to mdcv_partial_reduce + mdcv_bn_finalize through `accum`). */
+int mdcv_bn_stats_finalize(const float* partial, int rows, double* accum, double count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                           float* invstd, int C, void* stream);
+/* mdcv_bn_act_bwd_reduce + mdcv_bn_bwd_finalize for one BatchNorm (y2 == NULL) or the fused residual pair, two launches in all. */
+int mdcv_bn_act_bwd_reduce_finalize(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,
+                                    const float* mean1, const float* invstd1, const void* y2, int ld2, const float* s2, const float* b2,
+                                    const float* mean2, const float* invstd2, float* partial_ws, int M, int C, int act, float slope,
+                                    double count, const float* gamma1, float* dgamma1, float* dbeta1, float* cA1, float* cB1, float* cC1,
+                                    const float* gamma2, float* dgamma2, float* dbeta2, float* cA2, float* cB2, float* cC2, void* stream);
 int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,
                            const float* mean1, const float* invstd1, const void* y2, int ld2, const float* s2, const float* b2,
                            const float* mean2, const float* invstd2, double* accum, float* partial_ws, int M, int C, int act, float slope,

@@ -315,6 +315,80 @@ __global__ void bn_bwd_finalize_kernel(double* __restrict__ accum, int kx, int z
   cC[c] = (float)(-g * is * mg + g * is * is * mu * mgx);
 }
 
+// ---------------------------------------------------------------- column-owner reduce + finalize
+// One launch instead of (partial-row reduce with fp64 atomics -> finalize): a workgroup OWNS 16 channels, sums their partial rows
+// itself (64 row lanes x 16 channels, 64-byte segments per row) and finalizes them.  No atomics, no second dependent launch,
+// deterministic.  Used while the partial buffer is small (rows <= COLFIN_MAX_ROWS); the 208^2 / 416^2 layers keep the two-stage path.
+constexpr int COLFIN_MAX_ROWS = 4096;
+struct ColFinArgs {
+  const float* partial; int rows, nsums, C; double count;
+  // MODE 0: forward statistics -> scale / shift / running stats
+  const float* gamma; const float* beta; float* rm; float* rv; float momentum, eps; float* scale; float* shift; float* mean; float* invstd;
+  // MODE 1: backward sums -> dgamma, dbeta, coefficient vectors; BN #1 uses sums (0, 1), BN #2 (fused residual pair) sums (0, 2)
+  const float* g1; const float* mean1; const float* is1; float* dg1; float* db1; float* cA1; float* cB1; float* cC1;
+  const float* g2; const float* mean2; const float* is2; float* dg2; float* db2; float* cA2; float* cB2; float* cC2;
+};
+
+__device__ __forceinline__ void bwd_coeffs(double sg, double sgx, double count, float gamma, float mean, float invstd, float* dg, float* db,
+                                           float* cA, float* cB, float* cC, int c) {
+  dg[c] = (float)sgx;
+  db[c] = (float)sg;
+  const double g = gamma, is = invstd, mu = mean;
+  const double mg = sg / count, mgx = sgx / count;
+  cA[c] = (float)(g * is);
+  cB[c] = (float)(-g * is * is * mgx);
+  cC[c] = (float)(-g * is * mg + g * is * is * mu * mgx);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void bn_colfinal_kernel(ColFinArgs a) {
+  __shared__ double red[3][64][16];
+  __shared__ double tot[3][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  if (c < a.C) {
+    const size_t stride = (size_t)a.nsums * a.C;
+    const float* p = a.partial + c;
+    if (a.nsums == 2) {
+#pragma unroll 4
+      for (int r = ry; r < a.rows; r += 64) { s0 += (double)p[r * stride]; s1 += (double)p[r * stride + a.C]; }
+    } else {
+#pragma unroll 4
+      for (int r = ry; r < a.rows; r += 64) { s0 += (double)p[r * stride]; s1 += (double)p[r * stride + a.C]; s2 += (double)p[r * stride + 2 * a.C]; }
+    }
+  }
+  red[0][ry][cx] = s0; red[1][ry][cx] = s1; red[2][ry][cx] = s2;
+  __syncthreads();
+  if (ry < 3) {
+    double t = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) t += red[ry][k][cx];
+    tot[ry][cx] = t;
+  }
+  __syncthreads();
+  if (ry != 0 || c >= a.C) return;
+  if (MODE == 0) {
+    const double mean = tot[0][cx] / a.count;
+    double var = tot[1][cx] / a.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float g = a.gamma[c], b = a.beta[c];
+    a.scale[c] = g * invstd;
+    a.shift[c] = b - (float)mean * g * invstd;
+    a.mean[c] = (float)mean;
+    a.invstd[c] = invstd;
+    if (a.rm) {
+      const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+      a.rm[c] = (1.f - a.momentum) * a.rm[c] + a.momentum * (float)mean;
+      a.rv[c] = (1.f - a.momentum) * a.rv[c] + a.momentum * (float)unbiased;
+    }
+  } else {
+    bwd_coeffs(tot[0][cx], tot[1][cx], a.count, a.g1[c], a.mean1[c], a.is1[c], a.dg1, a.db1, a.cA1, a.cB1, a.cC1, c);
+    if (a.nsums == 3) bwd_coeffs(tot[0][cx], tot[2][cx], a.count, a.g2[c], a.mean2[c], a.is2[c], a.dg2, a.db2, a.cA2, a.cB2, a.cC2, c);
+  }
+}
+
 // backward, pass 2: dy_i = cA_i*g + cB_i*y_i + cC_i
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnBwdArgs a) {
@@ -569,6 +643,24 @@ int mdcv_bn_finalize(double* accum, double count, const float* gamma, const floa
   return MDCV_OK;
 }
 
+// conv-epilogue partial rows -> batch statistics -> scale / shift (+ running stats): one launch while the partial buffer is small
+int mdcv_bn_stats_finalize(const float* partial, int rows, double* accum, double count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                           float* invstd, int C, void* stream) {
+  if (!partial || !accum || rows < 1 || !gamma || !beta || !scale || !shift || !mean || !invstd) return MDCV_EARG;
+  if (rows > COLFIN_MAX_ROWS) {
+    const int rc = mdcv_partial_reduce(partial, rows, 2, C, accum, stream);
+    if (rc) return rc;
+    return mdcv_bn_finalize(accum, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C, stream);
+  }
+  ColFinArgs a = {};
+  a.partial = partial; a.rows = rows; a.nsums = 2; a.C = C; a.count = count; a.gamma = gamma; a.beta = beta; a.rm = running_mean;
+  a.rv = running_var; a.momentum = momentum; a.eps = eps; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
+  hipLaunchKernelGGL(bn_colfinal_kernel<0>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, a);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
 int mdcv_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                         float* scale, float* shift, int C, void* stream) {
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean,
@@ -637,6 +729,40 @@ int mdcv_bn_bwd_finalize(double* accum, int kx, int nsums, int zero_after, doubl
   if (!accum || !gamma || !dgamma || !dbeta || !cA || !cB || !cC) return MDCV_EARG;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, accum, kx, zero_after, count,
                      gamma, mean, invstd, dgamma, dbeta, cA, cB, cC, C, nsums);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+// pass 1 of the BN(+act) backward including the finalize: partial rows -> (dgamma, dbeta, cA, cB, cC) of one or two BatchNorms
+// in the same launch sequence (main reduce kernel + one column-owner kernel; no atomics, nothing left in `accum`).
+int mdcv_bn_act_bwd_reduce_finalize(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,
+                                    const float* mean1, const float* invstd1, const void* y2, int ld2, const float* s2, const float* b2,
+                                    const float* mean2, const float* invstd2, float* partial_ws, int M, int C, int act, float slope,
+                                    double count, const float* gamma1, float* dgamma1, float* dbeta1, float* cA1, float* cB1, float* cC1,
+                                    const float* gamma2, float* dgamma2, float* dbeta2, float* cA2, float* cB2, float* cC2, void* stream) {
+  if (!dout || !y1 || !partial_ws || (C & 7) || !gamma1 || !dgamma1 || !dbeta1 || !cA1 || !cB1 || !cC1 || !mean1 || !invstd1) return MDCV_EARG;
+  if (y2 && (!gamma2 || !dgamma2 || !dbeta2 || !cA2 || !cB2 || !cC2 || !mean2 || !invstd2)) return MDCV_EARG;
+  BnBwdArgs a = {};
+  a.dout = dout; a.y1 = y1; a.y2 = y2; a.s1 = s1; a.b1 = b1; a.m1 = mean1; a.is1 = invstd1; a.s2 = s2; a.b2 = b2; a.m2 = mean2; a.is2 = invstd2;
+  a.accum = nullptr; a.partial = partial_ws; a.ldd = ldd; a.ld1 = ld1; a.ld2 = ld2; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
+  hipStream_t st = (hipStream_t)stream;
+  const int nsums = y2 ? 3 : 2;
+  int rows = 0;
+  if (dtype == MDCV_BF16) {
+    Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
+    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, a);
+  } else if (dtype == MDCV_F32) {
+    Strip s = make_strip<float>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
+    a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, a);
+  } else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  ColFinArgs f = {};
+  f.partial = partial_ws; f.rows = rows; f.nsums = nsums; f.C = C; f.count = count;
+  f.g1 = gamma1; f.mean1 = mean1; f.is1 = invstd1; f.dg1 = dgamma1; f.db1 = dbeta1; f.cA1 = cA1; f.cB1 = cB1; f.cC1 = cC1;
+  f.g2 = gamma2; f.mean2 = mean2; f.is2 = invstd2; f.dg2 = dgamma2; f.db2 = dbeta2; f.cA2 = cA2; f.cB2 = cB2; f.cC2 = cC2;
+  hipLaunchKernelGGL(bn_colfinal_kernel<1>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, f);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -296,9 +296,8 @@ class Plan:
         """conv-epilogue partial sums -> batch statistics -> scale/shift (+ running stats)."""
         L = self.L
         bn = bs.bn
-        self.call(self.fwd, L.partial_reduce, partial.data_ptr(), rows, 2, bs.C, bs.accum.data_ptr())
-        self.call(self.fwd, L.bn_finalize, bs.accum.data_ptr(), float(y.M), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+        self.call(self.fwd, L.bn_stats_finalize, partial.data_ptr(), rows, bs.accum.data_ptr(), float(y.M), bn.weight.data_ptr(),
+                  bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
                   bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), bs.invstd.data_ptr(), bs.C)
 
     def emit_bn_eval(self, bs):
@@ -320,18 +319,17 @@ class Plan:
         dy2 = self._alloc_like(y2) if y2 is not None else None
         n = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         pws = self.f32(L.bn_act_bwd_reduce_ws_floats(dt, y1.M, y1.C, 3 if y2 is not None else 2), zero=False)
-        self.call(self.bwd, L.bn_act_bwd_reduce, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.mean),
-                  n(bs1.invstd), y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
-                  n(bs2.scale) if bs2 else None, n(bs2.shift) if bs2 else None, n(bs2.mean) if bs2 else None,
-                  n(bs2.invstd) if bs2 else None, bs1.accum.data_ptr(), pws.data_ptr(), y1.M, y1.C, act, float(slope))
-        nsums = 3 if y2 is not None else 2
         g1, b1 = self.param_grad(bs1.bn.weight), self.param_grad(bs1.bn.bias)
+        g2 = b2 = None
         if y2 is not None:
             g2, b2 = self.param_grad(bs2.bn.weight), self.param_grad(bs2.bn.bias)
-            self.call(self.bwd, L.bn_bwd_finalize, bs1.accum.data_ptr(), 2, nsums, 0, float(y1.M), bs2.bn.weight.data_ptr(),
-                      n(bs2.mean), n(bs2.invstd), g2.data_ptr(), b2.data_ptr(), n(bs2.cA), n(bs2.cB), n(bs2.cC), bs2.C)
-        self.call(self.bwd, L.bn_bwd_finalize, bs1.accum.data_ptr(), 1, nsums, 1, float(y1.M), bs1.bn.weight.data_ptr(),
-                  n(bs1.mean), n(bs1.invstd), g1.data_ptr(), b1.data_ptr(), n(bs1.cA), n(bs1.cB), n(bs1.cC), bs1.C)
+        self.call(self.bwd, L.bn_act_bwd_reduce_finalize, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.mean),
+                  n(bs1.invstd), y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
+                  n(bs2.scale) if bs2 else None, n(bs2.shift) if bs2 else None, n(bs2.mean) if bs2 else None,
+                  n(bs2.invstd) if bs2 else None, pws.data_ptr(), y1.M, y1.C, act, float(slope), float(y1.M),
+                  bs1.bn.weight.data_ptr(), g1.data_ptr(), b1.data_ptr(), n(bs1.cA), n(bs1.cB), n(bs1.cC),
+                  bs2.bn.weight.data_ptr() if bs2 else None, n(g2), n(b2), n(bs2.cA) if bs2 else None, n(bs2.cB) if bs2 else None,
+                  n(bs2.cC) if bs2 else None)
         self.call(self.bwd, L.bn_act_bwd_apply, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.cA),
                   n(bs1.cB), n(bs1.cC), dy1.ptr, dy1.ldc,
                   y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,

@@ -321,6 +321,35 @@ def test_bn_act_fwd_bwd(dt, C, act, dual, resid):
     if dual:
         np.testing.assert_allclose(to_nchw(dy2, dt, C).numpy(), a2.grad.numpy(), **btol)
         np.testing.assert_allclose(o2[0].cpu().numpy(), p2g.grad.numpy(), rtol=2e-3 if dt == F32 else 3e-2, atol=1e-3 if dt == F32 else 1e-1)
+    # the fused entry points (what the launch plans call) give the same vectors as the two-step path above
+    rows = 37
+    yf = y1b.float().reshape(M, C)
+    part = torch.zeros(rows, 2, C, device="cuda")
+    idx = torch.arange(M, device="cuda") % rows
+    part[:, 0].index_add_(0, idx, yf)
+    part[:, 1].index_add_(0, idx, yf * yf)
+    fb = [torch.zeros(C, device="cuda") for _ in range(4)]
+    rm2, rv2 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    g1d, b1d, g2d = gam1.cuda(), bet1.cuda(), gam2.cuda()
+    scratch = torch.zeros(3 * C, dtype=torch.float64, device="cuda")
+    L.check(L.bn_stats_finalize(part.data_ptr(), rows, scratch.data_ptr(), float(M), g1d.data_ptr(), b1d.data_ptr(), rm2.data_ptr(),
+                                rv2.data_ptr(), 0.1, 1e-5, *[b.data_ptr() for b in fb], C, st()))
+    for got, ref in zip(fb, (s1, b1, m1, i1)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(rm2.cpu().numpy(), rmd.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv2.cpu().numpy(), rvd.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    f1 = [torch.zeros(C, device="cuda") for _ in range(5)]
+    f2 = [torch.zeros(C, device="cuda") for _ in range(5)]
+    L.check(L.bn_act_bwd_reduce_finalize(dt, db.data_ptr(), C, y1b.data_ptr(), C, s1.data_ptr(), b1.data_ptr(), m1.data_ptr(), i1.data_ptr(),
+                                         P(y2b) if dual else None, C, P(s2) if dual else None, P(b2) if dual else None,
+                                         P(m2) if dual else None, P(i2) if dual else None, pws.data_ptr(), M, C, act, slope, float(M),
+                                         g1d.data_ptr(), *[b.data_ptr() for b in f1],
+                                         g2d.data_ptr() if dual else None, *[(b.data_ptr() if dual else None) for b in f2], st()))
+    for got, ref in zip(f1, o1):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    if dual:
+        for got, ref in zip(f2, o2):
+            np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("dt", [F32, BF16], ids=["fp32", "bf16"])
