@@ -92,6 +92,9 @@ int mdcv_bn_act_bwd_apply(int dtype, const void* dout, int ldd, const void* y1, 
                           const void* y2, int ld2, const float* s2, const float* b2, const float* cA2, const float* cB2,
                           const float* cC2, void* dy2, int ldy2, int M, int C, int act, float slope, void* stream);
 int mdcv_colsum(int dtype, const void* x, int ldc, int M, int C, double* accum, void* stream);
+/* the same sums without atomics: per-block partial rows in partial_ws (mdcv_colsum_ws_floats floats), then one reduce launch -> out[C] */
+int mdcv_colsum_ws_floats(int dtype, int M, int C);
+int mdcv_colsum_f32(int dtype, const void* x, int ldc, int M, int C, float* partial_ws, float* out, void* stream);
 int mdcv_accum_to_f32(double* accum, float* out, int n, int zero_after, void* stream);
 
 /* ---- nn.Upsample(scale 2, nearest) fwd/bwd (models.py:86-88); H,W are the LOW-resolution dims */

@@ -1365,6 +1365,35 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
       tile[co * cstride + rem] = (gco < d.Cout && gci < d.Cin) ? w[((size_t)gco * d.Cin + gci) * KK + t] : 0.f;
     }
     __syncthreads();
+    constexpr int VEC = ET<T>::VEC;
+    if (CIT % VEC == 0) {                                   // 16-byte stores: VEC consecutive ci (wf) / co (wd) per thread
+      const int cvn = CIT / VEC;
+      for (int i = threadIdx.x; i < 16 * KK * cvn; i += 256) {
+        const int cv = i % cvn, r = i / cvn;
+        const int t = r % KK, co = r / KK;
+        const int gco = co0 + co, gci = ci0 + cv * VEC;
+        if (gco < d.Cout_pad && gci < d.Cin_pad) {
+          float v[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = tile[co * cstride + (cv * VEC + e) * KK + t];
+          *reinterpret_cast<uint4*>(wf + ((size_t)gco * KK + t) * d.Cin_pad + gci) = ET<T>::pack(v);
+        }
+      }
+      if (wd) {
+        constexpr int COV = 16 / VEC;
+        for (int i = threadIdx.x; i < COV * per; i += 256) {
+          const int cov = i % COV, r = i / COV;
+          const int t = r % KK, c = r / KK;
+          const int gco = co0 + cov * VEC, gci = ci0 + c;
+          if (gco < d.Cout_pad && gci < d.Cin_pad) {
+            float v[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = tile[(cov * VEC + e) * cstride + c * KK + t];
+            *reinterpret_cast<uint4*>(wd + ((size_t)gci * KK + t) * d.Cout_pad + gco) = ET<T>::pack(v);
+          }
+        }
+      }
+    } else {
     for (int i = threadIdx.x; i < 16 * per; i += 256) {   // wf: c fastest
       const int c = i % CIT, r = i / CIT;
       const int t = r % KK, co = r / KK;
@@ -1378,6 +1407,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
         const int gco = co0 + co, gci = ci0 + c;
         if (gco < d.Cout_pad && gci < d.Cin_pad) ET<T>::st(wd + ((size_t)gci * KK + t) * d.Cout_pad + gco, tile[co * cstride + c * KK + t]);
       }
+    }
     }
     __syncthreads();
   }

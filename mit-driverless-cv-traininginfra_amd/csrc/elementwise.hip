@@ -350,7 +350,10 @@ __global__ __launch_bounds__(1024) void bn_colfinal_kernel(ColFinArgs a) {
   if (c < a.C) {
     const size_t stride = (size_t)a.nsums * a.C;
     const float* p = a.partial + c;
-    if (a.nsums == 2) {
+    if (a.nsums == 1) {
+#pragma unroll 4
+      for (int r = ry; r < a.rows; r += 64) s0 += (double)p[r * stride];
+    } else if (a.nsums == 2) {
 #pragma unroll 4
       for (int r = ry; r < a.rows; r += 64) { s0 += (double)p[r * stride]; s1 += (double)p[r * stride + a.C]; }
     } else {
@@ -383,6 +386,8 @@ __global__ __launch_bounds__(1024) void bn_colfinal_kernel(ColFinArgs a) {
       a.rm[c] = (1.f - a.momentum) * a.rm[c] + a.momentum * (float)mean;
       a.rv[c] = (1.f - a.momentum) * a.rv[c] + a.momentum * (float)unbiased;
     }
+  } else if (MODE == 2) {
+    a.scale[c] = (float)tot[0][cx];            // plain column sum (bias gradient)
   } else {
     bwd_coeffs(tot[0][cx], tot[1][cx], a.count, a.g1[c], a.mean1[c], a.is1[c], a.dg1, a.db1, a.cA1, a.cB1, a.cC1, c);
     if (a.nsums == 3) bwd_coeffs(tot[0][cx], tot[2][cx], a.count, a.g2[c], a.mean2[c], a.is2[c], a.dg2, a.db2, a.cA2, a.cB2, a.cC2, c);
@@ -470,6 +475,37 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
       float t = 0.f;
       for (int q = 0; q < PPI; ++q) t += red[(q * CV + cv) * 8 + e];
       atomicAdd(&accum[cv * VEC + e], (double)t);
+    }
+  }
+}
+// same strip walk, but every block stores its [C] partial row (no atomics); bn_colfinal_kernel<2> sums the rows
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const T* __restrict__ x, int ldc, int M, int C, float* __restrict__ partial, int PB, int CV, int PPI) {
+  constexpr int VEC = ET<T>::VEC;
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const bool active = tid < PPI * CV;
+  const int cv = active ? tid % CV : 0, pi = active ? tid / CV : 0;
+  float s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+  const long long p0 = (long long)blockIdx.x * PB, p1 = min((long long)M, p0 + PB);
+  if (active)
+    for (long long p = p0 + pi; p < p1; p += PPI) {
+      float v[VEC];
+      ET<T>::unpack(*reinterpret_cast<const uint4*>(x + p * ldc + cv * VEC), v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s[e] += v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[tid * 8 + e] = s[e];
+  __syncthreads();
+  if (active && pi == 0) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float t = 0.f;
+      for (int q = 0; q < PPI; ++q) t += red[(q * CV + cv) * 8 + e];
+      partial[(size_t)blockIdx.x * C + cv * VEC + e] = t;
     }
   }
 }
@@ -800,6 +836,32 @@ int mdcv_colsum(int dtype, const void* x, int ldc, int M, int C, double* accum, 
     Strip s = make_strip<float>(M, C, reduce_blocks(C, 1)); if (s.CV > 256) return MDCV_EARG;
     hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, (const float*)x, ldc, M, C, accum, s.PB, s.CV, s.PPI);
   } else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+// column sums without atomics: per-block partial rows (partial_ws: mdcv_colsum_ws_floats floats) + one column-owner launch
+int mdcv_colsum_ws_floats(int dtype, int M, int C) {
+  const Strip s = dtype == MDCV_BF16 ? make_strip<bf16_t>(M, C, reduce_blocks(C, 1)) : make_strip<float>(M, C, reduce_blocks(C, 1));
+  return cdiv(M, s.PB) * C;
+}
+int mdcv_colsum_f32(int dtype, const void* x, int ldc, int M, int C, float* partial_ws, float* out, void* stream) {
+  if (!x || !partial_ws || !out || (C & 7)) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  int rows = 0;
+  if (dtype == MDCV_BF16) {
+    Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, 1)); if (s.CV > 256) return MDCV_EARG;
+    rows = cdiv(M, s.PB);
+    hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)x, ldc, M, C, partial_ws, s.PB, s.CV, s.PPI);
+  } else if (dtype == MDCV_F32) {
+    Strip s = make_strip<float>(M, C, reduce_blocks(C, 1)); if (s.CV > 256) return MDCV_EARG;
+    rows = cdiv(M, s.PB);
+    hipLaunchKernelGGL(colsum_rows_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)x, ldc, M, C, partial_ws, s.PB, s.CV, s.PPI);
+  } else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  ColFinArgs f = {};
+  f.partial = partial_ws; f.rows = rows; f.nsums = 1; f.C = C; f.count = 1.0; f.scale = out;
+  hipLaunchKernelGGL(bn_colfinal_kernel<2>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, f);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -280,11 +280,9 @@ class Plan:
             zero.__name__ = "zero_bias_grad"
             self.bwd.append((zero, ()))
             return
-        acc = torch.zeros(cs.cout_pad, dtype=torch.float64, device=self.device)
         tmp = self.f32(cs.cout_pad)
-        self.keep.append(acc)
-        self.call(self.bwd, self.L.colsum, self.dtype, dy.ptr, dy.ldc, dy.M, cs.cout_pad, acc.data_ptr())
-        self.call(self.bwd, self.L.accum_to_f32, acc.data_ptr(), tmp.data_ptr(), cs.cout_pad, 1)
+        pws = self.f32(int(self.L.colsum_ws_floats(self.dtype, dy.M, cs.cout_pad)), zero=False)
+        self.call(self.bwd, self.L.colsum_f32, self.dtype, dy.ptr, dy.ldc, dy.M, cs.cout_pad, pws.data_ptr(), tmp.data_ptr())
 
         def copy(stream, gb=gb, tmp=tmp, n=cs.cout):
             gb.copy_(tmp[:n].view_as(gb), non_blocking=True)

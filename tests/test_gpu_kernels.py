@@ -376,6 +376,15 @@ def test_upsample_and_colsum(dt):
     L.check(L.colsum(dt, tb.data_ptr(), 24, 3 * 7 * 5, 24, acc.data_ptr(), st()))
     L.check(L.accum_to_f32(acc.data_ptr(), o.data_ptr(), 24, 1, st()))
     np.testing.assert_allclose(o.cpu().numpy(), rnd(dt, t).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+    # atomics-free variant (partial rows + column-owner reduce), also on a tall input (many partial rows)
+    for shape in ((3, 24, 7, 5), (4, 264, 40, 37)):
+        t = torch.randn(*shape)
+        tb = to_nhwc(t, dt)
+        Cc, Mm = shape[1], shape[0] * shape[2] * shape[3]
+        pws = torch.empty(L.colsum_ws_floats(dt, Mm, Cc), device="cuda")
+        o2 = torch.zeros(Cc, device="cuda")
+        L.check(L.colsum_f32(dt, tb.data_ptr(), Cc, Mm, Cc, pws.data_ptr(), o2.data_ptr(), st()))
+        np.testing.assert_allclose(o2.cpu().numpy(), rnd(dt, t).sum((0, 2, 3)).numpy(), rtol=1e-4, atol=2e-3 * (Mm / 105) ** 0.5)
 
 
 def test_adam_sgd_match_torch():
