@@ -10,6 +10,7 @@ already resident in HBM.  Primary workload: CVC-YOLOv3 (yolo_baseline topology) 
 (configs[1]).  Weak scaling: per-GPU batch fixed.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -351,7 +352,8 @@ def main():
     if a.workload in ("both", "rektnet"):
         torch.manual_seed(0)
         kp = KeypointNet(7, (80, 80), precision=a.precision).to(device).train()
-        crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
+        with contextlib.redirect_stdout(sys.stderr):           # the reference's constructor prints its configuration
+            crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
         opt = FusedAdam(kp, lr=0.1)
         red = GradAllReducer.attach(kp, bucket_mb=32.0)
         g = torch.Generator().manual_seed(2000 + rank)

@@ -34,6 +34,7 @@ class GradAllReducer:
         self._flat = None
         self._pending_hi = 0
         self._overlap = False
+        self.extra_streams = []                   # compute-side streams besides the current one (the plans' wgrad stream)
         self.log = []
 
     # ---------------------------------------------------------------- plain use
@@ -96,6 +97,8 @@ class GradAllReducer:
         self.log.append((lo, hi))
         if seg.is_cuda:
             self._stream.wait_stream(torch.cuda.current_stream())
+            for extra in self.extra_streams:
+                self._stream.wait_stream(extra)
             with torch.cuda.stream(self._stream):
                 self._reduce(seg)
         else:

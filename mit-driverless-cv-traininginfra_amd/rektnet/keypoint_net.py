@@ -52,7 +52,7 @@ class _KpPlan(_NetPlan):
         if self.use_graph:
             self._graphed("bwd")          # one graph per (dpts, dhm) presence combination (self.flags)
         else:
-            self.run(self.bwd, torch.cuda.current_stream().cuda_stream)
+            self.run_bwd_list()
 
 
 class KeypointNet(nn.Module, FlatParamsMixin):

@@ -239,13 +239,45 @@ class _NetPlan(Plan):
                 self.L.check(self.L.graph_launch(g, gs.cuda_stream), "graph_launch")
         cur.wait_stream(gs)
 
+    # Weight gradients are leaves of the backward dependency chain (only the optimizer / the gradient exchange read them), so
+    # they run on a side stream: the MFMA-bound wgrad kernels of layer L overlap the HBM-bound BatchNorm passes and the
+    # latency-bound tiny kernels of layers L-1, L-2, ... on the main stream.  Every buffer of a plan is its own allocation (no
+    # pooling), so the only ordering needed is "dY(L), X(L) ready" (side waits on main) and "all gradients done" (main waits on
+    # side at the end; the data-parallel reducer's comm stream waits on both).
+    overlap_wgrad = os.environ.get("MDCV_WGRAD_STREAM", "1") == "1"
+
+    def side(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def run_bwd_list(self):
+        """The backward launch list on the current stream, weight gradients on the side stream (see above)."""
+        cur = torch.cuda.current_stream()
+        if not self.overlap_wgrad or "run" in self.__dict__:                   # (bench.py's per-kernel timing swaps `run`)
+            self.run(self.bwd, cur.cuda_stream)
+            return
+        side = self.side()
+        st, ss = cur.cuda_stream, side.cuda_stream
+        used = False
+        for fn, args in self.bwd:
+            if getattr(fn, "__name__", "") == "conv2d_wgrad":
+                side.wait_stream(cur)
+                rc = fn(*args, ss)
+                used = True
+            else:
+                rc = fn(*args, st)
+            if rc:
+                raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
+        if used:
+            cur.wait_stream(side)
+
     def run_backward(self, gout):
-        st = torch.cuda.current_stream().cuda_stream
         self.gscale.copy_(gout.reshape(-1)[:self.gscale.numel()], non_blocking=True)
         if self.use_graph:
             self._graphed("bwd")
         else:
-            self.run(self.bwd, st)
+            self.run_bwd_list()
 
 
 class FlatParamsMixin:
@@ -298,6 +330,7 @@ class FlatParamsMixin:
         plan.on_ready = red.on_ready if overlap else None
         if red is not None:
             red.begin(self._gflat, overlap)
+            red.extra_streams = [plan.side()] if (plan.overlap_wgrad and not plan.use_graph and self._gflat.is_cuda) else []
         plan.run_backward(gout)
         plan.on_ready = None
         if keep is not None:
