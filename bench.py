@@ -279,6 +279,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     os.environ["MDCV_GRAPH"] = str(a.graph)
+    if os.environ.get("MDCV_MAIN_PRIO", "0") == "1":            # run the step on a high-priority stream (the wgrad side stream stays normal)
+        hp = torch.cuda.Stream(device=device, priority=-1)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
 
     from mdcv.yolo.models import Darknet
     from mdcv.rektnet.keypoint_net import KeypointNet
@@ -336,13 +340,12 @@ def main():
             extra["yolo"]["sum_kernel_ms"] = round(tot, 3)
             if conv[1] > 0:
                 ach = conv[2] / (conv[1] * 1e-3) / 1e12
-                traffic = None           # HBM bytes per launch of this kernel from rocprofv3 PMC passes of this same command
-                tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_yolo.json")   # (cannot be collected live: see file note)
+                traffic = None           # HBM bytes per mdcv_conv2d call from rocprofv3 PMC passes of this same command
+                tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_yolo_v2.json")   # (scripts/pmc_traffic.sh; cannot be collected live)
                 if os.path.exists(tpath) and B == 32 and a.precision == "bf16":
-                    tk = json.load(open(tpath))["kernels"].get("conv_glds_kernel")
-                    if tk:
-                        traffic = tk["fetch_bytes_per_launch"] + tk["write_bytes_per_launch"]
-                result["roofline"] = {"bound": "mfma", "kernel": "conv_glds_kernel<bf16> (all mdcv_conv2d launches: forward + data gradient)",
+                    fam = json.load(open(tpath))["conv2d_family"]
+                    traffic = (fam["fetch_bytes_per_step"] + fam["write_bytes_per_step"]) / conv[0]
+                result["roofline"] = {"bound": "mfma", "kernel": "mdcv_conv2d family (mdcv_conv3x3_shift_kernel + conv_glds_kernel, bf16): every forward + data-gradient launch",
                                       "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                       "traffic": traffic, "launches": conv[0], "avg_launch_ms": conv[1] / conv[0],
                                       "flops_per_launch_avg": conv[2] / conv[0]}

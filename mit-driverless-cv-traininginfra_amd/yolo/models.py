@@ -248,7 +248,13 @@ class _NetPlan(Plan):
 
     def side(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            prio = int(os.environ.get("MDCV_WGRAD_PRIO", "0"))       # 0 = same as the main stream ; 1 = lowest the device offers
+            if prio:
+                with torch.cuda.device(self.device):
+                    lo = torch.cuda.Stream.priority_range()[0]        # (least, greatest): the least priority is the larger number
+                self._side = torch.cuda.Stream(device=self.device, priority=lo)
+            else:
+                self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
     def run_bwd_list(self):
