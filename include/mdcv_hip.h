@@ -34,6 +34,16 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
                 const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
                 int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
                 int KH, int KW, int stride, int pad, int dil, void* stream);
+/* Data gradient (mode 1, same geometry arguments as mdcv_conv2d) that also writes the BatchNorm-backward partial sums of the layer
+ * whose output gradient it produces: partial[row][0][c] = sum g, partial[row][1][c] = sum g*(y - mean), g = dz * act'(scale*y + shift),
+ * one row per 128 output positions (y: that layer's raw conv output, same pixel/channel indexing as the gradient written to `out`).
+ * _rows() = number of rows written, or 0 when the geometry cannot take the fused path.  Finish with mdcv_bn_bwd_finalize_rows. */
+int mdcv_conv2d_dgrad_bnsums_rows(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
+                                  int pad, int dil, int in_ldc);
+int mdcv_conv2d_dgrad_bnsums(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const void* addsrc,
+                             int add_ldc, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
+                             int pad, int dil, const void* y, int ldy, const float* scale, const float* shift, const float* mean, int act,
+                             float slope, float* partial, void* stream);
 int mdcv_conv2d_stats_rows(int M);      /* generic kernels: one row per 128 output pixels */
 /* rows of stats_partial a FORWARD launch with this geometry writes (use this one to size the buffer: the 3x3 / stride-1 /
  * pad-1 shift kernel walks a padded pixel stream and writes more rows than M / 128; every row it returns is written). */
@@ -81,6 +91,9 @@ int mdcv_bn_act_bwd_reduce_finalize(int dtype, const void* dout, int ldd, const 
                                     const float* mean2, const float* invstd2, float* partial_ws, int M, int C, int act, float slope,
                                     double count, const float* gamma1, float* dgamma1, float* dbeta1, float* cA1, float* cB1, float* cC1,
                                     const float* gamma2, float* dgamma2, float* dbeta2, float* cA2, float* cB2, float* cC2, void* stream);
+/* finalize for the fused data-gradient sums: rows x [2][C] partials (sum g, sum g*(y-mean)) -> dgamma, dbeta, cA, cB, cC */
+int mdcv_bn_bwd_finalize_rows(const float* partial, int rows, int C, double count, const float* gamma, const float* mean,
+                              const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cC, void* stream);
 int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,
                            const float* mean1, const float* invstd1, const void* y2, int ld2, const float* s2, const float* b2,
                            const float* mean2, const float* invstd2, double* accum, float* partial_ws, int M, int C, int act, float slope,

@@ -17,6 +17,7 @@
 // (sum, sum of squares per output channel) are produced from the fp32 accumulators in the epilogue.
 #include "common.h"
 #include "conv_shift.h"
+#include "bn_fuse.h"
 
 namespace {
 
@@ -29,6 +30,7 @@ struct ConvArgs {
   int KH, KW, stride, pad, dil;
   int M, Ktot, tiles_n, sshift, tiles_total, xcd_chunk;
   int ph, pw, Hs, Ws, kh0, kw0, nkh, nkw;     // MODE 2 (stride-2 data gradient, one output-parity class per launch)
+  BnFuseArgs fuse;                            // BatchNorm-backward sums folded into the store loop of a data gradient (fuse.y == NULL: off)
 };
 
 // One K tile of MFMAs for a wave: FM x FN fragments of 16x16, KT k-steps of 64 bytes per LDS row (row pitch RB bytes).
@@ -356,7 +358,7 @@ template <> struct FragSwz<float> {
 typedef __attribute__((address_space(3))) void lds_void_t;
 int g_conv_no_ut = 0;    // tuning/A-B: 1 disables the uniform-tap address path
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE>
 __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, unsigned in_bytes, unsigned w_bytes) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int VEC = ET<T>::VEC;
@@ -626,6 +628,58 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
   const T* __restrict__ addsrc = reinterpret_cast<const T*>(a.addsrc);
   constexpr int VPRO = BN / VEC;
+  if constexpr (FUSE) {
+    // data gradient with the BatchNorm-backward sums of the producer layer folded in (bn_fuse.h)
+    using Acc = BnFuseAcc<T, BN, NT>;
+    Acc fz;
+    const int cv = tid % VPRO, n = tile_n * BN + cv * VEC;
+    fz.init(a.fuse, n, a.Nout);
+    const T* __restrict__ fy = reinterpret_cast<const T*>(a.fuse.y);
+    float* fred = sstat;
+    constexpr int PPG = 128 / Acc::RPP;                    // passes per 128-pixel group
+#pragma unroll 1
+    for (int g0 = 0; g0 < BM; g0 += 128) {
+      long long pixv[PPG]; uint4 dq[PPG], aq[PPG], yq[PPG];
+#pragma unroll
+      for (int u = 0; u < PPG; ++u) {
+        const int row = g0 + u * Acc::RPP + tid / VPRO;
+        const int m = tile_m * BM + row;
+        pixv[u] = -1;
+        dq[u] = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
+        if (m < a.M && n < a.Nout) {
+          long long pix = m;
+          if (MODE == 2) {
+            const int img = m / HWo, rem = m - img * HWo;
+            const int ha = rem / Wrow, wb = rem - ha * Wrow;
+            pix = ((long long)img * a.Hout + (a.ph + 2 * ha)) * a.Wout + (a.pw + 2 * wb);
+          }
+          pixv[u] = pix;
+          if (addsrc) aq[u] = *reinterpret_cast<const uint4*>(addsrc + (pix * a.add_ldc + n));
+          yq[u] = *reinterpret_cast<const uint4*>(fy + (pix * a.fuse.ldy + n));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PPG; ++u) {
+        if (pixv[u] >= 0) {
+          float x[VEC];
+          uint4 d = dq[u];
+          ET<T>::unpack(d, x);
+          if (addsrc) {
+            float y[VEC];
+            ET<T>::unpack(aq[u], y);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) x[e] += y[e];
+            d = ET<T>::pack(x);
+            ET<T>::unpack(d, x);
+          }
+          *reinterpret_cast<uint4*>(out + (pixv[u] * a.out_ldc + n)) = d;
+          fz.add(a.fuse, x, yq[u]);
+        }
+      }
+      fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (tile_m * BM + g0) >> 7);
+    }
+    return;
+  }
   for (int v = tid; v < BM * VPRO; v += NT) {
     const int row = v / VPRO, cv = v - row * VPRO;
     const int m = tile_m * BM + row, n = tile_n * BN + cv * VEC;
@@ -650,14 +704,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
   }
 }
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT>
-int launch_conv_glds_ut(const ConvArgs& a0, hipStream_t st, int B) {
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE>
+int launch_conv_glds_f(const ConvArgs& a0, hipStream_t st, int B) {
   ConvArgs a = a0;
   constexpr int PIPE = STAGES * (BM + BN) * 64;
   constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
-  constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;
+  constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;   // + statistics / fused-sum scratch (NW*BN floats <= WM*2*BN)
   static bool attr_set = false;
-  auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN, STAGES, UT>;
+  auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN, STAGES, UT, FUSE>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
@@ -671,6 +725,14 @@ int launch_conv_glds_ut(const ConvArgs& a0, hipStream_t st, int B) {
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(WM * WN * 64), LDS, st, a, in_bytes, w_bytes);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
+}
+
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT>
+int launch_conv_glds_ut(const ConvArgs& a, hipStream_t st, int B) {
+  if constexpr (MODE != 0) {                    // the fused BatchNorm-backward sums exist for data gradients only
+    if (a.fuse.y) return launch_conv_glds_f<T, MODE, BM, BN, WM, WN, STAGES, UT, true>(a, st, B);
+  }
+  return launch_conv_glds_f<T, MODE, BM, BN, WM, WN, STAGES, UT, false>(a, st, B);
 }
 
 template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES = 2>
@@ -1455,10 +1517,10 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
 // =================================================================================================
 extern "C" {
 
-int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc,
-                const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
-                int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
-                int KH, int KW, int stride, int pad, int dil, void* stream) {
+static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc,
+                       const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
+                       int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
+                       int KH, int KW, int stride, int pad, int dil, const BnFuseArgs* fuse, void* stream) {
   if (!in || !w_packed || !out) return MDCV_EARG;
   if ((Cin & 7) || (Nout & 7) || (in_ldc & 7) || (out_ldc & 7) || (addsrc && (add_ldc & 7))) return MDCV_EARG;
   if (stride != 1 && stride != 2) return MDCV_EARG;
@@ -1470,12 +1532,14 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin; a.tiles_n = 0; a.sshift = stride == 2 ? 1 : 0; a.tiles_total = 0; a.xcd_chunk = 0;
   a.ph = a.pw = a.kh0 = a.kw0 = 0; a.Hs = Hout; a.Ws = Wout; a.nkh = KH; a.nkw = KW;
+  a.fuse = fuse ? *fuse : BnFuseArgs{};
   if (a.M <= 0) return MDCV_OK;
   hipStream_t st = (hipStream_t)stream;
   // stride-2 data gradient: 4 launches, one per output-parity class, each visiting only its live taps (no masked MACs)
   const bool small = (long long)B * Hin * Win * in_ldc * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31) &&
                      (long long)Nout * KH * KW * Cin * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31);
-  if (mode == 1 && stride == 2 && dil == 1 && small && g_conv_variant != 0) {
+  if (mode == 1 && stride == 2 && dil == 1 && small && (g_conv_variant != 0 || fuse)) {
+    int row_base = 0;
     for (int cls = 0; cls < 4; ++cls) {
       ConvArgs c = a;
       c.ph = cls >> 1; c.pw = cls & 1;
@@ -1485,6 +1549,8 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
       c.M = B * c.Hs * c.Ws;
       c.Ktot = c.nkh * c.nkw * Cin;
       if (c.M <= 0) continue;
+      c.fuse.row_base = row_base;                 // (fused BatchNorm sums: one partial row per 128 pixels of each parity class)
+      row_base += cdiv(c.M, 128);
       int rc;
       if (c.nkh <= 0 || c.nkw <= 0) { c.nkh = c.nkh > 0 ? c.nkh : 0; c.nkw = c.nkw > 0 ? c.nkw : 0; c.Ktot = 0; }
       if (dtype == MDCV_BF16) rc = dispatch_dgrad_s2<bf16_t>(c, st, B);
@@ -1496,8 +1562,16 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
   }
   // 3x3 / stride 1 / pad 1 on wide layers: nine shifted GEMMs over one LDS-resident activation chunk (conv_shift.hip)
   const bool shift_ok = Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc);
-  if (shift_ok && g_conv_variant < 0)
-    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, st);
+  if (shift_ok && (g_conv_variant < 0 || fuse))
+    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st);
+  if (fuse) {                                     // the fused store loop lives in the LDS-DMA kernels: never fall back to the staged ones
+    if (!small) return MDCV_EARG;
+    const int keep = g_conv_variant;
+    if (keep >= 0 && keep < 6) g_conv_variant = -1;
+    const int rc = dtype == MDCV_BF16 ? dispatch_conv<bf16_t, 1>(a, st, B) : (dtype == MDCV_F32 ? dispatch_conv<float, 1>(a, st, B) : MDCV_EARG);
+    g_conv_variant = keep;
+    return rc;
+  }
   if (shift_ok && stats_partial) {   // forced generic kernel on a shift-eligible geometry (A/B runs): the caller sized the partial
     const int r0 = cdiv(a.M, 128), r1 = mdcv_shift_stats_rows(B, Hout, Wout);   // rows for the shift kernel; zero the unused tail
     if (r1 > r0) {
@@ -1508,6 +1582,50 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
   if (dtype == MDCV_BF16) return mode == 0 ? dispatch_conv<bf16_t, 0>(a, st, B) : dispatch_conv<bf16_t, 1>(a, st, B);
   if (dtype == MDCV_F32) return mode == 0 ? dispatch_conv<float, 0>(a, st, B) : dispatch_conv<float, 1>(a, st, B);
   return MDCV_EARG;
+}
+
+int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc,
+                const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
+                int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
+                int KH, int KW, int stride, int pad, int dil, void* stream) {
+  return conv2d_impl(dtype, mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hin, Win, Cin, Hout, Wout, Nout,
+                     KH, KW, stride, pad, dil, nullptr, stream);
+}
+
+// Data gradient (mode 1 of mdcv_conv2d, same geometry arguments) that ALSO writes the BatchNorm-backward partial sums of the
+// layer that produced the tensor whose gradient this is:  partial[row][0][c] = sum g, partial[row][1][c] = sum g*(y - mean),
+// g = dz * act'(scale*y + shift), one row per 128 output positions.  rows() returns how many rows are written for a geometry,
+// or 0 when this geometry cannot take the fused path (the caller then keeps mdcv_conv2d + mdcv_bn_act_bwd_reduce).
+int mdcv_conv2d_dgrad_bnsums_rows(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
+                                  int pad, int dil, int in_ldc) {
+  const int es = dtype == MDCV_BF16 ? 2 : 4;
+  if (dtype != MDCV_BF16 && dtype != MDCV_F32) return 0;
+  if ((long long)B * Hin * Win * in_ldc * es >= (1LL << 31) || (long long)Nout * KH * KW * Cin * es >= (1LL << 31)) return 0;
+  if (Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc))
+    return mdcv_shift_stats_rows(B, Hout, Wout);
+  if (stride == 2 && dil == 1) {
+    int rows = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int ph = cls >> 1, pw = cls & 1;
+      const int m = B * ((Hout - ph + 1) / 2) * ((Wout - pw + 1) / 2);
+      if (m > 0) rows += cdiv(m, 128);
+    }
+    return rows;
+  }
+  return cdiv(B * Hout * Wout, 128);
+}
+
+int mdcv_conv2d_dgrad_bnsums(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const void* addsrc,
+                             int add_ldc, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
+                             int pad, int dil, const void* y, int ldy, const float* scale, const float* shift, const float* mean, int act,
+                             float slope, float* partial, void* stream) {
+  if (!y || !scale || !shift || !mean || !partial || (ldy & 7)) return MDCV_EARG;
+  if (mdcv_conv2d_dgrad_bnsums_rows(dtype, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW, stride, pad, dil, in_ldc) <= 0) return MDCV_EARG;
+  BnFuseArgs f;
+  f.y = y; f.scale = scale; f.shift = shift; f.mean = mean; f.partial = partial; f.ldy = ldy; f.act = act; f.row_base = 0;
+  f.slope = act == 2 ? 0.f : slope;
+  return conv2d_impl(dtype, 1, in, in_ldc, w_packed, out, out_ldc, nullptr, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Hout, Wout, Nout,
+                     KH, KW, stride, pad, dil, &f, stream);
 }
 
 // number of rows of the [rows][2][Nout] BatchNorm partial-statistics buffer mdcv_conv2d writes (one per 128 output pixels)

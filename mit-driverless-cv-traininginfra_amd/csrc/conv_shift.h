@@ -1,6 +1,7 @@
 // Internal interface between conv_igemm.hip (dispatch of mdcv_conv2d) and conv_shift.hip (3x3 stride-1 shift-GEMM kernel).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "bn_fuse.h"
 
 struct ShiftArgs {
   const void* in; const void* w; void* out; const float* bias; const void* addsrc; float* stats;
@@ -9,11 +10,12 @@ struct ShiftArgs {
   int Wq, Sq, Mq;                       // W+1, (H+1)(W+1), B*Sq: the padded position stream
   int tiles_n, tiles_total, xcd_chunk;
   int p_base;                           // first stream position of this launch (multiple of 256)
+  BnFuseArgs fuse;                      // BatchNorm-backward sums folded into the store loop (fuse.y == NULL: off)
   int nchunks, wrow, nca;               // Cin/32 ; 9*Cin elements per weight row ; KiB-chunks per activation chunk
 };
 
 bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc);
 int mdcv_shift_stats_rows(int B, int H, int W);
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
-                    int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, hipStream_t st);
+                    int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st);
 void mdcv_shift_set_ring(int ring);

@@ -20,6 +20,7 @@
 // All DMA addresses are loop invariant per lane (voffset) + a scalar (soffset): the K loop has no address VALU at all.
 #include "common.h"
 #include "conv_shift.h"
+#include "bn_fuse.h"
 
 namespace {
 
@@ -49,7 +50,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 }  // namespace
 
-template <int MODE, int BM, int NPA, int BRING>
+template <int MODE, int BM, int NPA, int BRING, bool FUSE>
 __global__ __launch_bounds__(NW * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a, unsigned in_bytes, unsigned w_bytes) {
   constexpr int TM = BM / WM, FM = TM / 16;
   // LDS: [A0: nca KiB][A1: nca KiB][weight ring: BRING x 8 KiB][1 KiB sink for the surplus chunk DMAs]; the epilogue reuses it
@@ -275,20 +276,65 @@ __global__ __launch_bounds__(NW * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
   const bf16_t* __restrict__ addsrc = reinterpret_cast<const bf16_t*>(a.addsrc);
   constexpr int VPRO = BN / 8;
-  for (int v = tid; v < BM * VPRO; v += NW * 64) {
-    const int row = v / VPRO, cv = v - row * VPRO;
-    const int pix = rowpix[row], n = tile_n * BN + cv * 8;
-    if (pix >= 0 && n < a.Nout) {
-      uint4 d = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
-      if (addsrc) {
-        float x[8], y[8];
-        ET<bf16_t>::unpack(d, x);
-        ET<bf16_t>::unpack(*reinterpret_cast<const uint4*>(addsrc + ((size_t)pix * a.add_ldc + n)), y);
+  if constexpr (!FUSE) {
+    for (int v = tid; v < BM * VPRO; v += NW * 64) {
+      const int row = v / VPRO, cv = v - row * VPRO;
+      const int pix = rowpix[row], n = tile_n * BN + cv * 8;
+      if (pix >= 0 && n < a.Nout) {
+        uint4 d = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
+        if (addsrc) {
+          float x[8], y[8];
+          ET<bf16_t>::unpack(d, x);
+          ET<bf16_t>::unpack(*reinterpret_cast<const uint4*>(addsrc + ((size_t)pix * a.add_ldc + n)), y);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] += y[e];
-        d = ET<bf16_t>::pack(x);
+          for (int e = 0; e < 8; ++e) x[e] += y[e];
+          d = ET<bf16_t>::pack(x);
+        }
+        *reinterpret_cast<uint4*>(out + ((size_t)pix * a.out_ldc + n)) = d;
       }
-      *reinterpret_cast<uint4*>(out + ((size_t)pix * a.out_ldc + n)) = d;
+    }
+  } else {
+    // data gradient with the BatchNorm-backward sums of the producer layer folded in (bn_fuse.h)
+    using Acc = BnFuseAcc<bf16_t, BN, NW * 64>;
+    Acc fz;
+    const int cv = tid % VPRO, n = tile_n * BN + cv * 8;
+    fz.init(a.fuse, n, a.Nout);
+    const bf16_t* __restrict__ fy = reinterpret_cast<const bf16_t*>(a.fuse.y);
+    float* fred = reinterpret_cast<float*>(smem + STAT_OFF);
+    constexpr int PPG = 128 / Acc::RPP;                    // passes per 128-position group
+#pragma unroll 1
+    for (int g0 = 0; g0 < BM; g0 += 128) {
+      // all loads of the group first (staging, addsrc, y), then the arithmetic: the passes are independent
+      int pixv[PPG]; uint4 dq[PPG], aq[PPG], yq[PPG];
+#pragma unroll
+      for (int u = 0; u < PPG; ++u) {
+        const int row = g0 + u * Acc::RPP + tid / VPRO;
+        pixv[u] = n < a.Nout ? rowpix[row] : -1;
+        dq[u] = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
+        if (pixv[u] >= 0) {
+          if (addsrc) aq[u] = *reinterpret_cast<const uint4*>(addsrc + ((size_t)pixv[u] * a.add_ldc + n));
+          yq[u] = *reinterpret_cast<const uint4*>(fy + ((size_t)pixv[u] * a.fuse.ldy + n));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PPG; ++u) {
+        if (pixv[u] >= 0) {
+          float x[8];
+          uint4 d = dq[u];
+          ET<bf16_t>::unpack(d, x);
+          if (addsrc) {
+            float y[8];
+            ET<bf16_t>::unpack(aq[u], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += y[e];
+            d = ET<bf16_t>::pack(x);
+            ET<bf16_t>::unpack(d, x);                     // the sums see dz as stored
+          }
+          *reinterpret_cast<uint4*>(out + ((size_t)pixv[u] * a.out_ldc + n)) = d;
+          fz.add(a.fuse, x, yq[u]);
+        }
+      }
+      fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (p0 + g0) >> 7);
     }
   }
 #if defined(MDCV_SHIFT_TS) || defined(MDCV_SHIFT_WG)
@@ -298,18 +344,18 @@ __global__ __launch_bounds__(NW * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a
 
 namespace {
 
-template <int MODE, int BM, int NPA>
-int launch_shift(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
+template <int MODE, int BM, int NPA, bool FUSE>
+int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   constexpr int BRING = 3;
   a.p_base = p_base;
   a.tiles_total = tiles_m * a.tiles_n;
   a.xcd_chunk = (a.tiles_total + 7) / 8;
   a.nca = (BM + 2 * a.Wq + 2 + 15) / 16;                   // KiB-chunks (16 stream rows each) of one activation chunk
   const int pipe = 2 * a.nca * 1024 + BRING * BTILE + 1024;
-  const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;
+  const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics / fused-sum scratch (NW*BN floats)
   const int lds = pipe > epi ? pipe : epi;
   static int attr_lds = 0;
-  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING>;
+  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE>;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
@@ -318,6 +364,14 @@ int launch_shift(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned 
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, in_bytes, w_bytes);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
+}
+
+template <int MODE, int BM, int NPA>
+int launch_shift(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
+  if constexpr (MODE == 1) {                    // the fused BatchNorm-backward sums exist for data gradients only
+    if (a.fuse.y) return launch_shift_f<MODE, BM, NPA, true>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  }
+  return launch_shift_f<MODE, BM, NPA, false>(a, p_base, tiles_m, st, in_bytes, w_bytes);
 }
 
 template <int MODE, int BM>
@@ -370,8 +424,9 @@ bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int 
 int mdcv_shift_stats_rows(int B, int H, int W) { return (int)(((long long)B * (H + 1) * (W + 1) + 127) / 128); }
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
-                    int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, hipStream_t st) {
+                    int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st) {
   ShiftArgs a;
+  if (fuse) a.fuse = *fuse; else a.fuse = BnFuseArgs{};
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addsrc = addsrc; a.stats = stats;
   a.in_ldc = in_ldc; a.out_ldc = out_ldc; a.add_ldc = add_ldc;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Nout = Nout;
@@ -394,7 +449,7 @@ extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
 #if defined(MDCV_SHIFT_TS) || defined(MDCV_SHIFT_WG)
 extern "C" int mdcv_debug_shift_occ(int lds) {
   int nb = -1;
-  auto kern = mdcv_conv3x3_shift_kernel<0, 256, 3, 3>;
+  auto kern = mdcv_conv3x3_shift_kernel<0, 256, 3, 3, false>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NW * 64, (size_t)lds);
   hipFuncAttributes fa; hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));

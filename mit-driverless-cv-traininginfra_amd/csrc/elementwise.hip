@@ -388,6 +388,8 @@ __global__ __launch_bounds__(1024) void bn_colfinal_kernel(ColFinArgs a) {
     }
   } else if (MODE == 2) {
     a.scale[c] = (float)tot[0][cx];            // plain column sum (bias gradient)
+  } else if (MODE == 3) {                      // sums from the fused data gradient: second sum is sum g*(y - mean), not yet / std
+    bwd_coeffs(tot[0][cx], tot[1][cx] * (double)a.is1[c], a.count, a.g1[c], a.mean1[c], a.is1[c], a.dg1, a.db1, a.cA1, a.cB1, a.cC1, c);
   } else {
     bwd_coeffs(tot[0][cx], tot[1][cx], a.count, a.g1[c], a.mean1[c], a.is1[c], a.dg1, a.db1, a.cA1, a.cB1, a.cC1, c);
     if (a.nsums == 3) bwd_coeffs(tot[0][cx], tot[2][cx], a.count, a.g2[c], a.mean2[c], a.is2[c], a.dg2, a.db2, a.cA2, a.cB2, a.cC2, c);
@@ -799,6 +801,17 @@ int mdcv_bn_act_bwd_reduce_finalize(int dtype, const void* dout, int ldd, const 
   f.g1 = gamma1; f.mean1 = mean1; f.is1 = invstd1; f.dg1 = dgamma1; f.db1 = dbeta1; f.cA1 = cA1; f.cB1 = cB1; f.cC1 = cC1;
   f.g2 = gamma2; f.mean2 = mean2; f.is2 = invstd2; f.dg2 = dgamma2; f.db2 = dbeta2; f.cA2 = cA2; f.cB2 = cB2; f.cC2 = cC2;
   hipLaunchKernelGGL(bn_colfinal_kernel<1>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, f);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_bn_bwd_finalize_rows(const float* partial, int rows, int C, double count, const float* gamma, const float* mean,
+                              const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cC, void* stream) {
+  if (!partial || rows < 1 || !gamma || !mean || !invstd || !dgamma || !dbeta || !cA || !cB || !cC) return MDCV_EARG;
+  ColFinArgs f = {};
+  f.partial = partial; f.rows = rows; f.nsums = 2; f.C = C; f.count = count;
+  f.g1 = gamma; f.mean1 = mean; f.is1 = invstd; f.dg1 = dgamma; f.db1 = dbeta; f.cA1 = cA; f.cB1 = cB; f.cC1 = cC;
+  hipLaunchKernelGGL(bn_colfinal_kernel<3>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, f);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

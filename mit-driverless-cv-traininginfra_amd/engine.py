@@ -10,6 +10,8 @@ Gradient routing (fan-out, residual adds, route-concat slices) is resolved at pl
   * the first computed contribution writes the buffer, later ones accumulate through the conv kernel's `addsrc`
     epilogue (out = GEMM + addsrc), so residual/fan-out sums cost no extra pass over HBM.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -113,6 +115,8 @@ class Plan:
         self.low_water = 1 << 62
         self._last_mark = 1 << 62
         self.on_ready = None               # set per backward by the data-parallel reducer
+        self.dgrad_entries = {}            # grad buffer ptr -> backward-list entry of the data gradient that wrote it last
+        self.fused_bn = 0                  # BatchNorm backward reductions folded into data-gradient store loops
 
     # ------------------------------------------------------------------ buffers
     def new_act(self, B, H, W, C, zero=False):
@@ -267,6 +271,11 @@ class Plan:
         self.bwd.append((wgrad, ()))
         if xnode.needs_grad:
             out, add = self.grad_target(xnode)
+            self.dgrad_entries[out.ptr] = dict(
+                idx=len(self.bwd), out=out, used=False,
+                geom=(x.B, dy.H, dy.W, cs.cout_pad, x.H, x.W, cs.cin_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil),
+                head=(dy.ptr, dy.ldc, cs.wd.data_ptr(), out.ptr, out.ldc, add.ptr if add is not None else None,
+                      add.ldc if add is not None else 0))
             self.call(self.bwd, L.conv2d, dt, 1, dy.ptr, dy.ldc, cs.wd.data_ptr(), out.ptr, out.ldc, None,
                       add.ptr if add is not None else None, add.ldc if add is not None else 0, None,
                       x.B, dy.H, dy.W, cs.cout_pad, x.H, x.W, cs.cin_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
@@ -321,13 +330,15 @@ class Plan:
         g2 = b2 = None
         if y2 is not None:
             g2, b2 = self.param_grad(bs2.bn.weight), self.param_grad(bs2.bn.bias)
-        self.call(self.bwd, L.bn_act_bwd_reduce_finalize, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.mean),
-                  n(bs1.invstd), y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
-                  n(bs2.scale) if bs2 else None, n(bs2.shift) if bs2 else None, n(bs2.mean) if bs2 else None,
-                  n(bs2.invstd) if bs2 else None, pws.data_ptr(), y1.M, y1.C, act, float(slope), float(y1.M),
-                  bs1.bn.weight.data_ptr(), g1.data_ptr(), b1.data_ptr(), n(bs1.cA), n(bs1.cB), n(bs1.cC),
-                  bs2.bn.weight.data_ptr() if bs2 else None, n(g2), n(b2), n(bs2.cA) if bs2 else None, n(bs2.cB) if bs2 else None,
-                  n(bs2.cC) if bs2 else None)
+        fused = y2 is None and self._fuse_bn_sums(dout, y1, bs1, act, slope, g1, b1)
+        if not fused:
+            self.call(self.bwd, L.bn_act_bwd_reduce_finalize, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.mean),
+                      n(bs1.invstd), y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
+                      n(bs2.scale) if bs2 else None, n(bs2.shift) if bs2 else None, n(bs2.mean) if bs2 else None,
+                      n(bs2.invstd) if bs2 else None, pws.data_ptr(), y1.M, y1.C, act, float(slope), float(y1.M),
+                      bs1.bn.weight.data_ptr(), g1.data_ptr(), b1.data_ptr(), n(bs1.cA), n(bs1.cB), n(bs1.cC),
+                      bs2.bn.weight.data_ptr() if bs2 else None, n(g2), n(b2), n(bs2.cA) if bs2 else None, n(bs2.cB) if bs2 else None,
+                      n(bs2.cC) if bs2 else None)
         self.call(self.bwd, L.bn_act_bwd_apply, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.cA),
                   n(bs1.cB), n(bs1.cC), dy1.ptr, dy1.ldc,
                   y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
@@ -335,6 +346,46 @@ class Plan:
                   n(bs2.cB) if bs2 else None, n(bs2.cC) if bs2 else None,
                   dy2.ptr if dy2 is not None else None, dy2.ldc if dy2 is not None else 0, y1.M, y1.C, act, float(slope))
         return (dy1, dy2) if y2 is not None else dy1
+
+    # Opt-in (MDCV_BN_FUSE=1).  Measured on YOLOv3 416^2 B=32: the stand-alone reduce kernels it removes cost 0.95 ms per step, but
+    # the fused store loop adds 1.1 ms to the 66 data gradients (the y loads are HBM misses whose latency is exposed once per
+    # 128-row group at the end of each tile), so the default stays the two-pass form.
+    fuse_bn = os.environ.get("MDCV_BN_FUSE", "0") == "1"
+
+    def _fuse_bn_sums(self, dout, y, bs, act, slope, dgamma, dbeta):
+        """Fold the BatchNorm-backward reduction over (dout, y) into the store loop of the data gradient that wrote `dout`.
+
+        Legal when that launch is the LAST writer of the buffer (nothing between it and this point of the backward list mentions
+        the pointer), it wrote exactly this tensor, and the library has a fused path for its geometry.  The earlier list entry is
+        rewritten in place; what remains here is the column-owner finalize."""
+        if not self.fuse_bn:
+            return False
+        e = self.dgrad_entries.get(dout.ptr)
+        if e is None or e["used"]:
+            return False
+        o = e["out"]
+        if (o.M, o.C, o.ldc) != (dout.M, dout.C, dout.ldc) or (y.M, y.C) != (dout.M, dout.C):
+            return False
+        for fn, args in self.bwd[e["idx"] + 1:]:
+            if dout.ptr in args:
+                return False
+        L, dt = self.L, self.dtype
+        rows = int(L.conv2d_dgrad_bnsums_rows(dt, *e["geom"], e["head"][1]))
+        if rows <= 0 or rows > 4096:
+            return False
+        fn0, _ = self.bwd[e["idx"]]
+        assert fn0 is L.conv2d
+        partial = self.f32(rows * 2 * y.C, zero=False)
+        h = e["head"]
+        self.bwd[e["idx"]] = (L.conv2d_dgrad_bnsums, (dt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], *e["geom"], y.ptr, y.ldc,
+                                                       bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope),
+                                                       partial.data_ptr()))
+        e["used"] = True
+        self.call(self.bwd, L.bn_bwd_finalize_rows, partial.data_ptr(), rows, y.C, float(y.M), bs.bn.weight.data_ptr(),
+                  bs.mean.data_ptr(), bs.invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bs.cA.data_ptr(), bs.cB.data_ptr(),
+                  bs.cC.data_ptr())
+        self.fused_bn += 1
+        return True
 
     def finish_pack(self, position=0):
         import struct

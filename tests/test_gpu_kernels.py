@@ -442,3 +442,69 @@ def test_maxpool2x2(dt, stride, H, W):
     din = torch.empty(B, H, W, C, dtype=TD[dt], device="cuda")
     L.check(L.maxpool2x2_bwd(dt, db.data_ptr(), C, idx.data_ptr(), din.data_ptr(), C, B, H, W, C, stride, st()))
     np.testing.assert_allclose(to_nchw(din, dt, C).numpy(), xr.grad.numpy(), rtol=1e-6 if dt == F32 else 1e-2, atol=1e-6 if dt == F32 else 2e-2)
+
+
+FUSE_CASES = [
+    # B, Cin(conv input = channels of the BatchNorm), H, W, Cout, k, stride, pad
+    (2, 64, 26, 20, 128, 3, 1, 1),      # shift kernel, 256-row tiles
+    (5, 128, 13, 13, 256, 3, 1, 1),     # shift kernel, 128-row tiles, images straddling tiles
+    (2, 256, 14, 14, 128, 1, 1, 0),     # 1x1, 128x128 tiles
+    (2, 64, 17, 19, 128, 3, 2, 1),      # stride-2 data gradient: four parity-class launches
+    (3, 32, 20, 20, 48, 3, 1, 1),       # narrow conv input: 128x32 tile
+    (2, 16, 24, 24, 32, 3, 1, 2),       # dilated (pad 2, dil 2 below), 128x16 tile
+    (2, 64, 15, 17, 72, 3, 1, 1),       # K (= Cout_pad 72) not a multiple of 32: generic address path
+]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", FUSE_CASES, ids=[str(c) for c in FUSE_CASES])
+@pytest.mark.parametrize("act,with_add", [(1, True), (0, False), (2, True)])
+def test_dgrad_with_fused_bn_sums(case, dt, act, with_add):
+    """mdcv_conv2d_dgrad_bnsums == mdcv_conv2d(mode 1) + mdcv_bn_act_bwd_reduce + mdcv_bn_bwd_finalize (same dz, same vectors)."""
+    L = _lib.lib()
+    B, Ci, H, W, Co, k, s, p = case
+    d = 2 if (k == 3 and p == 2) else 1
+    g = torch.Generator().manual_seed(Ci * 7 + Co + act)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1
+    Wo = (W + 2 * p - d * (k - 1) - 1) // s + 1
+    cip, cop = pad8(Ci), pad8(Co)
+    wf, wd = pack(dt, w)
+    dyb = to_nhwc(torch.randn(B, Co, Ho, Wo, generator=g), dt)
+    addb = to_nhwc(torch.randn(B, Ci, H, W, generator=g), dt) if with_add else None
+    yb = to_nhwc(torch.randn(B, Ci, H, W, generator=g) * 1.3 + 0.2, dt)          # raw conv output of the producer layer
+    M = B * H * W
+    scale = (torch.rand(cip, generator=g) + 0.5).cuda(); shift = (torch.randn(cip, generator=g) * 0.3).cuda()
+    mean = (torch.randn(cip, generator=g) * 0.2 + 0.2).cuda(); invstd = (torch.rand(cip, generator=g) + 0.5).cuda()
+    gamma = (torch.rand(cip, generator=g) + 0.5).cuda()
+    slope = 0.1
+    rows = L.conv2d_dgrad_bnsums_rows(dt, B, Ho, Wo, cop, H, W, cip, k, k, s, p, d, cop)
+    assert rows > 0
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    # reference path
+    dx0 = torch.empty(B, H, W, cip, dtype=TD[dt], device="cuda")
+    L.check(L.conv2d(dt, 1, dyb.data_ptr(), cop, wd.data_ptr(), dx0.data_ptr(), cip, None, P(addb), cip, None,
+                     B, Ho, Wo, cop, H, W, cip, k, k, s, p, d, st()), "dgrad")
+    acc = torch.zeros(3 * cip, dtype=torch.float64, device="cuda")
+    pws = torch.empty(L.bn_act_bwd_reduce_ws_floats(dt, M, cip, 2), device="cuda")
+    L.check(L.bn_act_bwd_reduce(dt, dx0.data_ptr(), cip, yb.data_ptr(), cip, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                invstd.data_ptr(), None, 0, None, None, None, None, acc.data_ptr(), pws.data_ptr(), M, cip, act, slope, st()))
+    ref = [torch.zeros(cip, device="cuda") for _ in range(5)]
+    L.check(L.bn_bwd_finalize(acc.data_ptr(), 1, 2, 1, float(M), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                              *[b.data_ptr() for b in ref], cip, st()))
+    # fused path
+    dx1 = torch.empty(B, H, W, cip, dtype=TD[dt], device="cuda")
+    part = torch.full((rows, 2, cip), float("nan"), device="cuda")
+    L.check(L.conv2d_dgrad_bnsums(dt, dyb.data_ptr(), cop, wd.data_ptr(), dx1.data_ptr(), cip, P(addb), cip, B, Ho, Wo, cop, H, W, cip,
+                                  k, k, s, p, d, yb.data_ptr(), cip, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), act, slope,
+                                  part.data_ptr(), st()), "fused dgrad")
+    got = [torch.zeros(cip, device="cuda") for _ in range(5)]
+    L.check(L.bn_bwd_finalize_rows(part.data_ptr(), rows, cip, float(M), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                   *[b.data_ptr() for b in got], st()))
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)                                   # same kernel arithmetic, same stored gradient
+    assert not bool(torch.isnan(part[:, :, :Ci]).any())            # every row the query promised was written
+    for a, b, name in zip(got, ref, ("dgamma", "dbeta", "cA", "cB", "cC")):
+        an, bn_ = a.cpu().numpy()[:Ci], b.cpu().numpy()[:Ci]
+        scale_ = max(1.0, float(np.abs(bn_).max()))
+        np.testing.assert_allclose(an, bn_, rtol=2e-4, atol=2e-4 * scale_, err_msg=name)

@@ -553,3 +553,23 @@ def test_hipgraph_replay_matches_eager():
         res[graph] = (torch.stack([o.detach() for o in out]).cpu(), net.flat_parameters()[1].clone().cpu())
     assert torch.equal(res[False][0], res[True][0])
     assert relerr(res[True][1], res[False][1]) < 1e-6
+
+
+def test_mini_darknet_with_fused_bn_backward_sums(monkeypatch):
+    """MDCV_BN_FUSE=1 (BatchNorm-backward sums folded into the data-gradient store loops) gives the same losses / gradients."""
+    from mdcv import engine
+    z = load("mini_darknet.npz")
+    outs = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(engine.Plan, "fuse_bn", fuse)
+        net = make_mini("fp32")
+        net.train()
+        x, tg = T(z["x"]).cuda(), T(z["targets"]).cuda()
+        out = net(x, tg)
+        out[0].sum().backward()
+        plan = [p for p in net._plans.values() if p.has_bwd][0]
+        outs[fuse] = (float(out[0]), net.flat_parameters()[1].clone(), plan.fused_bn)
+    assert outs[True][2] > 0 and outs[False][2] == 0
+    assert abs(outs[True][0] - outs[False][0]) <= 1e-6 * abs(outs[False][0])
+    g0, g1 = outs[False][1], outs[True][1]
+    assert float((g0 - g1).abs().max()) <= 2e-4 * float(g0.abs().max())
