@@ -179,6 +179,13 @@ int mdcv_average_precision(const unsigned char* tp, const float* conf, int m, in
 int mdcv_crop_resize(const float* frames, int B, int C, int H, int W, const float* boxes, const int* count, int K, float scale_x,
                      float scale_y, float off_x, float off_y, int out_h, int out_w, float* out, int* owner, int* total, void* stream);
 
+/* ---- on-device synthetic cone data with the output contracts of the reference's datasets; every value is a pure
+ *      function of (seed, step, index), reproduced bit for bit by oracle/synth_oracle.py.
+ *      detector batch (CVC-YOLOv3/utils/datasets.py:124-315): images [B,3,H,W] in [0,1], targets [B,T,5] (cls,cx,cy,w,h), zero rows last.
+ *      crop batch (RektNet/dataset.py:34-56, RektNet/utils.py:83-111): images [B,3,80,80], heat-maps [B,7,80,80], points [B,7,2]. */
+int mdcv_synth_cone_batch(unsigned int seed, int step, int B, int T, int H, int W, int num_classes, float* images, float* targets, void* stream);
+int mdcv_synth_crop_batch(unsigned int seed, int step, int B, int size, float* images, float* heatmaps, float* points, void* stream);
+
 /* ---- optimizer step over the flat fp32 parameter buffer (train.py:180-187,72 ; train_eval.py:263,72) */
 int mdcv_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, void* stream);

@@ -1,0 +1,83 @@
+"""GPU parity for the on-device synthetic cone data: HIP generator vs oracle/synth_oracle.py, bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import synth_oracle as SO  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,T,H,W,C,seed,index", [(3, 6, 64, 96, 1, 7, 0), (2, 16, 416, 416, 80, 123, 5), (4, 1, 33, 21, 3, 0, 2)])
+def test_cone_batches_bit_exact_and_contract(B, T, H, W, C, seed, index):
+    from mdcv.data import SyntheticCones
+    ds = SyntheticCones(B, H, W, num_targets_per_image=T, num_classes=C, batches=8, seed=seed)
+    uris, imgs, tg = ds.batch(index)
+    ref_t = SO.cone_targets(seed, index, B, T, C)
+    np.testing.assert_array_equal(tg.cpu().numpy(), ref_t)
+    np.testing.assert_array_equal(imgs.cpu().numpy(), SO.cone_images(seed, index, ref_t, H, W))
+    # contract of ImageLabelDataset batches: shapes, ranges, real rows first then zero rows, boxes inside the image
+    assert imgs.shape == (B, 3, H, W) and tg.shape == (B, T, 5) and len(uris) == B and len(ds) == 8
+    assert float(imgs.min()) >= 0.0 and float(imgs.max()) <= 1.0
+    t = tg.cpu().numpy()
+    for b in range(B):
+        real = (t[b, :, 3] > 0)
+        n = int(real.sum())
+        assert n >= 1 and real[:n].all() and not real[n:].any() and np.all(t[b, n:] == 0)
+        assert np.all(t[b, :n, 1] - t[b, :n, 3] / 2 >= -1e-6) and np.all(t[b, :n, 1] + t[b, :n, 3] / 2 <= 1 + 1e-6)
+        assert np.all(t[b, :n, 0] >= 0) and np.all(t[b, :n, 0] < C)
+    # a different batch index / rank gives different data; the same index reproduces
+    _, i2, _ = ds.batch(index + 1)
+    assert not torch.equal(i2, imgs)
+    assert torch.equal(ds.batch(index)[1], imgs)
+    assert not torch.equal(SyntheticCones(B, H, W, T, C, 8, seed, rank=1, world_size=2).batch(index)[1], imgs)
+
+
+@pytest.mark.parametrize("B,seed,index", [(5, 3, 0), (16, 99, 4)])
+def test_crop_batches_bit_exact_and_contract(B, seed, index):
+    from mdcv.data import SyntheticConeCrops
+    ds = SyntheticConeCrops(B, batches=4, seed=seed)
+    imgs, hm, pts, names, sizes = ds.batch(index)
+    ri, rh, rp = SO.cone_crops(seed, index, B)
+    np.testing.assert_array_equal(imgs.cpu().numpy(), ri)
+    np.testing.assert_array_equal(pts.cpu().numpy(), rp)
+    np.testing.assert_array_equal(hm.cpu().numpy(), rh)
+    assert imgs.shape == (B, 3, 80, 80) and hm.shape == (B, 7, 80, 80) and pts.shape == (B, 7, 2) and len(names) == B
+    s = hm.sum((2, 3)).cpu().numpy()
+    np.testing.assert_allclose(s, 1.0, atol=1e-5)                       # prep_label normalises every heat-map
+    # the heat-map peak sits at the (scaled) key point, within the blur radius
+    peak = hm.flatten(2).argmax(2).cpu().numpy()
+    py, px = peak // 80, peak % 80
+    p = pts.cpu().numpy() * 80
+    assert np.all(np.abs(px - p[..., 0]) <= 4) and np.all(np.abs(py - p[..., 1]) <= 4)
+    with pytest.raises(ValueError):
+        SyntheticConeCrops(4, size=64)
+
+
+def test_training_steps_on_generated_batches():
+    """The generated batches drive the two training steps (loss finite, decreasing over a few Adam steps on one batch)."""
+    from mdcv.data import SyntheticCones, SyntheticConeCrops
+    from mdcv.rektnet.keypoint_net import KeypointNet
+    from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+    from mdcv.optim import FusedAdam
+    torch.manual_seed(0)
+    kp = KeypointNet(7, (80, 80), precision="bf16").cuda().train()
+    crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
+    opt = FusedAdam(kp, lr=1e-2)
+    imgs, hm_t, pts_t, _, _ = SyntheticConeCrops(32, batches=1, seed=1).batch(0)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        hm, pts = kp(imgs)
+        loss = crit(hm, pts, hm_t, pts_t)[2]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    _, x, tg = SyntheticCones(2, 96, 96, 8, 1, 1, 5).batch(0)
+    assert x.is_cuda and tg.is_cuda and float(tg[:, 0, 3].min()) > 0

@@ -283,3 +283,36 @@ def test_crop_bounds_and_order():
     crops, owner = PL.crop_resize(frames, boxes, [2, 1], 16, 8)
     assert crops.shape == (3, 3, 16, 8) and owner.tolist() == [0, 0, 1]
     np.testing.assert_array_equal(crops[2], PL.resize_bilinear(frames[1, :, 5:25, 5:25], 16, 8))
+
+
+# ---------------------------------------------------------------------------
+# synthetic cone data — oracle/synth_oracle.py: contracts and the cv2 heat-map restatement
+from oracle import synth_oracle as SO
+
+
+def test_synth_oracle_contracts():
+    t = SO.cone_targets(5, 2, 4, 9, 3)
+    assert t.shape == (4, 9, 5) and t.dtype == np.float32
+    for b in range(4):
+        n = int((t[b, :, 3] > 0).sum())
+        assert 1 <= n <= 9 and np.all(t[b, n:] == 0) and np.all(t[b, :n, 3:] > 0)
+    img = SO.cone_images(5, 2, t, 48, 64)
+    assert img.shape == (4, 3, 48, 64) and 0.0 <= img.min() and img.max() <= 1.0
+    i2, hm, pts = SO.cone_crops(5, 2, 3)
+    assert i2.shape == (3, 3, 80, 80) and hm.shape == (3, 7, 80, 80) and pts.shape == (3, 7, 2)
+    np.testing.assert_allclose(hm.sum((2, 3)), 1.0, atol=1e-5)
+    assert 0.0 <= pts.min() and pts.max() <= 1.0
+
+
+def test_synth_oracle_heatmap_matches_dense_resize_and_blur():
+    """The separable closed form == resizing the dense one-hot image (pipeline oracle's bilinear) and blurring it densely."""
+    oh, ow, iy, ix = 37, 52, 20, 31
+    dense = np.zeros((1, oh, ow), np.float32)
+    dense[0, iy, ix] = 1.0
+    r = PL.resize_bilinear(dense, 80, 80)[0].astype(np.float64)
+    k = SO.GAUSS5
+    pad = np.pad(r, 2, mode="reflect")                                  # numpy "reflect" == BORDER_REFLECT_101
+    blur = sum(k[a] * k[b] * pad[a:a + 80, b:b + 80] for a in range(5) for b in range(5))
+    vy = SO._blur_reflect101(SO._resize_onehot_axis(iy, oh, 80))
+    vx = SO._blur_reflect101(SO._resize_onehot_axis(ix, ow, 80))
+    np.testing.assert_allclose(np.outer(vy, vx), blur, atol=1e-7)
