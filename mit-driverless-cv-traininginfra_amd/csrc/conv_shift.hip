@@ -184,10 +184,16 @@ __global__ __launch_bounds__(NW * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a
             if (lastc) ISSUE_A(rin0, c + 1, (cc + 1) & 1);
             else ISSUE_A(rin, c + 1, (cc + 1) & 1);
           }
+#ifdef MDCV_SHIFT_PRIO
+          __builtin_amdgcn_s_setprio(MDCV_SHIFT_PRIO);
+#endif
 #pragma unroll
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#ifdef MDCV_SHIFT_PRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
           STS(3);
 #ifdef MDCV_SHIFT_TS
           ++ts_i;
@@ -385,8 +391,8 @@ int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st,
 
 // Tile plan (measured, scripts/conv_ab.py + scripts/shift_wg.py): 256-row tiles run two workgroups per CU; a tile that has a
 // CU to itself takes ~0.8x the time of one that shares it, so a short extra round costs less than splitting the remainder
-// into 128-row tiles (their weight fill per MAC doubles).  Only grids that would leave CUs idle (<= 256 tiles) switch to
-// 128-row tiles.  Plan 3 (tuning) runs full rounds as 256-row tiles and a remainder of at most half a round as 128-row tiles.
+// into 128-row tiles (their weight fill per MAC doubles).  Only grids that would leave half the CUs idle (<= 128 tiles) switch
+// to 128-row tiles.  Plan 3 (tuning) runs full rounds as 256-row tiles and a remainder of at most half a round as 128-row tiles.
 template <int MODE>
 int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   const int SLOTS = 512;
@@ -395,7 +401,7 @@ int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, uns
   int nbig_m;
   if (g_shift_plan == 1) nbig_m = big_m;                                   // tuning: 256-row tiles only
   else if (g_shift_plan == 2) nbig_m = 0;                                  //         128-row tiles only
-  else if (t_big <= SLOTS / 2) nbig_m = 0;
+  else if (t_big <= SLOTS / 4) nbig_m = 0;          // (measured: 184- and 200-tile grids are still faster as 256-row tiles)
   else if (g_shift_plan == 3) {
     const int full = t_big / SLOTS * SLOTS, rem = t_big - full;
     nbig_m = (rem > 0 && rem <= SLOTS / 2) ? full / a.tiles_n : big_m;
