@@ -64,6 +64,11 @@ class _Lib:
             fn.restype = ret
             fn.argtypes = argt
             setattr(self, name[len("mdcv_"):], fn)
+        for v in os.environ.get("MDCV_CONV_VARIANT", "").split(","):      # tuning hook for in-network A/B runs (see conv2d_set_variant)
+            if v.strip():
+                self.cdll.mdcv_conv2d_set_variant(int(v))
+        if os.environ.get("MDCV_WGRAD_VARIANT", "").strip():
+            self.cdll.mdcv_conv2d_wgrad_set_variant(int(os.environ["MDCV_WGRAD_VARIANT"]))
 
     def check(self, rc, what=""):
         if rc != 0:
