@@ -1640,7 +1640,7 @@ int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, i
 // tuning hook: force the tile configuration of wide (Nout > 64) layers; -1 restores the heuristic
 int mdcv_conv2d_wgrad_set_variant(int v) { g_wgrad_variant = v; return MDCV_OK; }   /* tuning hook */
 int mdcv_conv2d_set_variant(int v) {
-  if (v <= -3 && v >= -10) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed
+  if (v <= -3 && v >= -12) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11/-12 always/never 16 waves
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
   g_conv_variant = v == 99 ? -1 : v;
   return MDCV_OK;

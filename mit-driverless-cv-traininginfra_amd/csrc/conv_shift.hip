@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int BN = 128, WM = 4, WN = 2, NW = 8, TN = 64, FN = 4;     // 8 waves: 4 (M) x 2 (N); wave tile (BM/4) x 64
+constexpr int BN = 128, WM = 4;     // waves: 4 (M) x WN (N), WN = 2 (8 waves, wave tile (BM/4) x 64) or 4 (16 waves, (BM/4) x 32)
 constexpr int BTILE = BN * 64;                            // one weight tile of the ring: 8 KiB
 constexpr unsigned OOB = 0x80000000u;
 constexpr int SROW = BN * 2 + 16;                          // epilogue staging pitch (bf16)
@@ -44,15 +44,17 @@ __device__ long long g_shift_ts[4 * 512];
 #endif
 
 int g_shift_ring = 3;
-int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row tiles only ; 3: mixed rounds (tuning hook)   // weight-ring depth (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
+int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row only ; 3: mixed rounds ; 4 / 5: always / never 16 waves (tuning)   // weight-ring depth (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 }  // namespace
 
-template <int MODE, int BM, int NPA, int BRING, bool FUSE>
-__global__ __launch_bounds__(NW * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a, unsigned in_bytes, unsigned w_bytes) {
+template <int MODE, int BM, int NPA, int BRING, bool FUSE, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a, unsigned in_bytes, unsigned w_bytes) {
+  constexpr int NW = WM * WN, TN = BN / WN, FN = TN / 16;
   constexpr int TM = BM / WM, FM = TM / 16;
+  static_assert(!FUSE || WN == 2, "the fused-sum scratch is sized for 8 waves");
   // LDS: [A0: nca KiB][A1: nca KiB][weight ring: BRING x 8 KiB][1 KiB sink for the surplus chunk DMAs]; the epilogue reuses it
   // as [bf16 staging BM x SROW][rowpix BM ints][statistics WM*2*BN floats].
   constexpr int STAGE = BM * SROW;
@@ -87,10 +89,10 @@ __global__ __launch_bounds__(NW * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a
     ok = ok && yy < a.H && xx < a.W;
     avo[k] = ok ? (unsigned)((((img * a.H + yy) * a.W + xx) * a.in_ldc + kv * 8) * 2) : OOB;
   }
-  unsigned bvo;
+  unsigned bvo;                                            // the weight tile is 8 KiB-chunks: waves 8..15 (16-wave variant) fill the sink
   {
     const int n = tile_n * BN + wave * 16 + lrow;
-    bvo = n < a.Nout ? (unsigned)((n * a.wrow + kv * 8) * 2) : OOB;
+    bvo = (wave < 8 && n < a.Nout) ? (unsigned)((n * a.wrow + kv * 8) * 2) : OOB;
   }
   // ---- per-tap fragment offsets (activation rows shifted by the tap displacement)
   const int r = lane & 15, q = lane >> 4;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(NW * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a
     }                                                                                                               \
   } while (0)
 #define ISSUE_B(RS, TAP, CHUNK, SLOT)                                                                               \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + BBASE + (SLOT) * BTILE + wave * 1024), 16, (int)bvo, \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + (wave < 8 ? BBASE + (SLOT) * BTILE + wave * 1024 : SINK)), 16, (int)bvo, \
                                            ((TAP) * a.Cin + (CHUNK) * 32) * 2, 0, 0)
 
   f32x4_t acc[FM][FN];
@@ -350,9 +352,9 @@ __global__ __launch_bounds__(NW * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a
 
 namespace {
 
-template <int MODE, int BM, int NPA, bool FUSE>
+template <int MODE, int BM, int NPA, bool FUSE, int WN>
 int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
-  constexpr int BRING = 3;
+  constexpr int BRING = 3, NW = WM * WN;
   a.p_base = p_base;
   a.tiles_total = tiles_m * a.tiles_n;
   a.xcd_chunk = (a.tiles_total + 7) / 8;
@@ -361,7 +363,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics / fused-sum scratch (NW*BN floats)
   const int lds = pipe > epi ? pipe : epi;
   static int attr_lds = 0;
-  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE>;
+  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE, WN>;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
@@ -372,21 +374,31 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   return MDCV_OK;
 }
 
-template <int MODE, int BM, int NPA>
+template <int MODE, int BM, int NPA, int WN>
 int launch_shift(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
-  if constexpr (MODE == 1) {                    // the fused BatchNorm-backward sums exist for data gradients only
-    if (a.fuse.y) return launch_shift_f<MODE, BM, NPA, true>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  if constexpr (MODE == 1 && WN == 2) {         // the fused BatchNorm-backward sums exist for 8-wave data gradients only
+    if (a.fuse.y) return launch_shift_f<MODE, BM, NPA, true, WN>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
-  return launch_shift_f<MODE, BM, NPA, false>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  return launch_shift_f<MODE, BM, NPA, false, WN>(a, p_base, tiles_m, st, in_bytes, w_bytes);
 }
 
+// 16-wave workgroups (4 x 4 waves of (BM/4) x 32) were tried for grids that put at most one workgroup on a CU (idea: 4 waves per
+// SIMD from one workgroup hide the K-step latencies like two co-resident 8-wave workgroups).  Measured slower everywhere
+// (26x26 dgrad 54.4 vs 50.4 us, 13x13 forward 56.1 vs 52.2 us: the 16-wave barrier and the extra fragment reads cost more than
+// the latency hiding gains), so the variant is only reachable through the tuning hook (plan 4).
 template <int MODE, int BM>
 int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   const int nca = (BM + 2 * a.Wq + 2 + 15) / 16;
-  const int npa = (nca + NW - 1) / NW;
-  if (npa <= 2) return launch_shift<MODE, BM, 2>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-  if (npa == 3) return launch_shift<MODE, BM, 3>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-  return launch_shift<MODE, BM, 4>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  const bool wide = g_shift_plan == 4 && !a.fuse.y;
+  if (wide) {
+    const int npa = (nca + 15) / 16;
+    if (npa <= 1) return launch_shift<MODE, BM, 1, 4>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+    return launch_shift<MODE, BM, 2, 4>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  }
+  const int npa = (nca + 7) / 8;
+  if (npa <= 2) return launch_shift<MODE, BM, 2, 2>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  if (npa == 3) return launch_shift<MODE, BM, 3, 2>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  return launch_shift<MODE, BM, 4, 2>(a, p_base, tiles_m, st, in_bytes, w_bytes);
 }
 
 // Tile plan (measured, scripts/conv_ab.py + scripts/shift_wg.py): 256-row tiles run two workgroups per CU; a tile that has a
@@ -455,9 +467,9 @@ extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
 #if defined(MDCV_SHIFT_TS) || defined(MDCV_SHIFT_WG)
 extern "C" int mdcv_debug_shift_occ(int lds) {
   int nb = -1;
-  auto kern = mdcv_conv3x3_shift_kernel<0, 256, 3, 3, false>;
+  auto kern = mdcv_conv3x3_shift_kernel<0, 256, 3, 3, false, 2>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NW * 64, (size_t)lds);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 512, (size_t)lds);
   hipFuncAttributes fa; hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
   printf("occupancy(lds=%d) = %d blocks/CU (err %d); numRegs %d sharedSizeBytes %zu maxThreadsPerBlock %d\n", lds, nb, (int)e, fa.numRegs,
          (size_t)fa.sharedSizeBytes, fa.maxThreadsPerBlock);

@@ -27,3 +27,10 @@ med = statistics.median
 print("steps", n, "| step %.0f | wait %.0f  barrier %.0f  body %.0f  loop %.0f (medians)" % (med(step), med(wait), med(bar), med(body), med(loop)))
 print("means: step %.0f wait %.0f barrier %.0f body %.0f" % (sum(step) / len(step), sum(wait) / n, sum(bar) / n, sum(body) / n))
 print("first 12 steps (wait, barrier, body):", [(wait[i], bar[i], body[i]) for i in range(12)])
+# effective shader clock of the instrumented wave: s_memtime ticks per wall-clock (100 MHz) tick over the K loop of its tile
+buf2 = (ctypes.c_longlong * (3 * 4096))()
+f2 = L.cdll.mdcv_debug_shift_wg; f2.argtypes = [ctypes.c_void_p]
+assert f2(buf2) == 0
+wall = (buf2[4096 + 300] - buf2[300]) / 100.0        # us, whole tile 300
+cyc = t[3][n - 1] - t[0][0]
+print("tile 300: wall %.2f us, K-loop %d cycles -> if the loop were the whole tile: %.0f MHz (lower bound of the shader clock)" % (wall, cyc, cyc / wall))
