@@ -1573,7 +1573,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
     return rc;
   }
   if (shift_ok && stats_partial) {   // forced generic kernel on a shift-eligible geometry (A/B runs): the caller sized the partial
-    const int r0 = cdiv(a.M, 128), r1 = mdcv_shift_stats_rows(B, Hout, Wout);   // rows for the shift kernel; zero the unused tail
+    const int r0 = cdiv(a.M, 128), r1 = mdcv_shift_fwd_stats_rows(B, Hout, Wout, Nout);   // rows for the shift kernel; zero the unused tail
     if (r1 > r0) {
       hipError_t e = hipMemsetAsync(stats_partial + (size_t)r0 * 2 * Nout, 0, (size_t)(r1 - r0) * 2 * Nout * sizeof(float), st);
       if (e != hipSuccess) return (int)e;
@@ -1633,14 +1633,14 @@ int mdcv_conv2d_stats_rows(int M) { return cdiv(M, 128); }
 // rows for a given forward geometry: the 3x3 stride-1 shift kernel walks a padded position stream and writes more rows
 int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil,
                                 int in_ldc) {
-  if (mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc)) return mdcv_shift_stats_rows(B, Hout, Wout);
+  if (mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc)) return mdcv_shift_fwd_stats_rows(B, Hout, Wout, Nout);
   return cdiv(B * Hout * Wout, 128);
 }
 
 // tuning hook: force the tile configuration of wide (Nout > 64) layers; -1 restores the heuristic
 int mdcv_conv2d_wgrad_set_variant(int v) { g_wgrad_variant = v; return MDCV_OK; }   /* tuning hook */
 int mdcv_conv2d_set_variant(int v) {
-  if (v <= -3 && v >= -12) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11/-12 always/never 16 waves
+  if (v <= -3 && v >= -13) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11 16-wave workgroups, -12 192-row tiles where they save a round
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
   g_conv_variant = v == 99 ? -1 : v;
   return MDCV_OK;

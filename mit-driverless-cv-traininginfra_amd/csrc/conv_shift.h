@@ -15,7 +15,8 @@ struct ShiftArgs {
 };
 
 bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc);
-int mdcv_shift_stats_rows(int B, int H, int W);
+int mdcv_shift_stats_rows(int B, int H, int W);                 // partial rows of the fused data-gradient sums (one per 128 positions)
+int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout);  // partial rows of the forward statistics (depends on the tile plan)
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
                     int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st);
 void mdcv_shift_set_ring(int ring);

@@ -44,7 +44,7 @@ __device__ long long g_shift_ts[4 * 512];
 #endif
 
 int g_shift_ring = 3;
-int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row only ; 3: mixed rounds ; 4 / 5: always / never 16 waves (tuning)   // weight-ring depth (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
+int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row only ; 3: mixed rounds ; 4: 16 waves ; 5: 192-row tiles (tuning)   // weight-ring depth (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -54,7 +54,7 @@ template <int MODE, int BM, int NPA, int BRING, bool FUSE, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a, unsigned in_bytes, unsigned w_bytes) {
   constexpr int NW = WM * WN, TN = BN / WN, FN = TN / 16;
   constexpr int TM = BM / WM, FM = TM / 16;
-  static_assert(!FUSE || WN == 2, "the fused-sum scratch is sized for 8 waves");
+  static_assert(!FUSE || (WN == 2 && BM % 128 == 0), "the fused sums: 8 waves, one partial row per 128 positions");
   // LDS: [A0: nca KiB][A1: nca KiB][weight ring: BRING x 8 KiB][1 KiB sink for the surplus chunk DMAs]; the epilogue reuses it
   // as [bf16 staging BM x SROW][rowpix BM ints][statistics WM*2*BN floats].
   constexpr int STAGE = BM * SROW;
@@ -268,15 +268,16 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
         reinterpret_cast<bf16_t*>(smem + (row + 1) * SROW)[col] = (bf16_t)(pk >> 16);
       }
   __syncthreads();
-  constexpr int G = BM / 128, WPG = WM / G;                // groups of 128 stream positions per tile; waves (in M) per group
-  if (a.stats && tid < BN * G) {                           // one partial-statistics row per 128 stream positions
+  constexpr int GR = BM % 128 == 0 ? 128 : BM;             // stream positions per partial-statistics row (192-row tiles: one row per tile)
+  constexpr int G = BM / GR, WPG = WM / G;                 // rows per tile; waves (in M) per row
+  if (a.stats && tid < BN * G) {
     const int g = tid / BN, col = tid - g * BN;
     const int n = tile_n * BN + col;
     if (n < a.Nout) {
       float s = 0.f, qq = 0.f;
 #pragma unroll
       for (int w2 = 0; w2 < WPG; ++w2) { s += sstat[((g * WPG + w2) * 2 + 0) * BN + col]; qq += sstat[((g * WPG + w2) * 2 + 1) * BN + col]; }
-      const size_t srow = (size_t)(p0 >> 7) + g;
+      const size_t srow = (size_t)(p0 / GR) + g;
       a.stats[(srow * 2 + 0) * a.Nout + n] = s;
       a.stats[(srow * 2 + 1) * a.Nout + n] = qq;
     }
@@ -376,7 +377,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
 
 template <int MODE, int BM, int NPA, int WN>
 int launch_shift(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
-  if constexpr (MODE == 1 && WN == 2) {         // the fused BatchNorm-backward sums exist for 8-wave data gradients only
+  if constexpr (MODE == 1 && WN == 2 && BM % 128 == 0) {   // the fused BatchNorm-backward sums exist for 8-wave data gradients only
     if (a.fuse.y) return launch_shift_f<MODE, BM, NPA, true, WN>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
   return launch_shift_f<MODE, BM, NPA, false, WN>(a, p_base, tiles_m, st, in_bytes, w_bytes);
@@ -401,23 +402,35 @@ int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st,
   return launch_shift<MODE, BM, 4, 2>(a, p_base, tiles_m, st, in_bytes, w_bytes);
 }
 
-// Tile plan (measured, scripts/conv_ab.py + scripts/shift_wg.py): 256-row tiles run two workgroups per CU; a tile that has a
-// CU to itself takes ~0.8x the time of one that shares it, so a short extra round costs less than splitting the remainder
-// into 128-row tiles (their weight fill per MAC doubles).  Only grids that would leave half the CUs idle (<= 128 tiles) switch
-// to 128-row tiles.  Plan 3 (tuning) runs full rounds as 256-row tiles and a remainder of at most half a round as 128-row tiles.
+// Tile plan.  Inside a busy CU the K loop is MFMA-bound whether one or two workgroups share it (a lone workgroup simply runs
+// twice as fast), so an isolated launch takes ceil(tiles / 256) x (time of one tile) and loses the CUs left without a tile in
+// the last round.  192-row tiles (wave tile 48 x 64) cut that loss and are 7-12 % faster in a tight loop on the 52^2 / 26^2
+// layers (scripts/conv_ab.py), but inside the training step the idle CUs are not wasted — the weight-gradient stream fills
+// them — and the 192-row tile's lower MFMA density per barrier makes the step 0.7 % slower, so they are a tuning option (plan 5)
+// and the default is 256-row tiles, 128-row tiles only for grids of at most 128 tiles.
+int shift_plan_bm(int Mq, int tiles_n, bool fused) {
+  if (g_shift_plan == 1) return 256;
+  if (g_shift_plan == 2) return 128;
+  const int t256 = ((Mq + 255) / 256) * tiles_n;
+  if (t256 <= 128) return 128;                       // (measured: 184- and 200-tile grids are still faster as 256-row tiles)
+  if (fused || g_shift_plan != 5) return 256;
+  const int t192 = ((Mq + 191) / 192) * tiles_n;
+  const int c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
+  return c192 < c256 ? 192 : 256;
+}
+
 template <int MODE>
 int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   const int SLOTS = 512;
+  const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr);
+  if (bm == 192) return launch_shift_bm<MODE, 192>(a, 0, (a.Mq + 191) / 192, st, in_bytes, w_bytes);
   const int big_m = (a.Mq + 255) / 256;
   const int t_big = big_m * a.tiles_n;
-  int nbig_m;
-  if (g_shift_plan == 1) nbig_m = big_m;                                   // tuning: 256-row tiles only
-  else if (g_shift_plan == 2) nbig_m = 0;                                  //         128-row tiles only
-  else if (t_big <= SLOTS / 4) nbig_m = 0;          // (measured: 184- and 200-tile grids are still faster as 256-row tiles)
-  else if (g_shift_plan == 3) {
+  int nbig_m = bm == 128 ? 0 : big_m;
+  if (g_shift_plan == 3 && bm == 256) {              // tuning: full rounds as 256-row tiles, a short remainder as 128-row tiles
     const int full = t_big / SLOTS * SLOTS, rem = t_big - full;
     nbig_m = (rem > 0 && rem <= SLOTS / 2) ? full / a.tiles_n : big_m;
-  } else nbig_m = big_m;
+  }
   if (nbig_m > 0) {
     const int rc = launch_shift_bm<MODE, 256>(a, 0, nbig_m, st, in_bytes, w_bytes);
     if (rc) return rc;
@@ -440,6 +453,11 @@ bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int 
 }
 
 int mdcv_shift_stats_rows(int B, int H, int W) { return (int)(((long long)B * (H + 1) * (W + 1) + 127) / 128); }
+// rows of the FORWARD statistics buffer: one per 128 stream positions, or one per tile when the plan picks 192-row tiles
+int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout) {
+  const int Mq = B * (H + 1) * (W + 1);
+  return shift_plan_bm(Mq, Nout / BN, false) == 192 ? (Mq + 191) / 192 : (Mq + 127) / 128;
+}
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
                     int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st) {

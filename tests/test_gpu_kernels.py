@@ -508,3 +508,39 @@ def test_dgrad_with_fused_bn_sums(case, dt, act, with_add):
         an, bn_ = a.cpu().numpy()[:Ci], b.cpu().numpy()[:Ci]
         scale_ = max(1.0, float(np.abs(bn_).max()))
         np.testing.assert_allclose(an, bn_, rtol=2e-4, atol=2e-4 * scale_, err_msg=name)
+
+
+@pytest.mark.parametrize("variant", [-8, -9, -10, -11, -12])
+def test_shift_tile_plans(variant):
+    """Every tuning plan of the 3x3 shift kernel (256 / 128 / mixed rows, 16-wave workgroups, 192-row tiles) gives the forward
+    result and the same BatchNorm statistics as the default plan."""
+    L = _lib.lib()
+    dt = BF16
+    g = torch.Generator().manual_seed(5)
+    outs = {}
+    for v in (-7, variant):
+        L.conv2d_set_variant(v)
+        try:
+            for case in ((4, 64, 26, 26, 256), (32, 128, 13, 13, 128), (9, 32, 30, 17, 128)):
+                B, Ci, H, W, Co = case
+                gg = torch.Generator().manual_seed(B + Ci)
+                x = torch.randn(B, Ci, H, W, generator=gg)
+                w = torch.randn(Co, Ci, 3, 3, generator=gg) / (Ci * 9) ** 0.5
+                xb = to_nhwc(x, dt)
+                wf, wd = pack(dt, w)
+                y = torch.empty(B, H, W, Co, dtype=TD[dt], device="cuda")
+                rows = L.conv2d_stats_rows_geom(dt, B, H, W, Ci, Co, 3, 3, 1, 1, 1, Ci)
+                stats = torch.zeros(rows, 2, Co, device="cuda")
+                L.check(L.conv2d(dt, 0, xb.data_ptr(), Ci, wf.data_ptr(), y.data_ptr(), Co, None, None, 0, stats.data_ptr(),
+                                 B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, st()), "conv")
+                dx = torch.empty(B, H, W, Ci, dtype=TD[dt], device="cuda")
+                dyb = to_nhwc(torch.randn(B, Co, H, W, generator=gg), dt)
+                L.check(L.conv2d(dt, 1, dyb.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, None, None, 0, None,
+                                 B, H, W, Co, H, W, Ci, 3, 3, 1, 1, 1, st()), "dgrad")
+                torch.cuda.synchronize()
+                outs.setdefault(v, []).append((y.clone(), stats.sum(0).clone(), dx.clone()))
+        finally:
+            L.conv2d_set_variant(-7)
+    for (y0, s0, d0), (y1, s1, d1) in zip(outs[-7], outs[variant]):
+        assert torch.equal(y0, y1) and torch.equal(d0, d1)
+        np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=1e-4, atol=1e-2)
