@@ -54,6 +54,10 @@ int mdcv_conv2d_set_variant(int v);   /* tuning hook: force a tile configuration
 /* weight gradient: dW (OIHW fp32, real channel counts) = dY^T * im2col(X).  ws = splits*Cout*KH*KW*Cin floats of scratch. */
 int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot);
 int mdcv_conv2d_wgrad_set_variant(int v);   /* tuning hook: step size / ring depth of the bf16 weight-gradient kernel */
+/* number of fp32 slabs for the kernel mdcv_conv2d_wgrad picks for this geometry (3x3 stride-1 layers with 128-multiple channel
+ * counts run a kernel whose kw taps share one activation tile and that wants its own split); ws = splits*Cout*KH*KW*Cin floats. */
+int mdcv_conv2d_wgrad_splits_geom(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride,
+                                  int pad, int dil, int dy_ldc, int x_ldc);
 int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits,
                       float* dw_oihw, int accumulate, int B, int Hin, int Win, int Cin, int Cin_real,
                       int Hout, int Wout, int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream);

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "conv_shift.h"
 #include "bn_fuse.h"
+#include "wgrad_shift.h"
 
 namespace {
 
@@ -1660,11 +1661,45 @@ int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot) {
   return cdiv(M, pps);
 }
 
+// The kw-shared-tile kernel (wgrad_shift.hip) is used where it measured faster than the generic one on MI355X inside the
+// training step: long pixel runs per block (>= 128 steps of 64 positions, i.e. RektNet's 80x80 layers: 740 -> 680 us).
+// On YOLOv3's 52x52 / 26x26 layers at batch 32 the generic kernel's larger grid wins by 5-10%; on 13x13 512->1024 the new
+// kernel is faster alone (126 -> 116 us) but the step is 0.5% slower with it (one fat block per CU leaves less room for the
+// main stream's kernels that run beside the weight gradients).  Variant 8 forces it wherever eligible, 9 disables it.
+static bool use_wgrad_shift(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride, int pad,
+                            int dil, long long dy_ldc, long long x_ldc) {
+  if (g_wgrad_variant == 9 || Hin != Hout || Win != Wout) return false;
+  if (!mdcv_wgrad_shift_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc)) return false;
+  if (g_wgrad_variant == 8) return true;
+  const long long Mq = (long long)B * (Hout + 1) * (Wout + 1);
+  const int s = mdcv_wgrad_shift_splits(B, Hout, Wout, Cin, Cout);
+  return Mq / (64LL * s) >= 128;
+}
+
+// geometry-aware variant: the kernel mdcv_conv2d_wgrad will pick for this layer decides the split (use this one to size `ws`)
+int mdcv_conv2d_wgrad_splits_geom(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride,
+                                  int pad, int dil, int dy_ldc, int x_ldc) {
+  if (use_wgrad_shift(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc))
+    return mdcv_wgrad_shift_splits(B, Hout, Wout, Cin, Cout);
+  return mdcv_conv2d_wgrad_splits(dtype, B * Hout * Wout, Cout, KH * KW * Cin);
+}
+
 int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits,
                       float* dw_oihw, int accumulate, int B, int Hin, int Win, int Cin, int Cin_real,
                       int Hout, int Wout, int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream) {
   if (!dy || !x || !ws || !dw_oihw) return MDCV_EARG;
   if ((Cin & 7) || (Cout & 7) || (dy_ldc & 7) || (x_ldc & 7) || splits < 1) return MDCV_EARG;
+  // 3x3 / stride 1 / pad 1 with 128-multiple channel counts: the three kw taps of a kernel row share one activation tile
+  const bool shift_w = use_wgrad_shift(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc) &&
+                       mdcv_wgrad_shift_splits_ok(splits, B, Hout, Wout);
+  if (shift_w) {
+    const int rc = mdcv_wgrad_shift(dy, dy_ldc, x, x_ldc, ws, splits, B, Hout, Wout, Cin, Cout, (hipStream_t)stream);
+    if (rc) return rc;
+    const dim3 rg((unsigned)Cout_real, (unsigned)cdiv(Cin_real, 64));
+    hipLaunchKernelGGL(wgrad_reduce_kk_kernel<9>, rg, dim3(256), 0, (hipStream_t)stream, ws, dw_oihw, splits, Cout, Cin_real, Cin, 9 * Cin, accumulate);
+    MDCV_CHECK_LAUNCH();
+    return MDCV_OK;
+  }
   WgradArgs a;
   a.dy = dy; a.x = x; a.ws = ws; a.dy_ldc = dy_ldc; a.x_ldc = x_ldc;
   a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;

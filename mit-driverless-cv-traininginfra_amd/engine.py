@@ -258,7 +258,8 @@ class Plan:
         L, dt = self.L, self.dtype
         x = xnode.act
         gw = self.param_grad(cs.weight)
-        splits = L.conv2d_wgrad_splits(dt, dy.M, cs.cout_pad, cs.ktot)
+        splits = int(L.conv2d_wgrad_splits_geom(dt, x.B, x.H, x.W, cs.cin_pad, dy.H, dy.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad,
+                                                cs.dil, dy.ldc, x.ldc))
         self.ws_floats = max(self.ws_floats, splits * cs.cout_pad * cs.ktot)
         plan = self
 

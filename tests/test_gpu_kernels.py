@@ -544,3 +544,42 @@ def test_shift_tile_plans(variant):
     for (y0, s0, d0), (y1, s1, d1) in zip(outs[-7], outs[variant]):
         assert torch.equal(y0, y1) and torch.equal(d0, d1)
         np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=1e-4, atol=1e-2)
+
+
+WGRAD_SHIFT_CASES = [(2, 128, 13, 13, 128), (3, 128, 26, 20, 256), (1, 256, 52, 52, 128), (5, 128, 9, 8, 128), (32, 128, 13, 13, 256),
+                     (8, 128, 80, 80, 128)]
+
+
+@pytest.mark.parametrize("case", WGRAD_SHIFT_CASES, ids=[str(c) for c in WGRAD_SHIFT_CASES])
+def test_wgrad_shift_kernel(case):
+    """3x3 stride-1 weight gradient with the kw taps sharing one activation tile == torch reference == generic kernel."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, H, W, Co = case
+    g = torch.Generator().manual_seed(Ci + Co + H)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    xr = rnd(dt, x)
+    F.conv2d(xr, w, None, stride=1, padding=1).backward(rnd(dt, dy))
+    ref = w.grad.numpy()
+    xb, dyb = to_nhwc(x, dt), to_nhwc(dy, dt)
+    M, ktot = B * H * W, 9 * Ci
+    outs = {}
+    for variant in (8, 0, 9):                   # 8: kw-shared kernel wherever eligible ; 0: default dispatch ; 9: generic kernel
+        L.conv2d_wgrad_set_variant(variant)
+        try:
+            splits = L.conv2d_wgrad_splits_geom(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, Co, Ci)
+            ws = torch.full((splits * Co * ktot,), float("nan"), dtype=torch.float32, device="cuda")
+            dw = torch.full((Co, Ci, 3, 3), 7.0, dtype=torch.float32, device="cuda")
+            L.check(L.conv2d_wgrad(dt, dyb.data_ptr(), Co, xb.data_ptr(), Ci, ws.data_ptr(), splits, dw.data_ptr(), 0, B, H, W, Ci, Ci,
+                                   H, W, Co, Co, 3, 3, 1, 1, 1, st()), "wgrad")
+            torch.cuda.synchronize()
+            outs[variant] = (dw.cpu().numpy(), splits)
+        finally:
+            L.conv2d_wgrad_set_variant(0)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for v, (got, splits) in outs.items():
+        assert np.isfinite(got).all(), v
+        np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * scale, err_msg=f"variant {v} splits {splits}")
+    np.testing.assert_allclose(outs[8][0], outs[9][0], rtol=1e-3, atol=1e-3 * scale)      # same bf16 products, fp32 sums in another order
