@@ -1050,15 +1050,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsign
 
   // fragment read offsets of this lane inside an operand tile (k-step ks adds ks*32 pixel rows, fragment F adds 32 bytes of columns)
   const int t = lane & 15, kq = lane >> 4;
-  const int prow = kq * 8 + (t >> 2);                       // pixel row of the first transpose read (second: +4)
+  // K slot (kq, half, i) of the MFMA <-> pixel row kq*4 + i + 16*half of the 32-row k-step (any bijection works: both operands use
+  // it).  Lanes 0-31 (one LDS service group) then read 8 consecutive rows = 8 distinct swizzle classes = all 64 banks; with
+  // rows kq*8 + i every transpose read was a 2-way conflict (rocprofv3: SQ_LDS_BANK_CONFLICT = 49 % of SQ_LDS_IDX_ACTIVE).
+  const int prow = kq * 4 + (t >> 2);                       // pixel row of the first transpose read (second: +16)
   const int sub = (t & 1) * 8;                              // 8-byte half of the 16-byte column
   const int qlo = (t & 3) >> 1;                             // which 16-byte column of the fragment's pair
-  const int g0 = 2 * (t >> 2), g1 = 2 * ((t >> 2) + 4);     // swizzle of the two reads (pixel&7 = t>>2 and t>>2 + 4)
+  const int g0 = 2 * (prow & 7), g1 = g0;                   // swizzle of the two reads (same pixel & 7)
   auto frag = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {
     const int row0 = ks * 32 + prow;
     const int c = 2 * F + qlo;
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 256 + ((c ^ g0) << 4) + sub));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 4) * 256 + ((c ^ g1) << 4) + sub));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 16) * 256 + ((c ^ g1) << 4) + sub));
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);

@@ -29,7 +29,11 @@ constexpr int BTILE = BN * 64;                            // one weight tile of 
 constexpr unsigned OOB = 0x80000000u;
 constexpr int SROW = BN * 2 + 16;                          // epilogue staging pitch (bf16)
 
-__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
+// 16-byte slot of logical k-vector q in a 64-byte tile row: q ^ swz(row).  ds_read_b128 is serviced in 16-lane groups that hold
+// rows i..i+3 and i+12..i+15 of one k-vector and rows i+4..i+11 of its neighbour (q^1); with swz = 2*((row>>2)&1) the four rows
+// of a residue class (row&3) land in four different slots for EVERY row offset, so the tap-shifted reads are conflict-free too
+// (the aligned-only swizzle (-(row>>2))&3 left 27-30 % of the LDS cycles as bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 2; }
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 #if defined(MDCV_SHIFT_TS) || defined(MDCV_SHIFT_WG)

@@ -108,14 +108,14 @@ __global__ __launch_bounds__(512) void wgrad3x3_shift_kernel(WgradShiftArgs a, u
 
   // fragment reads (see conv_wgrad_dma_kernel): 16-lane group = 4 rows x 4 quads of a 16-channel block, lane i receives column i
   const int t = lane & 15, kq = lane >> 4;
-  const int prow = kq * 8 + (t >> 2);
+  const int prow = kq * 4 + (t >> 2);      // K slot (kq, half, i) <-> pixel row kq*4 + i + 16*half: lanes 0-31 read 8 consecutive rows = all 64 banks
   const int sub = (t & 1) * 8;
   const int qlo = (t & 3) >> 1;
-  auto frag = [&](const unsigned char* tile, int row0, int F) -> bf16x8_t {   // rows row0 .. row0+3 and row0+4 .. row0+7 of this lane group
+  auto frag = [&](const unsigned char* tile, int row0, int F) -> bf16x8_t {   // rows row0 .. row0+3 and row0+16 .. row0+19 of this lane group
     const int c = 2 * F + qlo;
-    const int g0 = 2 * (row0 & 7), g1 = 2 * ((row0 + 4) & 7);
+    const int g0 = 2 * (row0 & 7), g1 = g0;
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 256 + ((c ^ g0) << 4) + sub));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 4) * 256 + ((c ^ g1) << 4) + sub));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 16) * 256 + ((c ^ g1) << 4) + sub));
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
