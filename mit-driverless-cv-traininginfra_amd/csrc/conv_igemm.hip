@@ -19,6 +19,7 @@
 #include "conv_shift.h"
 #include "bn_fuse.h"
 #include "wgrad_shift.h"
+#include "wgrad_stream.h"
 
 namespace {
 
@@ -1204,6 +1205,63 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kk_kernel(const float* __res
   }
 }
 
+// Slab reduce for SMALL layers (Cout * ceil(Cin/64) < 128 blocks in the kernel above: RektNet's 16..64-channel layers took 13-25 us
+// there, most of it idle lanes and serial split loops).  One thread per slab element k (coalesced), 16 split groups per block
+// with 8 loads in flight each, fixed-order tree in LDS -> deterministic.  Grid (ceil(Ktot/64), Cout_real).
+__global__ __launch_bounds__(1024) void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int Cout_pad,
+                                                                 int Cin_real, int Cin_pad, int KK, int Ktot, int accumulate) {
+  __shared__ float part[16][64];
+  const int co = blockIdx.y, c = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + c;
+  const size_t slab = (size_t)Cout_pad * Ktot;
+  float acc = 0.f;
+  if (k < Ktot) {
+    const float* p = ws + (size_t)co * Ktot + k;
+    int sp = sg;
+    for (; sp + 112 < splits; sp += 128) {                 // 8 independent loads in flight
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(sp + 16 * u) * slab];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; sp < splits; sp += 16) acc += p[(size_t)sp * slab];
+  }
+  part[sg][c] = acc;
+  __syncthreads();
+  if (sg == 0 && k < Ktot) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = part[u][c];
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int u = 0; u < w; ++u) v[u] += v[u + w];
+    const int t = k / Cin_pad, ci = k - t * Cin_pad;
+    if (ci < Cin_real) {
+      float* out = dw + ((size_t)co * Cin_real + ci) * KK + t;
+      *out = accumulate ? *out + v[0] : v[0];
+    }
+  }
+}
+
+// sums the fp32 slabs ws[splits][Cout_pad][KK*Cin_pad] into the OIHW gradient
+static int launch_wgrad_reduce(const float* ws, float* dw_oihw, int splits, int Cout_pad, int Cout_real, int Cin_pad, int Cin_real, int KK,
+                               int accumulate, hipStream_t st) {
+  const int Ktot = KK * Cin_pad;
+  if (Cout_real * cdiv(Cin_real, 64) < 128) {
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)cdiv(Ktot, 64), (unsigned)Cout_real), dim3(1024), 0, st, ws, dw_oihw, splits,
+                       Cout_pad, Cin_real, Cin_pad, KK, Ktot, accumulate);
+  } else {
+    const dim3 rgrid((unsigned)Cout_real, (unsigned)cdiv(Cin_real, 64));
+    if (KK == 9) hipLaunchKernelGGL(wgrad_reduce_kk_kernel<9>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate);
+    else if (KK == 1) hipLaunchKernelGGL(wgrad_reduce_kk_kernel<1>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), KK * 65 * 4, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, KK, Ktot, accumulate);
+  }
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
 // OIHW fp32 master weights -> GEMM operand layouts (T):
 //   wf[n][tap][ci_pad]  (forward "B" operand, n < Cout_pad)      wd[ci][tap][co_pad]  (dgrad "B" operand, ci < Cin_pad)
 template <typename T>
@@ -1247,9 +1305,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
   const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, dy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, x_bytes, 0x00020000);
 
-  // A (dY) DMA role: chunk = wave; lane fills pixel row ra = lane>>2, channels 8*(lane&3)..+7
+  // A (dY) DMA role: chunk = wave; lane fills pixel row ra = lane>>2, 16-byte slot lane&3; rows with bit 2 set hold their two
+  // 32-byte halves swapped, so the 8 consecutive rows one LDS service group reads (64-byte rows: 4 rows per bank period) hit all banks
   const int ra = lane >> 2;
-  const int coA = (lane & 3) * 8;
+  const int coA = ((lane & 3) ^ (2 * ((ra >> 2) & 1))) * 8;
   const bool a_ok = coA < a.Cout;
   // B (X) DMA role: as in the wide kernel
   const int r = lane >> 4, q = lane & 15;
@@ -1314,22 +1373,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
   };
 
   const int t = lane & 15, kq = lane >> 4;
-  const int prow = kq * 8 + (t >> 2);
+  const int prow = kq * 4 + (t >> 2);                       // conflict-free K-slot <-> pixel-row mapping (see conv_wgrad_dma_kernel)
   const int sub = (t & 1) * 8, qlo = (t & 3) >> 1;
-  const int g0 = 2 * (t >> 2), g1 = 2 * ((t >> 2) + 4);
+  const int g0 = 2 * (prow & 7), g1 = g0;
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   auto fragB = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {
     const int row0 = ks * 32 + prow, c = 2 * F + qlo;
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 256 + ((c ^ g0) << 4) + sub));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 4) * 256 + ((c ^ g1) << 4) + sub));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 16) * 256 + ((c ^ g1) << 4) + sub));
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
-  auto fragA = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {       // 64-byte rows: F selects the 32-byte half
-    const int row0 = ks * 32 + prow;
-    const int col = F * 32 + (t & 3) * 8;
+  auto fragA = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {       // 64-byte rows: F selects the 32-byte half,
+    const int row0 = ks * 32 + prow;                                             // stored swapped in rows with bit 2 set
+    const int col = (F ^ (kq & 1)) * 32 + (t & 3) * 8;
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 64 + col));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 4) * 64 + col));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 16) * 64 + col));
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
@@ -1642,7 +1701,12 @@ int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, i
 }
 
 // tuning hook: force the tile configuration of wide (Nout > 64) layers; -1 restores the heuristic
-int mdcv_conv2d_wgrad_set_variant(int v) { g_wgrad_variant = v; return MDCV_OK; }   /* tuning hook */
+int mdcv_conv2d_wgrad_set_variant(int v) {   /* tuning hook; 1000 + 100*d + blocks/64: stream-kernel prefetch depth / target blocks */
+  if (v >= 1000) { mdcv_wgrad_stream_tune((v - 1000) / 100, ((v - 1000) % 100) * 64); v = 0; }
+  else if (v == 0) mdcv_wgrad_stream_tune(0, 0);
+  g_wgrad_variant = v;
+  return MDCV_OK;
+}
 int mdcv_conv2d_set_variant(int v) {
   if (v <= -3 && v >= -13) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11 16-wave workgroups, -12 192-row tiles where they save a round
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
@@ -1679,9 +1743,19 @@ static bool use_wgrad_shift(int dtype, int B, int Hin, int Win, int Cin, int Hou
   return Mq / (64LL * s) >= 128;
 }
 
+// 16..128-channel 3x3 stride-1 layers (dilation 1 or 2): all nine taps read one activation window kept in an LDS ring
+// (wgrad_stream.hip).  Variants 9 and 10 disable it.
+static bool use_wgrad_stream(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride, int pad,
+                             int dil, long long dy_ldc, long long x_ldc) {
+  if (g_wgrad_variant == 9 || g_wgrad_variant == 10 || Hin != Hout || Win != Wout) return false;
+  return mdcv_wgrad_stream_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc);
+}
+
 // geometry-aware variant: the kernel mdcv_conv2d_wgrad will pick for this layer decides the split (use this one to size `ws`)
 int mdcv_conv2d_wgrad_splits_geom(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride,
                                   int pad, int dil, int dy_ldc, int x_ldc) {
+  if (use_wgrad_stream(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc))
+    return mdcv_wgrad_stream_splits(B, Hout, Wout, Cin, Cout, dil);
   if (use_wgrad_shift(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc))
     return mdcv_wgrad_shift_splits(B, Hout, Wout, Cin, Cout);
   return mdcv_conv2d_wgrad_splits(dtype, B * Hout * Wout, Cout, KH * KW * Cin);
@@ -1692,16 +1766,19 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
                       int Hout, int Wout, int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream) {
   if (!dy || !x || !ws || !dw_oihw) return MDCV_EARG;
   if ((Cin & 7) || (Cout & 7) || (dy_ldc & 7) || (x_ldc & 7) || splits < 1) return MDCV_EARG;
+  if (use_wgrad_stream(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc) &&
+      mdcv_wgrad_stream_splits_ok(splits, B, Hout, Wout, Cin, Cout, dil)) {
+    const int rc = mdcv_wgrad_stream(dy, dy_ldc, x, x_ldc, ws, splits, B, Hout, Wout, Cin, Cout, dil, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, 9, accumulate, (hipStream_t)stream);
+  }
   // 3x3 / stride 1 / pad 1 with 128-multiple channel counts: the three kw taps of a kernel row share one activation tile
   const bool shift_w = use_wgrad_shift(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc) &&
                        mdcv_wgrad_shift_splits_ok(splits, B, Hout, Wout);
   if (shift_w) {
     const int rc = mdcv_wgrad_shift(dy, dy_ldc, x, x_ldc, ws, splits, B, Hout, Wout, Cin, Cout, (hipStream_t)stream);
     if (rc) return rc;
-    const dim3 rg((unsigned)Cout_real, (unsigned)cdiv(Cin_real, 64));
-    hipLaunchKernelGGL(wgrad_reduce_kk_kernel<9>, rg, dim3(256), 0, (hipStream_t)stream, ws, dw_oihw, splits, Cout, Cin_real, Cin, 9 * Cin, accumulate);
-    MDCV_CHECK_LAUNCH();
-    return MDCV_OK;
+    return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, 9, accumulate, (hipStream_t)stream);
   }
   WgradArgs a;
   a.dy = dy; a.x = x; a.ws = ws; a.dy_ldc = dy_ldc; a.x_ldc = x_ldc;
@@ -1736,13 +1813,7 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   else if (dtype == MDCV_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3(grid), dim3(256), lds, st, a);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
-  const int KK = KH * KW;
-  const dim3 rgrid((unsigned)Cout_real, (unsigned)cdiv(Cin_real, 64));
-  if (KK == 9) hipLaunchKernelGGL(wgrad_reduce_kk_kernel<9>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout, Cin_real, Cin, a.Ktot, accumulate);
-  else if (KK == 1) hipLaunchKernelGGL(wgrad_reduce_kk_kernel<1>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout, Cin_real, Cin, a.Ktot, accumulate);
-  else hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), KK * 65 * 4, st, ws, dw_oihw, splits, Cout, Cin_real, Cin, KK, a.Ktot, accumulate);
-  MDCV_CHECK_LAUNCH();
-  return MDCV_OK;
+  return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, KH * KW, accumulate, st);
 }
 
 int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,

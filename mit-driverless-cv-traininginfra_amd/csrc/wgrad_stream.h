@@ -1,0 +1,21 @@
+// Internal interface between conv_igemm.hip (mdcv_conv2d_wgrad) and wgrad_stream.hip: 3x3 stride-1 "same" weight gradient
+// (dilation 1 or 2) for 16..128-channel layers, activation window kept in an LDS ring.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct WgradStreamArgs {
+  const void* dy; const void* x; float* ws;
+  int dy_ldc, x_ldc;
+  int H, W, Cin, Cout, Ktot, dil;
+  int Wq, Sq, Mq;                       // W+dil, (H+dil)(W+dil), B*Sq: padded position stream with `dil` shared zero columns / rows
+  int hpad, RS;                         // halo rows on each side (multiple of 32) and rows of the activation ring
+  int pos_per_split, splits, xcd_chunk;
+};
+
+bool mdcv_wgrad_stream_eligible(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
+                                long long dy_ldc, long long x_ldc);
+int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil);
+bool mdcv_wgrad_stream_splits_ok(int splits, int B, int H, int W, int Cin, int Cout, int dil);
+int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, int Cin, int Cout,
+                      int dil, hipStream_t st);
+void mdcv_wgrad_stream_tune(int d, int blocks);   // tuning hook: prefetch depth (0 = default), target block count (0 = default)

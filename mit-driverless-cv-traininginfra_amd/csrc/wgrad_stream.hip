@@ -1,0 +1,344 @@
+// Weight gradient of a 3x3 / stride 1 / "same" convolution (dilation 1 or 2) for the 16..128-channel layers, with the activation
+// window of ALL NINE taps resident in an LDS ring.
+//
+// Why: the generic kernel (conv_igemm.hip, conv_wgrad_dma_kernel / _narrow_kernel) gathers an im2col tile per tap, so every activation
+// row travels through the global->LDS path nine times.  For C <= 64 that path, not HBM and not the MFMA pipe, sets the time
+// (RektNet 80x80 16->16: 118 us for 105 MB of operands = 0.9 TB/s; 64->64: 287 TFLOP/s), and a 128-wide output-channel tile wastes
+// half its MFMAs on Cout = 64.
+//
+// Here a block owns a run of stream positions and the WHOLE dW[Cout][9][Cin] (Cout, Cin <= 128; 128x128 stays with wgrad_shift.hip).
+// Positions run over a padded 1-D stream, p = img*(H+d)(W+d) + y*(W+d) + x with d = dilation shared zero columns per row and d
+// zero rows per image: dY'[p] is zero at junk positions, X'[p] is zero on the padding, so tap (kh,kw) of position p is simply
+// X'[p + ((kh-1)(W+d) + (kw-1))*d] and no per-tap masking exists.  Per step of BP positions the block DMAs BP new dY rows into
+// a stage buffer and BP new activation rows into a RING of RS >= (D+1)*BP + 2*hpad rows (a power of two) (hpad >= d(W+d+1) halo rows each side):
+// every activation byte is fetched once per block (plus the 2*hpad-row window at the start of the block's run).
+//
+// Operands stay in [position][channel] order; MFMA fragments (8 positions per channel) come from ds_read_b64_tr_b16 transpose
+// reads.  Rows are 32*NC bytes (NC = channels/16); the 32-byte unit u of row r is stored at unit u ^ ((r & 7) / (8/NC) & (NC-1)), which
+// makes any 8 CONSECUTIVE rows (one LDS service group: lanes 0-31 read rows r..r+7 of one 16-channel block) cover all 64 banks
+// for every start row, so the tap-shifted reads are conflict-free as well.  K slot (kq, half, i) <-> position kq*4 + i + 16*half.
+//
+// Waves: 8 = PG position groups x TG tile groups; a wave accumulates A co-tiles x 1 ci-tile x 9 taps (36*A VGPRs) over its share of
+// the 32-position sub-steps.  The PG partial sums meet in LDS in a fixed order (deterministic), then go to the split's fp32 slab
+// ws[split][Cout][9*Cin] that wgrad_reduce_kk_kernel<9> sums into OIHW.
+#include "common.h"
+#include "wgrad_stream.h"
+
+namespace {
+
+constexpr unsigned OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+__device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int& r) {   // 0 <= n < 2^24
+  q = (int)((float)n * inv);
+  r = n - q * d;
+  const int lt = r < 0;  q -= lt; r += lt ? d : 0;
+  const int ge = r >= d; q += ge; r -= ge ? d : 0;
+}
+
+// NCI / NCO: 16-channel blocks of Cin / Cout.  A: co blocks per wave.  PG: position groups.  BP: positions per step (8 KiB of
+// activations).  D: steps in flight behind the one being multiplied.  TGRP: taps staged together in the epilogue (9, 3 or 1).
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP>
+__global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a, unsigned dy_bytes, unsigned x_bytes) {
+  constexpr int RBX = NCI * 32, RBY = NCO * 32;            // row bytes
+  constexpr int LPRX = 2 * NCI, LPRY = 2 * NCO;            // 16-byte slots (= DMA lanes) per row
+  constexpr int RPIX = 64 / LPRX, RPIY = 64 / LPRY;        // rows per 1 KiB DMA instruction
+  constexpr int RX = 8 / NCI, RY = 8 / NCO;                // rows per 256-byte bank period
+  constexpr int DYI = BP / RPIY / 8;                       // dY DMA instructions per wave per step
+  constexpr int NI = 1 + DYI;                              // DMA instructions per wave per step
+  constexpr int NSUB = BP / 32 / PG;                       // 32-position sub-steps per wave per step
+  constexpr int TG = 8 / PG;
+  constexpr int YSTAGE = BP * RBY;
+  constexpr int CIN = NCI * 16, COUT = NCO * 16;
+  static_assert(BP / RPIX == 8, "one activation DMA per wave per step");
+  static_assert(TG == (NCO / A) * NCI && NSUB >= 1 && DYI >= 1, "wave grid");
+  static_assert(9 % TGRP == 0, "tap groups");
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* const ring = smem + (D + 1) * YSTAGE;
+  const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
+  if (logical >= a.splits) return;
+  const int split = logical;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pg = wave % PG, tg = wave / PG;
+  const int cog = tg / NCI, cit = tg - cog * NCI;          // this wave's co blocks cog*A .. +A-1 and ci block
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, x_bytes, 0x00020000);
+
+  const int RS = a.RS, rmask = a.RS - 1;                    // ring rows: a power of two
+  const int p_begin = split * a.pos_per_split;
+  const int p_end = min(a.Mq, p_begin + a.pos_per_split);
+  const int p_lo = p_begin - a.hpad;                        // stream position held by ring row 0
+  const float inv_sq = 1.0f / (float)a.Sq, inv_wq = 1.0f / (float)a.Wq;
+  const unsigned ldy2 = (unsigned)a.dy_ldc * 2u, lx2 = (unsigned)a.x_ldc * 2u;
+
+  // DMA roles.  activations: lane -> row rrx of the chunk, slot sx; it fetches the logical 16-byte column sx ^ 2*g(row).
+  const int rrx = lane / LPRX, sx = lane % LPRX;
+  const int gxw = ((rrx & 7) / RX) & (NCI - 1);             // chunks start at ring rows that are multiples of 8
+  const unsigned lane_x = (unsigned)((sx ^ (gxw << 1)) * 16);
+  const int rry = lane / LPRY, sy = lane % LPRY;
+  const int gyw = ((((wave * RPIY) + rry) & 7) / RY) & (NCO - 1);   // chunk c = wave + 8j starts at row c*RPIY; 8j*RPIY is a multiple of 8
+  const unsigned lane_y = (unsigned)((sy ^ (gyw << 1)) * 16);
+
+  auto pix_off = [&](int p, unsigned ld2, bool ok) -> unsigned {   // stream position -> byte offset of its pixel row, or OOB (zero fill)
+    ok = ok && p >= 0 && p < a.Mq;
+    const int pp = ok ? p : 0;
+    int img, rem, y, x;
+    fast_divmod(pp, a.Sq, inv_sq, img, rem);
+    fast_divmod(rem, a.Wq, inv_wq, y, x);
+    ok = ok && x < a.W && y < a.H;
+    return ok ? __umul24((unsigned)((img * a.H + y) * a.W + x), ld2) : OOB;
+  };
+  // one activation chunk: RPIX rows starting at stream position p (ring row rho, a multiple of RPIX)
+  auto issue_x = [&](int p, int rho) {
+    const unsigned off = pix_off(p + rrx, lx2, true);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + rho * RBX), 16, (int)(off == OOB ? OOB : off + lane_x), 0, 0, 0);
+  };
+  // step t: the BP new activation rows (p_begin + t*BP + hpad ..) and the BP dY rows of the step
+  auto issue = [&](int t, int rho_new) {
+    const int p0 = p_begin + t * BP;
+    {
+      const int rho = (rho_new + wave * RPIX) & rmask;
+      issue_x(p0 + a.hpad + wave * RPIX, rho);
+    }
+    unsigned char* sY = smem + (t % (D + 1)) * YSTAGE;
+#pragma unroll
+    for (int j = 0; j < DYI; ++j) {
+      const int chunk = wave + 8 * j;
+      const int p = p0 + chunk * RPIY + rry;
+      const unsigned off = pix_off(p, ldy2, p < p_end);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t*)(sY + chunk * 1024), 16, (int)(off == OOB ? OOB : off + lane_y), 0, 0, 0);
+    }
+  };
+
+  // fragment roles
+  const int t16 = lane & 15, kq = lane >> 4;
+  const int prow = kq * 4 + (t16 >> 2);
+  const int sub = (t16 & 1) * 8, qlo = (t16 & 3) >> 1;
+  const int gy = ((prow & 7) / RY) & (NCO - 1);             // sub-steps start at multiples of 32 rows
+  auto fragY = [&](const unsigned char* sY, int row0, int F) -> bf16x8_t {
+    const int col = (((2 * F + qlo) ^ (gy << 1)) << 4) + sub;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sY + (row0 + prow) * RBY + col));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sY + (row0 + prow + 16) * RBY + col));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  const int xcol = ((2 * cit + qlo) << 4) + sub;            // byte column of this lane's 8 bytes before the swizzle
+  auto fragX = [&](int rb) -> bf16x8_t {                     // rb: ring row of the sub-step's first position at this tap (0 <= rb < RS)
+    const int r1 = (rb + prow) & rmask, r2 = (rb + prow + 16) & rmask;      // RS is a power of two; r2 = r1 + 16 mod RS: same r & 7
+    const int gsw = ((r1 / RX) & (NCI - 1)) << 5;            // 32-byte unit swizzle
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ring + r1 * RBX + (xcol ^ gsw)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ring + r2 * RBX + (xcol ^ gsw)));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+
+  // ring-row displacement of each tap, reduced to [0, RS)
+  int dtap[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+    dtap[tap] = (((kh - 1) * a.Wq + (kw - 1)) * a.dil) & rmask;       // |displacement| <= hpad < RS
+  }
+
+  f32x4_t acc[9][A];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int i = 0; i < A; ++i) acc[k][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (p_end - p_begin + BP - 1) / BP;
+  auto compute = [&](int t, int rho0) {                      // rho0: ring row of the step's first position
+    const unsigned char* sY = smem + (t % (D + 1)) * YSTAGE;
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      const int ks = pg * NSUB + s;
+      const int rs = rho0 + ks * 32;
+      bf16x8_t fa[A], fb[9];                                 // all fragment reads of the sub-step first, then the 9*A MFMAs
+#pragma unroll
+      for (int i = 0; i < A; ++i) fa[i] = fragY(sY, ks * 32, cog * A + i);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) fb[tap] = fragX(rs + dtap[tap]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int i = 0; i < A; ++i) acc[tap][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[tap], acc[tap][i], 0, 0, 0);
+    }
+  };
+
+  // prologue: the 2*hpad rows below the first step's new rows, then D steps ahead
+  {
+    const int nch = 2 * a.hpad / RPIX;
+    for (int c = wave; c < nch; c += 8) issue_x(p_lo + c * RPIX, c * RPIX);
+  }
+  int issued = 0;
+  int rho_new = (2 * a.hpad) & rmask;                        // ring row of the next step's first new activation row
+  for (; issued < D && issued < nt; ++issued) {
+    issue(issued, rho_new);
+    rho_new = (rho_new + BP) & rmask;
+  }
+  int rho0 = a.hpad;
+  for (int t = 0; t < nt; ++t) {
+    if (issued - 1 - t >= D - 1 && D > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (issued < nt) {
+      issue(issued, rho_new);
+      ++issued;
+      rho_new = (rho_new + BP) & rmask;
+    }
+    compute(t, rho0);
+    rho0 = (rho0 + BP) & rmask;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // epilogue: the PG partial sums meet in LDS (fixed order), TGRP taps at a time, then coalesced rows of the split's slab
+  constexpr int OR = TGRP * CIN + 4;                         // floats per staged row
+  float* so = reinterpret_cast<float*>(smem);
+  float* __restrict__ ws = a.ws + (size_t)split * COUT * a.Ktot;
+#pragma unroll
+  for (int g0 = 0; g0 < 9 / TGRP; ++g0) {
+#pragma unroll
+    for (int pgi = 0; pgi < PG; ++pgi) {
+      if (pg == pgi) {
+#pragma unroll
+        for (int tl = 0; tl < TGRP; ++tl)
+#pragma unroll
+          for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int idx = ((cog * A + i) * 16 + kq * 4 + rr) * OR + tl * CIN + cit * 16 + t16;
+              const float v = acc[g0 * TGRP + tl][i][rr];
+              so[idx] = pgi == 0 ? v : so[idx] + v;
+            }
+      }
+      __syncthreads();
+    }
+    constexpr int V4 = TGRP * CIN / 4;                       // float4 per staged row
+    for (int v = tid; v < COUT * V4; v += 512) {
+      const int row = v / V4, c4 = (v - row * V4) * 4;
+      *reinterpret_cast<float4*>(ws + (size_t)row * a.Ktot + g0 * TGRP * CIN + c4) = *reinterpret_cast<const float4*>(so + row * OR + c4);
+    }
+    __syncthreads();
+  }
+}
+
+struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; };
+int g_stream_d = 0;        // tuning hook: force the prefetch depth (1..3); 0 = per-configuration default
+int g_stream_blocks = 0;   // tuning hook: force the target block count; 0 = default
+
+// (Cin, Cout) -> instantiation; false if unsupported
+inline bool stream_cfg(int Cin, int Cout, StreamCfg& c) {
+  if (Cin == 16 && Cout == 16)       c = {1, 1, 1, 8, 256, 1, 9};
+  else if (Cin == 16 && Cout == 32)  c = {1, 2, 2, 8, 256, 1, 9};
+  else if (Cin == 32 && Cout == 32)  c = {2, 2, 2, 4, 128, 1, 9};
+  else if (Cin == 32 && Cout == 64)  c = {2, 4, 4, 4, 128, 1, 3};
+  else if (Cin == 64 && Cout == 64)  c = {4, 4, 4, 2, 64, 1, 3};
+  else if (Cin == 64 && Cout == 128) c = {4, 8, 4, 1, 64, 1, 1};
+  else return false;
+  if (g_stream_d >= 1 && g_stream_d <= 3) c.d = g_stream_d;
+  return true;
+}
+
+inline int stream_hpad(int W, int dil) { return (dil * (W + dil + 1) + 31) / 32 * 32; }
+inline int stream_ring_rows(const StreamCfg& c, int W, int dil) {       // >= (D+1)*BP + 2*hpad, a power of two
+  int need = (c.d + 1) * c.bp + 2 * stream_hpad(W, dil), rs = 256;
+  while (rs < need) rs *= 2;
+  return rs;
+}
+inline int stream_lds(const StreamCfg& c, int W, int dil) {
+  const int rs = stream_ring_rows(c, W, dil);
+  const int ring = (c.d + 1) * c.bp * c.nco * 32 + rs * c.nci * 32;
+  const int stage_out = c.nco * 16 * (c.tgrp * c.nci * 16 + 4) * 4;
+  return ring > stage_out ? ring : stage_out;
+}
+
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP>
+int launch_stream(const WgradStreamArgs& a, int lds, unsigned dyb, unsigned xb, hipStream_t st) {
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+}  // namespace
+
+bool mdcv_wgrad_stream_eligible(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
+                                long long dy_ldc, long long x_ldc) {
+  if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != dil || (dil != 1 && dil != 2)) return false;
+  StreamCfg c;
+  if (!stream_cfg(Cin, Cout, c)) return false;
+  if (H < 4 || W < 4) return false;
+  if (stream_lds(c, W, dil) > 160 * 1024) return false;
+  const long long Mq = (long long)B * (H + dil) * (W + dil);
+  if (Mq + 4096 >= (1LL << 24) || (long long)B * H * W >= (1LL << 24)) return false;          // 24-bit multiplies / float divmod
+  if ((long long)B * H * W * dy_ldc * 2 >= (1LL << 31) || (long long)B * H * W * x_ldc * 2 >= (1LL << 31)) return false;
+  if (dy_ldc >= (1 << 23) || x_ldc >= (1 << 23)) return false;
+  return true;
+}
+
+// blocks = splits: two resident blocks per CU for the light configurations (A <= 2), one for A = 4; never less than 4 steps per split
+int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil) {
+  StreamCfg c;
+  if (!stream_cfg(Cin, Cout, c)) return 1;
+  const int Mq = B * (H + dil) * (W + dil);
+  int s = g_stream_blocks > 0 ? g_stream_blocks : (c.a <= 2 ? 512 : 256);
+  const int max_s = (Mq + c.bp * 4 - 1) / (c.bp * 4);
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  const int pps = ((Mq + s - 1) / s + c.bp - 1) / c.bp * c.bp;
+  return (Mq + pps - 1) / pps;
+}
+
+bool mdcv_wgrad_stream_splits_ok(int splits, int B, int H, int W, int Cin, int Cout, int dil) {
+  StreamCfg c;
+  if (splits < 1 || !stream_cfg(Cin, Cout, c)) return false;
+  const int Mq = B * (H + dil) * (W + dil);
+  const int pps = ((Mq + splits - 1) / splits + c.bp - 1) / c.bp * c.bp;
+  return (Mq + pps - 1) / pps == splits;
+}
+
+int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, int Cin, int Cout,
+                      int dil, hipStream_t st) {
+  StreamCfg c;
+  if (!stream_cfg(Cin, Cout, c)) return MDCV_EARG;
+  WgradStreamArgs a;
+  a.dy = dy; a.x = x; a.ws = ws; a.dy_ldc = dy_ldc; a.x_ldc = x_ldc;
+  a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Ktot = 9 * Cin; a.dil = dil;
+  a.Wq = W + dil; a.Sq = (H + dil) * (W + dil); a.Mq = B * a.Sq;
+  a.hpad = stream_hpad(W, dil);
+  a.RS = stream_ring_rows(c, W, dil);
+  a.pos_per_split = ((a.Mq + splits - 1) / splits + c.bp - 1) / c.bp * c.bp;
+  if ((a.Mq + a.pos_per_split - 1) / a.pos_per_split != splits) return MDCV_EARG;
+  a.splits = splits;
+  a.xcd_chunk = (splits + 7) / 8;
+  const int lds = stream_lds(c, W, dil);
+  const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
+#define STREAM_CASE(CI, CO, NCI, NCO, A, PG, BP, TGRP)                                            \
+  if (Cin == CI && Cout == CO) {                                                                  \
+    if (c.d == 1) return launch_stream<NCI, NCO, A, PG, BP, 1, TGRP>(a, lds, dyb, xb, st);        \
+    if (c.d == 2) return launch_stream<NCI, NCO, A, PG, BP, 2, TGRP>(a, lds, dyb, xb, st);        \
+    return launch_stream<NCI, NCO, A, PG, BP, 3, TGRP>(a, lds, dyb, xb, st);                      \
+  }
+  STREAM_CASE(16, 16, 1, 1, 1, 8, 256, 9)
+  STREAM_CASE(16, 32, 1, 2, 2, 8, 256, 9)
+  STREAM_CASE(32, 32, 2, 2, 2, 4, 128, 9)
+  STREAM_CASE(32, 64, 2, 4, 4, 4, 128, 3)
+  STREAM_CASE(64, 64, 4, 4, 4, 2, 64, 3)
+  STREAM_CASE(64, 128, 4, 8, 4, 1, 64, 1)
+#undef STREAM_CASE
+  return MDCV_EARG;
+}
+
+void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_d = d; g_stream_blocks = blocks; }

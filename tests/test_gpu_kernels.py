@@ -583,3 +583,42 @@ def test_wgrad_shift_kernel(case):
         assert np.isfinite(got).all(), v
         np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * scale, err_msg=f"variant {v} splits {splits}")
     np.testing.assert_allclose(outs[8][0], outs[9][0], rtol=1e-3, atol=1e-3 * scale)      # same bf16 products, fp32 sums in another order
+
+
+WGRAD_STREAM_CASES = [(2, 16, 16, 12, 9, 1), (3, 16, 16, 80, 80, 2), (2, 16, 32, 30, 17, 2), (4, 32, 32, 80, 80, 1), (2, 32, 64, 40, 33, 2),
+                      (3, 64, 64, 26, 20, 1), (2, 64, 128, 80, 80, 2), (1, 64, 128, 104, 104, 1), (1, 32, 64, 208, 208, 1), (5, 64, 64, 5, 4, 1)]
+
+
+@pytest.mark.parametrize("case", WGRAD_STREAM_CASES, ids=[str(c) for c in WGRAD_STREAM_CASES])
+def test_wgrad_stream_kernel(case):
+    """3x3 stride-1 weight gradient (dilation 1 / 2) with the nine taps reading one LDS activation ring == torch reference
+    == generic kernel."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, Co, H, W, dil = case
+    g = torch.Generator().manual_seed(Ci + Co + H + dil)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(rnd(dt, x), w, None, stride=1, padding=dil, dilation=dil).backward(rnd(dt, dy))
+    ref = w.grad.numpy()
+    xb, dyb = to_nhwc(x, dt), to_nhwc(dy, dt)
+    ktot = 9 * Ci
+    outs = {}
+    for variant in (0, 9):                      # 0: default dispatch (stream kernel) ; 9: generic kernel
+        L.conv2d_wgrad_set_variant(variant)
+        try:
+            splits = L.conv2d_wgrad_splits_geom(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, dil, dil, Co, Ci)
+            ws = torch.full((splits * Co * ktot,), float("nan"), dtype=torch.float32, device="cuda")
+            dw = torch.full((Co, Ci, 3, 3), 7.0, dtype=torch.float32, device="cuda")
+            L.check(L.conv2d_wgrad(dt, dyb.data_ptr(), Co, xb.data_ptr(), Ci, ws.data_ptr(), splits, dw.data_ptr(), 0, B, H, W, Ci, Ci,
+                                   H, W, Co, Co, 3, 3, 1, dil, dil, st()), "wgrad")
+            torch.cuda.synchronize()
+            outs[variant] = (dw.cpu().numpy(), splits)
+        finally:
+            L.conv2d_wgrad_set_variant(0)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for v, (got, splits) in outs.items():
+        assert np.isfinite(got).all(), v
+        np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * scale, err_msg=f"variant {v} splits {splits}")
+    np.testing.assert_allclose(outs[0][0], outs[9][0], rtol=1e-3, atol=1e-3 * scale)      # same bf16 products, fp32 sums in another order
