@@ -39,6 +39,27 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int
   const int ge = r >= d; q += ge; r -= ge ? d : 0;
 }
 
+// Transpose read as inline asm.  With the builtin, the compiler (which cannot tell the ring slots apart) drains the LDS-DMA queue
+// with s_waitcnt vmcnt(0) in front of every read that follows a DMA -- also across the loop back-edge -- so fill and compute never
+// overlap.  The asm read is invisible to that pass; the kernel orders DMA and reads itself (counted vmcnt + barrier) and waits for
+// the reads with wait_frags() below, whose "+v" operands make every MFMA depend on the wait.
+template <int OFF> __device__ __forceinline__ s16x4_t lds_tr16(unsigned addr) {      // addr: LDS byte address; OFF: immediate offset
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// wait until at most N of this wave's LDS reads are outstanding (they return in order); the MFMAs that use `f...` depend on it
+template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[1], bf16x8_t& f) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[0]), "+v"(f) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[2], bf16x8_t& f) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(f) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[4], bf16x8_t& f) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(f) : "n"(N) : "memory");
+}
+
 // NCI / NCO: 16-channel blocks of Cin / Cout.  A: co blocks per wave.  PG: position groups.  BP: positions per step (8 KiB of
 // activations).  D: steps in flight behind the one being multiplied.  TGRP: taps staged together in the epilogue (9, 3 or 1).
 template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP>
@@ -58,7 +79,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
   static_assert(9 % TGRP == 0, "tap groups");
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  unsigned char* const ring = smem + (D + 1) * YSTAGE;
+  unsigned char* const ring = smem;                          // the activation ring sits at LDS offset 0, the dY stages behind it
   const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
   if (logical >= a.splits) return;
   const int split = logical;
@@ -70,6 +91,8 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, x_bytes, 0x00020000);
 
   const int RS = a.RS, rmask = a.RS - 1;                    // ring rows: a power of two
+  unsigned char* const stages = smem + RS * RBX;
+  const unsigned ybase = (unsigned)(RS * RBX), bmask = (unsigned)(RS * RBX - 1);
   const int p_begin = split * a.pos_per_split;
   const int p_end = min(a.Mq, p_begin + a.pos_per_split);
   const int p_lo = p_begin - a.hpad;                        // stream position held by ring row 0
@@ -105,7 +128,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
       const int rho = (rho_new + wave * RPIX) & rmask;
       issue_x(p0 + a.hpad + wave * RPIX, rho);
     }
-    unsigned char* sY = smem + (t % (D + 1)) * YSTAGE;
+    unsigned char* sY = stages + (t % (D + 1)) * YSTAGE;
 #pragma unroll
     for (int j = 0; j < DYI; ++j) {
       const int chunk = wave + 8 * j;
@@ -119,31 +142,37 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
   const int t16 = lane & 15, kq = lane >> 4;
   const int prow = kq * 4 + (t16 >> 2);
   const int sub = (t16 & 1) * 8, qlo = (t16 & 3) >> 1;
-  const int gy = ((prow & 7) / RY) & (NCO - 1);             // sub-steps start at multiples of 32 rows
-  auto fragY = [&](const unsigned char* sY, int row0, int F) -> bf16x8_t {
-    const int col = (((2 * F + qlo) ^ (gy << 1)) << 4) + sub;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sY + (row0 + prow) * RBY + col));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(sY + (row0 + prow + 16) * RBY + col));
-    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8_t, v);
-  };
+  // Every fragment address is  (wave-uniform byte offset) + (lane constant): sub-steps start at ring rows that are multiples of 32,
+  // so the row-dependent swizzle of tap k depends only on (displacement_k + prow) & 7 -- a per-tap lane constant.
+  const int gy = ((prow & 7) / RY) & (NCO - 1);
+  unsigned laneY[A];                                          // dY: row prow of the sub-step, co block cog*A + i
+#pragma unroll
+  for (int i = 0; i < A; ++i) laneY[i] = ybase + (unsigned)(prow * RBY + ((((2 * (cog * A + i) + qlo) ^ (gy << 1)) << 4) + sub));
   const int xcol = ((2 * cit + qlo) << 4) + sub;            // byte column of this lane's 8 bytes before the swizzle
-  auto fragX = [&](int rb) -> bf16x8_t {                     // rb: ring row of the sub-step's first position at this tap (0 <= rb < RS)
-    const int r1 = (rb + prow) & rmask, r2 = (rb + prow + 16) & rmask;      // RS is a power of two; r2 = r1 + 16 mod RS: same r & 7
-    const int gsw = ((r1 / RX) & (NCI - 1)) << 5;            // 32-byte unit swizzle
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ring + r1 * RBX + (xcol ^ gsw)));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(ring + r2 * RBX + (xcol ^ gsw)));
-    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8_t, v);
-  };
-
-  // ring-row displacement of each tap, reduced to [0, RS)
-  int dtap[9];
+  unsigned laneX[9];                                          // activations: row prow + displacement, ci block cit
+  int dtap[9];                                                // ring-row displacement of each tap, reduced to [0, RS)
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int kh = tap / 3, kw = tap - kh * 3;
     dtap[tap] = (((kh - 1) * a.Wq + (kw - 1)) * a.dil) & rmask;       // |displacement| <= hpad < RS
+    const int g = (((dtap[tap] + prow) & 7) / RX) & (NCI - 1);
+    laneX[tap] = (unsigned)((dtap[tap] + prow) * RBX + (xcol ^ (g << 5)));
   }
+  auto fragY = [&](unsigned sbase, int i) -> bf16x8_t {        // sbase: byte offset of the sub-step's first row in its stage
+    const unsigned ad = sbase + laneY[i];
+    const s16x4_t lo = lds_tr16<0>(ad);
+    const s16x4_t hi = lds_tr16<16 * RBY>(ad);
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  auto fragX = [&](unsigned sbase, int tap) -> bf16x8_t {      // sbase: byte offset of the sub-step's first ring row (< ring bytes)
+    const unsigned a1 = (sbase + laneX[tap]) & bmask;          // the AND wraps the row, the column bits pass through
+    const unsigned a2 = (a1 + 16 * RBX) & bmask;               // 16 rows on: same row & 7, same swizzle
+    const s16x4_t lo = lds_tr16<0>(a1);
+    const s16x4_t hi = lds_tr16<0>(a2);
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
 
   f32x4_t acc[9][A];
 #pragma unroll
@@ -152,21 +181,43 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
     for (int i = 0; i < A; ++i) acc[k][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nt = (p_end - p_begin + BP - 1) / BP;
-  auto compute = [&](int t, int rho0) {                      // rho0: ring row of the step's first position
-    const unsigned char* sY = smem + (t % (D + 1)) * YSTAGE;
+  // One step: fragment reads of a sub-step, THEN (after the last sub-step's reads) the DMA of step t+D, then the MFMAs.  The DMA
+  // must come after the step's last LDS read in program order: the compiler drains the LDS-DMA queue (s_waitcnt vmcnt(0)) in front
+  // of any LDS read that follows a DMA in the same iteration, which would serialise fill and compute.
+  auto step = [&](int t, int rho0, bool more, int t_new, int rho_new) {
+    const unsigned ystage = (unsigned)((t % (D + 1)) * YSTAGE);
+#ifdef MDCV_WST_NOCOMPUTE
+    if (more) issue(t_new, rho_new);
+    return;
+#endif
+#ifdef MDCV_WST_NOMFMA
+    constexpr bool kMfma = false;
+#else
+    constexpr bool kMfma = true;
+#endif
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
       const int ks = pg * NSUB + s;
-      const int rs = rho0 + ks * 32;
-      bf16x8_t fa[A], fb[9];                                 // all fragment reads of the sub-step first, then the 9*A MFMAs
+      const unsigned xs = (unsigned)((rho0 + ks * 32) * RBX);
+      bf16x8_t fa[A], fb[9];
 #pragma unroll
-      for (int i = 0; i < A; ++i) fa[i] = fragY(sY, ks * 32, cog * A + i);
+      for (int i = 0; i < A; ++i) fa[i] = fragY(ystage + (unsigned)(ks * 32 * RBY), i);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) fb[tap] = fragX(rs + dtap[tap]);
+      for (int tap = 0; tap < 9; ++tap) fb[tap] = fragX(xs, tap);
+#ifndef MDCV_WST_NODMA
+      if (s == NSUB - 1 && more) issue(t_new, rho_new);
+#endif
+      // reads return in issue order (fa..., fb[0], fb[1], ...): tap k starts as soon as its fragment is in, the rest keeps streaming
+      wait_lds<15>(fa, fb[0]);                               // (the counter has 4 bits)
+      if constexpr (kMfma)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int i = 0; i < A; ++i) acc[tap][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[tap], acc[tap][i], 0, 0, 0);
+      for (int i = 0; i < A; ++i) acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[0], acc[0][i], 0, 0, 0);
+#define MDCV_TAP(K)                                                                                            \
+      wait_lds<16 - 2 * K>(fb[K]);                                                                             \
+      if constexpr (kMfma) _Pragma("unroll") for (int i = 0; i < A; ++i)                                       \
+        acc[K][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[K], acc[K][i], 0, 0, 0);
+      MDCV_TAP(1) MDCV_TAP(2) MDCV_TAP(3) MDCV_TAP(4) MDCV_TAP(5) MDCV_TAP(6) MDCV_TAP(7) MDCV_TAP(8)
+#undef MDCV_TAP
     }
   };
 
@@ -186,12 +237,12 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
     if (issued - 1 - t >= D - 1 && D > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (issued < nt) {
-      issue(issued, rho_new);
+    const bool more = issued < nt;
+    step(t, rho0, more, issued, rho_new);
+    if (more) {
       ++issued;
       rho_new = (rho_new + BP) & rmask;
     }
-    compute(t, rho0);
     rho0 = (rho0 + BP) & rmask;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -231,16 +282,19 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
 struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; };
 int g_stream_d = 0;        // tuning hook: force the prefetch depth (1..3); 0 = per-configuration default
 int g_stream_blocks = 0;   // tuning hook: force the target block count; 0 = default
+int g_stream_alt = 0;      // tuning hook: alternative wave grids (A = 2, two blocks per CU) for 32->64 and 64->64
 
 // (Cin, Cout) -> instantiation; false if unsupported
 inline bool stream_cfg(int Cin, int Cout, StreamCfg& c) {
-  if (Cin == 16 && Cout == 16)       c = {1, 1, 1, 8, 256, 1, 9};
-  else if (Cin == 16 && Cout == 32)  c = {1, 2, 2, 8, 256, 1, 9};
-  else if (Cin == 32 && Cout == 32)  c = {2, 2, 2, 4, 128, 1, 9};
-  else if (Cin == 32 && Cout == 64)  c = {2, 4, 4, 4, 128, 1, 3};
-  else if (Cin == 64 && Cout == 64)  c = {4, 4, 4, 2, 64, 1, 3};
-  else if (Cin == 64 && Cout == 128) c = {4, 8, 4, 1, 64, 1, 1};
+  if (Cin == 16 && Cout == 16)       c = {1, 1, 1, 8, 256, 2, 9};
+  else if (Cin == 16 && Cout == 32)  c = {1, 2, 2, 8, 256, 2, 9};
+  else if (Cin == 32 && Cout == 32)  c = {2, 2, 2, 4, 128, 2, 9};
+  else if (Cin == 32 && Cout == 64)  c = {2, 4, 4, 4, 128, 2, 3};
+  else if (Cin == 64 && Cout == 64)  c = {4, 4, 4, 2, 64, 2, 3};
+  else if (Cin == 64 && Cout == 128) c = {4, 8, 4, 1, 64, 2, 1};
   else return false;
+  if (g_stream_alt && Cin == 32 && Cout == 64) c = {2, 4, 2, 2, 128, 2, 3};
+  if (g_stream_alt && Cin == 64 && Cout == 64) c = {4, 4, 2, 1, 64, 2, 3};
   if (g_stream_d >= 1 && g_stream_d <= 3) c.d = g_stream_d;
   return true;
 }
@@ -256,6 +310,13 @@ inline int stream_lds(const StreamCfg& c, int W, int dil) {
   const int ring = (c.d + 1) * c.bp * c.nco * 32 + rs * c.nci * 32;
   const int stage_out = c.nco * 16 * (c.tgrp * c.nci * 16 + 4) * 4;
   return ring > stage_out ? ring : stage_out;
+}
+
+// configuration for a layer geometry: the prefetch depth shrinks until ring + stages fit the 160 KiB of a CU
+inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c) {
+  if (!stream_cfg(Cin, Cout, c)) return false;
+  while (c.d > 1 && stream_lds(c, W, dil) > 160 * 1024) --c.d;
+  return stream_lds(c, W, dil) <= 160 * 1024;
 }
 
 template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP>
@@ -278,9 +339,8 @@ bool mdcv_wgrad_stream_eligible(int dtype, int B, int H, int W, int Cin, int Cou
                                 long long dy_ldc, long long x_ldc) {
   if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != dil || (dil != 1 && dil != 2)) return false;
   StreamCfg c;
-  if (!stream_cfg(Cin, Cout, c)) return false;
   if (H < 4 || W < 4) return false;
-  if (stream_lds(c, W, dil) > 160 * 1024) return false;
+  if (!stream_cfg_geom(Cin, Cout, W, dil, c)) return false;
   const long long Mq = (long long)B * (H + dil) * (W + dil);
   if (Mq + 4096 >= (1LL << 24) || (long long)B * H * W >= (1LL << 24)) return false;          // 24-bit multiplies / float divmod
   if ((long long)B * H * W * dy_ldc * 2 >= (1LL << 31) || (long long)B * H * W * x_ldc * 2 >= (1LL << 31)) return false;
@@ -312,7 +372,7 @@ bool mdcv_wgrad_stream_splits_ok(int splits, int B, int H, int W, int Cin, int C
 int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, int Cin, int Cout,
                       int dil, hipStream_t st) {
   StreamCfg c;
-  if (!stream_cfg(Cin, Cout, c)) return MDCV_EARG;
+  if (!stream_cfg_geom(Cin, Cout, W, dil, c)) return MDCV_EARG;
   WgradStreamArgs a;
   a.dy = dy; a.x = x; a.ws = ws; a.dy_ldc = dy_ldc; a.x_ldc = x_ldc;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Ktot = 9 * Cin; a.dil = dil;
@@ -331,6 +391,10 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
     if (c.d == 2) return launch_stream<NCI, NCO, A, PG, BP, 2, TGRP>(a, lds, dyb, xb, st);        \
     return launch_stream<NCI, NCO, A, PG, BP, 3, TGRP>(a, lds, dyb, xb, st);                      \
   }
+  if (g_stream_alt) {
+    STREAM_CASE(32, 64, 2, 4, 2, 2, 128, 3)
+    STREAM_CASE(64, 64, 4, 4, 2, 1, 64, 3)
+  }
   STREAM_CASE(16, 16, 1, 1, 1, 8, 256, 9)
   STREAM_CASE(16, 32, 1, 2, 2, 8, 256, 9)
   STREAM_CASE(32, 32, 2, 2, 2, 4, 128, 9)
@@ -341,4 +405,4 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   return MDCV_EARG;
 }
 
-void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_d = d; g_stream_blocks = blocks; }
+void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_alt = d >= 4; g_stream_d = d & 3; g_stream_blocks = blocks; }
