@@ -181,43 +181,66 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
     for (int i = 0; i < A; ++i) acc[k][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nt = (p_end - p_begin + BP - 1) / BP;
-  // One step: fragment reads of a sub-step, THEN (after the last sub-step's reads) the DMA of step t+D, then the MFMAs.  The DMA
-  // must come after the step's last LDS read in program order: the compiler drains the LDS-DMA queue (s_waitcnt vmcnt(0)) in front
-  // of any LDS read that follows a DMA in the same iteration, which would serialise fill and compute.
-  auto step = [&](int t, int rho0, bool more, int t_new, int rho_new) {
+  // A sub-step is  reads (A + 9 fragments: address VALU + LDS)  then  9*A MFMAs.  The block's barrier keeps all waves in the same
+  // step, and the two waves that share a SIMD (w and w+4) would read together and multiply together, leaving the MFMA pipe idle
+  // during every read phase.  So waves 4..7 run half a sub-step late: they multiply the fragments they read in the previous slot
+  // first, then read -- one of the pair reads while the other multiplies.  No extra registers: the fragments simply live across
+  // the barrier (the data they were read from may be overwritten afterwards).
+  // The DMA of step t+D is issued after the step's last reads in program order: the compiler drains the LDS-DMA queue
+  // (s_waitcnt vmcnt(0)) in front of any LDS read it can see after a DMA, which would serialise fill and compute.
+  bf16x8_t fa[A], fb[9];
+#pragma unroll
+  for (int i = 0; i < A; ++i) fa[i] = bf16x8_t{};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) fb[k] = bf16x8_t{};
+#ifdef MDCV_WST_NOMFMA
+  constexpr bool kMfma = false;
+#else
+  constexpr bool kMfma = true;
+#endif
+  auto reads = [&](int t, int rho0, int s) {
     const unsigned ystage = (unsigned)((t % (D + 1)) * YSTAGE);
+    const int ks = pg * NSUB + s;
+    const unsigned xs = (unsigned)((rho0 + ks * 32) * RBX);
+#pragma unroll
+    for (int i = 0; i < A; ++i) fa[i] = fragY(ystage + (unsigned)(ks * 32 * RBY), i);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) fb[tap] = fragX(xs, tap);
+  };
+  auto mfmas = [&]() {
+    // reads return in issue order (fa..., fb[0], fb[1], ...): tap k starts as soon as its fragment is in, the rest keeps streaming
+    wait_lds<15>(fa, fb[0]);                               // (the counter has 4 bits)
+    if constexpr (kMfma)
+#pragma unroll
+    for (int i = 0; i < A; ++i) acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[0], acc[0][i], 0, 0, 0);
+#define MDCV_TAP(K)                                                                                            \
+    wait_lds<16 - 2 * K>(fb[K]);                                                                               \
+    if constexpr (kMfma) _Pragma("unroll") for (int i = 0; i < A; ++i)                                         \
+      acc[K][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[K], acc[K][i], 0, 0, 0);
+    MDCV_TAP(1) MDCV_TAP(2) MDCV_TAP(3) MDCV_TAP(4) MDCV_TAP(5) MDCV_TAP(6) MDCV_TAP(7) MDCV_TAP(8)
+#undef MDCV_TAP
+  };
+#ifdef MDCV_WST_NOSKEW
+  const bool late = false;
+#else
+  const bool late = NSUB == 1 && wave >= 4;                  // (two sub-steps per step: the skewed schedule spills)
+#endif
+  auto step = [&](int t, int rho0, bool more, int t_new, int rho_new) {
 #ifdef MDCV_WST_NOCOMPUTE
     if (more) issue(t_new, rho_new);
     return;
 #endif
-#ifdef MDCV_WST_NOMFMA
-    constexpr bool kMfma = false;
-#else
-    constexpr bool kMfma = true;
+    // (the asm reads are invisible to the compiler's LDS-DMA hazard tracking, so the DMA may sit anywhere; it sits where no
+    //  fragment is live, to keep the address arithmetic of the DMA out of the 256-register budget)
+    if (late) mfmas();                                       // the previous slot's fragments (zeros the first time)
+#ifndef MDCV_WST_NODMA
+    if (more) issue(t_new, rho_new);
 #endif
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
-      const int ks = pg * NSUB + s;
-      const unsigned xs = (unsigned)((rho0 + ks * 32) * RBX);
-      bf16x8_t fa[A], fb[9];
-#pragma unroll
-      for (int i = 0; i < A; ++i) fa[i] = fragY(ystage + (unsigned)(ks * 32 * RBY), i);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) fb[tap] = fragX(xs, tap);
-#ifndef MDCV_WST_NODMA
-      if (s == NSUB - 1 && more) issue(t_new, rho_new);
-#endif
-      // reads return in issue order (fa..., fb[0], fb[1], ...): tap k starts as soon as its fragment is in, the rest keeps streaming
-      wait_lds<15>(fa, fb[0]);                               // (the counter has 4 bits)
-      if constexpr (kMfma)
-#pragma unroll
-      for (int i = 0; i < A; ++i) acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[0], acc[0][i], 0, 0, 0);
-#define MDCV_TAP(K)                                                                                            \
-      wait_lds<16 - 2 * K>(fb[K]);                                                                             \
-      if constexpr (kMfma) _Pragma("unroll") for (int i = 0; i < A; ++i)                                       \
-        acc[K][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[K], acc[K][i], 0, 0, 0);
-      MDCV_TAP(1) MDCV_TAP(2) MDCV_TAP(3) MDCV_TAP(4) MDCV_TAP(5) MDCV_TAP(6) MDCV_TAP(7) MDCV_TAP(8)
-#undef MDCV_TAP
+      if (late && s > 0) mfmas();
+      reads(t, rho0, s);
+      if (!late) mfmas();
     }
   };
 
@@ -245,6 +268,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
     }
     rho0 = (rho0 + BP) & rmask;
   }
+  if (late) mfmas();                                         // the last slot of the late waves
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
