@@ -964,6 +964,26 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
+// Transpose read as inline asm (see wgrad_stream.hip): with the builtin, the compiler -- which cannot tell the ring slots apart --
+// puts s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA, so the fill of tile k+1 never overlapped the MFMAs of
+// tile k inside a block.  The asm read is invisible to that hazard pass; the kernels order DMA and reads themselves (barriers,
+// counted vmcnt) and wait for the reads with wait_lds_tr<N>(), whose "+v" operands make the MFMAs depend on the wait.
+template <int OFF> __device__ __forceinline__ s16x4_t lds_tr16_asm(unsigned addr) {
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+template <int N> __device__ __forceinline__ void wait_lds_tr(bf16x8_t& a0) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a0) : "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lds_tr(bf16x8_t& a0, bf16x8_t& a1, bf16x8_t& b0) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a0), "+v"(a1), "+v"(b0) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_lds_tr(bf16x8_t& a0, bf16x8_t& a1, bf16x8_t& a2, bf16x8_t& a3, bf16x8_t& b0) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0) : "n"(N) : "memory");
+}
+
 template <int BP, int STAGES, bool SAME>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsigned dy_bytes, unsigned x_bytes) {
   constexpr int NJ = BP / 16;            // chunks (of 4 pixel rows) per operand per wave per step
@@ -1061,8 +1081,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsign
   auto frag = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {
     const int row0 = ks * 32 + prow;
     const int c = 2 * F + qlo;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 256 + ((c ^ g0) << 4) + sub));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 16) * 256 + ((c ^ g1) << 4) + sub));
+    const unsigned ad = lds_addr(tile) + (unsigned)(row0 * 256 + ((c ^ g0) << 4) + sub);      // the row 16 further down has the same swizzle
+    const s16x4_t lo = lds_tr16_asm<0>(ad);
+    const s16x4_t hi = lds_tr16_asm<16 * 256>(ad);
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
@@ -1084,10 +1105,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsign
       for (int i = 0; i < 4; ++i) fa[i] = frag(sA, ks, wm * 4 + i);
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[j] = frag(sB, ks, wn * 4 + j);
+      // the 16 reads return in order: column j of the 4x4 fragment grid starts as soon as fb[j] is in
+      wait_lds_tr<6>(fa[0], fa[1], fa[2], fa[3], fb[0]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[0], acc[i][0], 0, 0, 0);
+      wait_lds_tr<4>(fb[1]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[1], acc[i][1], 0, 0, 0);
+      wait_lds_tr<2>(fb[2]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[2], acc[i][2], 0, 0, 0);
+      wait_lds_tr<0>(fb[3]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[3], acc[i][3], 0, 0, 0);
     }
   };
   if (STAGES == 2) {
@@ -1379,16 +1409,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   auto fragB = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {
     const int row0 = ks * 32 + prow, c = 2 * F + qlo;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 256 + ((c ^ g0) << 4) + sub));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 16) * 256 + ((c ^ g1) << 4) + sub));
+    const unsigned ad = lds_addr(tile) + (unsigned)(row0 * 256 + ((c ^ g0) << 4) + sub);
+    const s16x4_t lo = lds_tr16_asm<0>(ad);
+    const s16x4_t hi = lds_tr16_asm<16 * 256>(ad);
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
   auto fragA = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {       // 64-byte rows: F selects the 32-byte half,
     const int row0 = ks * 32 + prow;                                             // stored swapped in rows with bit 2 set
     const int col = (F ^ (kq & 1)) * 32 + (t & 3) * 8;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 64 + col));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 16) * 64 + col));
+    const unsigned ad = lds_addr(tile) + (unsigned)(row0 * 64 + col);
+    const s16x4_t lo = lds_tr16_asm<0>(ad);
+    const s16x4_t hi = lds_tr16_asm<16 * 64>(ad);
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
@@ -1409,10 +1441,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
       for (int i = 0; i < 2; ++i) fa[i] = fragA(sA, ks, i);
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[j] = fragB(sB, ks, wave * 2 + j);
+      wait_lds_tr<2>(fa[0], fa[1], fb[0]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[0], acc[i][0], 0, 0, 0);
+      wait_lds_tr<0>(fb[1]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[1], acc[i][1], 0, 0, 0);
     }
   };
   // these layers are HBM-latency-bound (tiny per-step work): keep STAGES-1 steps of DMA in flight (counted vmcnt, raw barrier)

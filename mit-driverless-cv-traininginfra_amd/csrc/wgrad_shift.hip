@@ -40,6 +40,18 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
+template <int OFF> __device__ __forceinline__ s16x4_t lds_tr16_asm(unsigned addr) {
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int N> __device__ __forceinline__ void wait_lds_tr(bf16x8_t& a0, bf16x8_t& a1, bf16x8_t& a2, bf16x8_t& a3, bf16x8_t& b0, bf16x8_t& b1) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_lds_tr(bf16x8_t& b0, bf16x8_t& b1) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(b0), "+v"(b1) : "n"(N) : "memory");
+}
+
 __device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int& r) {   // 0 <= n < 2^24
   q = (int)((float)n * inv);
   r = n - q * d;
@@ -114,8 +126,9 @@ __global__ __launch_bounds__(512) void wgrad3x3_shift_kernel(WgradShiftArgs a, u
   auto frag = [&](const unsigned char* tile, int row0, int F) -> bf16x8_t {   // rows row0 .. row0+3 and row0+16 .. row0+19 of this lane group
     const int c = 2 * F + qlo;
     const int g0 = 2 * (row0 & 7), g1 = g0;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + row0 * 256 + ((c ^ g0) << 4) + sub));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (row0 + 16) * 256 + ((c ^ g1) << 4) + sub));
+    const unsigned ad = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)tile + (unsigned)(row0 * 256 + ((c ^ g0) << 4) + sub);
+    const s16x4_t lo = lds_tr16_asm<0>(ad);                    // asm reads: see conv_igemm.hip (no compiler-forced DMA drain)
+    const s16x4_t hi = lds_tr16_asm<16 * 256>(ad);
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
@@ -138,16 +151,27 @@ __global__ __launch_bounds__(512) void wgrad3x3_shift_kernel(WgradShiftArgs a, u
       bf16x8_t fa[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = frag(sA, ks * 32 + prow, wm * 4 + i);
+      bf16x8_t fb[3][2];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        bf16x8_t fb[2];
+      for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = frag(sB, ks * 32 + prow + kw, wn * 2 + j);
+        for (int j = 0; j < 2; ++j) fb[kw][j] = frag(sB, ks * 32 + prow + kw, wn * 2 + j);
+      // 20 reads in order (fa x4, then the three taps): tap kw starts as soon as its two fragments are in
+      wait_lds_tr<8>(fa[0], fa[1], fa[2], fa[3], fb[0][0], fb[0][1]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[kw][i][j], 0, 0, 0);
-      }
+        for (int j = 0; j < 2; ++j) acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[0][j], acc[0][i][j], 0, 0, 0);
+      wait_lds_tr<4>(fb[1][0], fb[1][1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[1][j], acc[1][i][j], 0, 0, 0);
+      wait_lds_tr<0>(fb[2][0], fb[2][1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[2][j], acc[2][i][j], 0, 0, 0);
     }
   };
   // NSTAGE-deep ring with counted waits (never vmcnt(0) in steady state) and a raw barrier, like conv_glds_kernel
