@@ -1774,7 +1774,8 @@ static bool use_wgrad_shift(int dtype, int B, int Hin, int Win, int Cin, int Hou
   if (g_wgrad_variant == 8) return true;
   const long long Mq = (long long)B * (Hout + 1) * (Wout + 1);
   const int s = mdcv_wgrad_shift_splits(B, Hout, Wout, Cin, Cout);
-  return Mq / (64LL * s) >= 128;
+  if (Mq / (64LL * s) >= 128) return true;
+  return g_wgrad_variant == 11 && mdcv_conv2d_wgrad_splits(dtype, B * Hout * Wout, Cout, KH * KW * Cin) == 1;   // A/B: also the split-less layers
 }
 
 // 16..128-channel 3x3 stride-1 layers (dilation 1 or 2): all nine taps read one activation window kept in an LDS ring
