@@ -66,8 +66,9 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
 int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,
                       int Cout_pad, int Cin_pad, void* stream);
 
-/* all convs of a network in ONE launch; table = nlayers device-resident 64-byte records
- *   { const float* w_oihw; void* w_fwd; void* w_dgrad|NULL; int Cout, Cin, KH*KW, Cout_pad, Cin_pad; int reserved[3]; } */
+/* all convs of a network in ONE launch; table = nlayers device-resident 72-byte records
+ *   { const float* w_oihw; void* w_fwd; void* w_dgrad|NULL; int Cout, Cin, KH*KW, Cout_pad, Cin_pad; int reserved[3];
+ *     const float* bias|NULL; float* bias_padded; }   (bias: the fp32 bias parameter, copied into the padded operand buffer) */
 int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, int max_taps, void* stream);   /* max_taps = max KH*KW (times Cin_pad/64 scaling is internal) */
 
 /* ---- layout conversion at the API edge (reference tensors are NCHW fp32: train.py:60, train_eval.py:60) */

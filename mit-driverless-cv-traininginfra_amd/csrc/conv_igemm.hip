@@ -1534,7 +1534,7 @@ static int launch_wgrad_dma(const WgradArgs& a, unsigned grid, hipStream_t st, u
 }
 
 // all layers in one launch: blockIdx.y selects the layer descriptor, blockIdx.x grid-strides inside it
-struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, KK, Cout_pad, Cin_pad; int pad_[3]; };   // 64 bytes
+struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, KK, Cout_pad, Cin_pad; int pad_[3]; const float* bias; float* bias_pad; };   // 72 bytes
 // Tile = 16 output channels x up to 64 input channels x all taps, read from OIHW as contiguous runs (one run per output
 // channel), transposed through LDS and written as  wf[co][tap][ci .. ci+63]  (128-byte runs) and  wd[ci][tap][co .. co+15].
 // (A plain gather kernel read 17x the parameter bytes: rocprofv3 FETCH_SIZE 4.2 GB for 248 MB of weights.)
@@ -1542,6 +1542,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* __restrict__ table) {
   extern __shared__ float tile[];
   const PackDesc d = table[blockIdx.y];
+  if (blockIdx.x == 0 && d.bias)                          // the layer's fp32 bias parameter -> its padded operand buffer
+    for (int i = threadIdx.x; i < d.Cout; i += 256) d.bias_pad[i] = d.bias[i];
   const float* __restrict__ w = d.w;
   T* __restrict__ wf = reinterpret_cast<T*>(d.wf);
   T* __restrict__ wd = reinterpret_cast<T*>(d.wd);

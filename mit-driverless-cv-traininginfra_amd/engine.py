@@ -231,14 +231,7 @@ class Plan:
         if need_dgrad and cs.wd is None:
             cs.wd = torch.zeros(cs.cin_pad * cs.kh * cs.kw * cs.cout_pad, dtype=self.tdtype, device=self.device)
         self.pack_list.append(cs)
-        if cs.bias is not None:
-            bp, b = cs.bias_pad, cs.bias
-
-            def copy_bias(stream, bp=bp, b=b, n=cs.cout):
-                bp[:n].copy_(b.detach().reshape(-1), non_blocking=True)
-                return 0
-            copy_bias.__name__ = "copy_bias"
-            self.fwd.append((copy_bias, ()))
+        # (the fp32 bias goes to its padded operand buffer inside the same table-driven pack launch)
 
     def stats_rows(self, cs, x, y):
         """rows of the BatchNorm partial-statistics buffer the forward conv of this geometry writes"""
@@ -283,12 +276,8 @@ class Plan:
 
     def emit_bias_grad(self, cs, dy, zero_only=False):
         gb = self.param_grad(cs.bias)
-        if zero_only:   # bias in front of a BatchNorm: its gradient is identically zero
-            def zero(stream, gb=gb):
-                gb.zero_()
-                return 0
-            zero.__name__ = "zero_bias_grad"
-            self.bwd.append((zero, ()))
+        if zero_only:   # bias in front of a BatchNorm: its gradient is identically zero.  Nothing in the backward list
+            gb.zero_()  # writes this buffer, so it is zeroed once here instead of once per step (zero_grad / all-reduce keep it zero)
             return
         tmp = self.f32(cs.cout_pad)
         pws = self.f32(int(self.L.colsum_ws_floats(self.dtype, dy.M, cs.cout_pad)), zero=False)
@@ -390,8 +379,10 @@ class Plan:
 
     def finish_pack(self, position=0):
         import struct
-        rec = b"".join(struct.pack("<QQQiiiiiiii", cs.weight.data_ptr(), cs.wf.data_ptr(), cs.wd.data_ptr() if cs.wd is not None else 0,
-                                   cs.cout, cs.cin, cs.kh * cs.kw, cs.cout_pad, cs.cin_pad, 0, 0, 0) for cs in self.pack_list)
+        rec = b"".join(struct.pack("<QQQiiiiiiiiQQ", cs.weight.data_ptr(), cs.wf.data_ptr(), cs.wd.data_ptr() if cs.wd is not None else 0,
+                                   cs.cout, cs.cin, cs.kh * cs.kw, cs.cout_pad, cs.cin_pad, 0, 0, 0,
+                                   cs.bias.data_ptr() if cs.bias is not None else 0,
+                                   cs.bias_pad.data_ptr() if cs.bias is not None else 0) for cs in self.pack_list)
         table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.device)
         self.keep.append(table)
         # LDS tile of the pack kernel: 16 x (min(64, Cin_pad) x taps + 1) floats; express it as "taps at 64 input channels"
