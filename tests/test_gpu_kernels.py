@@ -622,3 +622,58 @@ def test_wgrad_stream_kernel(case):
         assert np.isfinite(got).all(), v
         np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * scale, err_msg=f"variant {v} splits {splits}")
     np.testing.assert_allclose(outs[0][0], outs[9][0], rtol=1e-3, atol=1e-3 * scale)      # same bf16 products, fp32 sums in another order
+
+
+@pytest.mark.parametrize("case", [(2, 32, 64, 20, 13, 1), (1, 16, 16, 9, 31, 2), (3, 64, 128, 16, 16, 1)], ids=str)
+def test_wgrad_stream_kernel_channel_slices(case):
+    """The LDS-ring weight gradient on operands that are channel slices of wider NHWC buffers (route / concat buffers: ldc > C,
+    base pointer inside a pixel row) == the generic kernel on the same slices == torch."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, Co, H, W, dil = case
+    g = torch.Generator().manual_seed(11 * Ci + Co + W)
+    xw = torch.randn(B, Ci + 24, H, W, generator=g)           # x lives at channels 8 .. 8+Ci of a wider buffer
+    dyw = torch.randn(B, Co + 16, H, W, generator=g)          # dy at channels 16 .. 16+Co
+    x, dy = xw[:, 8:8 + Ci], dyw[:, 16:16 + Co]
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(rnd(dt, x), w, None, stride=1, padding=dil, dilation=dil).backward(rnd(dt, dy))
+    ref = w.grad.numpy()
+    xb, dyb = to_nhwc(xw, dt), to_nhwc(dyw, dt)
+    xl, dyl = xb.shape[-1], dyb.shape[-1]
+    xp, dyp = xb.data_ptr() + 8 * 2, dyb.data_ptr() + 16 * 2
+    outs = {}
+    for variant in (0, 9):
+        L.conv2d_wgrad_set_variant(variant)
+        try:
+            splits = L.conv2d_wgrad_splits_geom(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, dil, dil, dyl, xl)
+            ws = torch.full((splits * Co * 9 * Ci,), float("nan"), dtype=torch.float32, device="cuda")
+            dw = torch.full((Co, Ci, 3, 3), 7.0, dtype=torch.float32, device="cuda")
+            L.check(L.conv2d_wgrad(dt, dyp, dyl, xp, xl, ws.data_ptr(), splits, dw.data_ptr(), 0, B, H, W, Ci, Ci,
+                                   H, W, Co, Co, 3, 3, 1, dil, dil, st()), "wgrad")
+            torch.cuda.synchronize()
+            outs[variant] = dw.cpu().numpy()
+        finally:
+            L.conv2d_wgrad_set_variant(0)
+    scale = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(outs[0], ref, rtol=2e-2, atol=2e-2 * scale)
+    np.testing.assert_allclose(outs[0], outs[9], rtol=1e-3, atol=1e-3 * scale)
+
+
+def test_wgrad_stream_accumulate_and_determinism():
+    """accumulate=1 adds to the existing gradient; two runs give bit-identical results (fixed-order slab and wave sums)."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, Co, H, W, dil = 4, 32, 32, 40, 40, 1
+    g = torch.Generator().manual_seed(5)
+    xb, dyb = to_nhwc(torch.randn(B, Ci, H, W, generator=g), dt), to_nhwc(torch.randn(B, Co, H, W, generator=g), dt)
+    splits = L.conv2d_wgrad_splits_geom(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, dil, dil, Co, Ci)
+    ws = torch.empty(splits * Co * 9 * Ci, dtype=torch.float32, device="cuda")
+    res = []
+    for acc, init in ((0, 3.0), (0, -1.0), (1, 2.5)):
+        dw = torch.full((Co, Ci, 3, 3), init, dtype=torch.float32, device="cuda")
+        L.check(L.conv2d_wgrad(dt, dyb.data_ptr(), Co, xb.data_ptr(), Ci, ws.data_ptr(), splits, dw.data_ptr(), acc, B, H, W, Ci, Ci,
+                               H, W, Co, Co, 3, 3, 1, dil, dil, st()), "wgrad")
+        torch.cuda.synchronize()
+        res.append(dw.cpu().numpy())
+    assert np.array_equal(res[0], res[1])
+    np.testing.assert_allclose(res[2], res[0] + 2.5, rtol=1e-6, atol=1e-5)
