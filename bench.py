@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+OPT_PIPELINE = os.environ.get("MDCV_OPT_PIPELINE", "1") == "1"   # FusedAdam(pipeline=True): see mdcv/optim.py
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 YOLO_TRAIN_GFLOP_PER_IMG = 197.59   # SURVEY.md §8d (conv only, fwd+dgrad+wgrad, classes=80, 416^2)
 REKT_TRAIN_GFLOP_PER_IMG = 11.872   # head conv counted once
@@ -304,7 +305,7 @@ def main():
         finally:
             os.chdir(cwd)
         net = net.to(device).train()
-        opt = FusedAdam(net, lr=1e-3)
+        opt = FusedAdam(net, lr=1e-3, pipeline=OPT_PIPELINE)      # update + re-pack run under the next forward's first layers
         red = GradAllReducer.attach(net, bucket_mb=32.0)       # RCCL all-reduce of finished buckets overlaps the rest of backward
         g = torch.Generator().manual_seed(1000 + rank)         # rank-seeded shard of the global batch
         B = a.yolo_batch
@@ -357,7 +358,7 @@ def main():
         kp = KeypointNet(7, (80, 80), precision=a.precision).to(device).train()
         with contextlib.redirect_stdout(sys.stderr):           # the reference's constructor prints its configuration
             crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
-        opt = FusedAdam(kp, lr=0.1)
+        opt = FusedAdam(kp, lr=0.1, pipeline=OPT_PIPELINE)
         red = GradAllReducer.attach(kp, bucket_mb=32.0)
         g = torch.Generator().manual_seed(2000 + rank)
         B = a.rekt_batch
@@ -498,7 +499,7 @@ def main():
                                     "joint": "YOLOv3 608x608 eval -> conf/NMS -> <=16 crops/frame 80x80 -> KeypointNet eval, %d frames/GPU"
                                              % a.joint_batch}[primary],
                        "global_batch": {"yolo": a.yolo_batch, "rektnet": a.rekt_batch, "postprocess": a.post_batch, "joint": a.joint_batch}[primary] * world,
-                       "parallelism": f"dp{world}", "hipgraph": bool(a.graph)},
+                       "parallelism": f"dp{world}", "hipgraph": bool(a.graph), "optimizer": "FusedAdam" + (" (pipelined under the next forward)" if OPT_PIPELINE else "")},
             "workloads": extra,
         }
         if "roofline" in result:

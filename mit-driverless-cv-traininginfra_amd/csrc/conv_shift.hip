@@ -282,8 +282,10 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 #pragma unroll
       for (int w2 = 0; w2 < WPG; ++w2) { s += sstat[((g * WPG + w2) * 2 + 0) * BN + col]; qq += sstat[((g * WPG + w2) * 2 + 1) * BN + col]; }
       const size_t srow = (size_t)(p0 / GR) + g;
-      a.stats[(srow * 2 + 0) * a.Nout + n] = s;
-      a.stats[(srow * 2 + 1) * a.Nout + n] = qq;
+      if (srow * GR < (size_t)a.Mq) {                       // the last tile may reach past the stream: the caller holds ceil(Mq/GR) rows
+        a.stats[(srow * 2 + 0) * a.Nout + n] = s;           // (an unguarded second row of the last 256-row tile wrote 2*Nout floats past
+        a.stats[(srow * 2 + 1) * a.Nout + n] = qq;          //  the buffer whenever ceil(Mq/128) was odd, e.g. batch 32 at 52/26/13)
+      }
     }
   }
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
           fz.add(a.fuse, x, yq[u]);
         }
       }
-      fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (p0 + g0) >> 7);
+      if (p0 + g0 < a.Mq) fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (p0 + g0) >> 7);   // block-uniform: rows past the stream do not exist
     }
   }
 #if defined(MDCV_SHIFT_TS) || defined(MDCV_SHIFT_WG)

@@ -18,6 +18,9 @@ from . import _lib
 from ._lib import F32, BF16, ACT_NONE, ACT_LEAKY, ACT_RELU  # noqa: F401
 
 
+_POISON = os.environ.get("MDCV_POISON", "0") == "1"     # debug: NaN-fill every uninitialised plan buffer (finds reads of unwritten memory)
+
+
 def pad8(c):
     return (c + 7) // 8 * 8
 
@@ -111,6 +114,13 @@ class Plan:
         self.bytes = 0
         self.graph_fwd = self.graph_bwd = None
         self.pack_list = []
+        self.layer_marks = []              # forward-list position where each packed layer's launches begin
+        self.param_groups = None           # pipelined parameter update (optim.py): [(lo, hi, first_layer, nlayers)] in forward order
+        self._group_events = []            # one "parameters + packed operands of group k are final" event per group, or None
+        self._pending_updates = []         # deferred group updates (closures), launched from the forward list
+        self._packed_ahead = False         # the optimizer already re-packed every layer for the coming forward
+        self._packed_version = -1
+        self.owner = None                  # the model (FlatParamsMixin) whose parameters this plan reads
         self.grad_offset = None            # callable(param) -> offset in the flat gradient buffer
         self.low_water = 1 << 62
         self._last_mark = 1 << 62
@@ -122,12 +132,16 @@ class Plan:
     def new_act(self, B, H, W, C, zero=False):
         Cp = pad8(C)
         buf = (torch.zeros if zero else torch.empty)(B * H * W * Cp, dtype=self.tdtype, device=self.device)
+        if not zero and _POISON:
+            buf.fill_(float("nan"))
         self.keep.append(buf)
         self.bytes += buf.numel() * buf.element_size()
         return Act(buf, B, H, W, Cp, Cp)
 
     def f32(self, n, zero=True):
         t = (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.device)
+        if not zero and _POISON:
+            t.fill_(float("nan"))
         self.keep.append(t)
         return t
 
@@ -231,6 +245,7 @@ class Plan:
         if need_dgrad and cs.wd is None:
             cs.wd = torch.zeros(cs.cin_pad * cs.kh * cs.kw * cs.cout_pad, dtype=self.tdtype, device=self.device)
         self.pack_list.append(cs)
+        self.layer_marks.append(len(self.fwd))
         # (the fp32 bias goes to its padded operand buffer inside the same table-driven pack launch)
 
     def stats_rows(self, cs, x, y):
@@ -387,7 +402,70 @@ class Plan:
         self.keep.append(table)
         # LDS tile of the pack kernel: 16 x (min(64, Cin_pad) x taps + 1) floats; express it as "taps at 64 input channels"
         eq_taps = max(1, max((min(64, cs.cin_pad) * cs.kh * cs.kw + 63) // 64 for cs in self.pack_list))
-        self.fwd.insert(position, (self.L.pack_weights_batched, (self.dtype, table.data_ptr(), len(self.pack_list), eq_taps)))
+        self.pack_table, self.pack_eq_taps = table, eq_taps
+        plan = self
+        args = (self.dtype, table.data_ptr(), len(self.pack_list), eq_taps)
+
+        def pack_all(stream):
+            owner = plan.owner
+            if plan._packed_ahead:                       # the optimizer packed every layer behind its update (optim.py, pipeline=True);
+                plan._packed_ahead = False               # the per-group waits further down this list order the forward behind it
+                if owner is None or owner._pflat._version == plan._packed_version:
+                    return 0
+            if owner is not None:
+                owner._param_sync()
+            return plan.L.pack_weights_batched(*args, stream)
+        pack_all.__name__ = "mdcv_pack_weights_batched"
+        self.fwd.insert(position, (pack_all, ()))
+        self.layer_marks = [m + 1 if m >= position else m for m in self.layer_marks]
+
+    def launch_param_group(self, k, gated):
+        """Enqueue a deferred group update (closure left by the optimizer).  gated: the parameter stream first waits for the
+        point the current stream has reached."""
+        if 0 <= k < len(self._pending_updates) and self._pending_updates[k] is not None:
+            fn, self._pending_updates[k] = self._pending_updates[k], None
+            fn(torch.cuda.current_stream() if gated else None)
+
+    def ensure_param_groups(self, pflat):
+        """Cuts the flat parameter buffer into a few forward-ordered groups of whole layers (small first, so the next forward can
+        start at once) and plants a `wait_params(k)` in the forward list in front of each group's first layer.  Returns
+        [(lo, hi, first_layer, nlayers)] or [] when the layout does not allow it."""
+        if self.param_groups is not None:
+            return self.param_groups
+        self.param_groups = []
+        base, n = pflat.data_ptr(), pflat.numel()
+        offs = [(cs.weight.data_ptr() - base) // 4 for cs in self.pack_list]
+        if not offs or any(o < 0 or o >= n for o in offs) or any(b <= a for a, b in zip(offs, offs[1:])):
+            return self.param_groups
+        firsts, target, lo = [0], 128 * 1024, 0           # 0.5 MB, then x4 per group up to 48 MB
+        for li in range(1, len(offs)):
+            if offs[li] - lo >= target:
+                firsts.append(li)
+                lo = offs[li]
+                target = min(target * 4, 12 * 1024 * 1024)
+        groups = []
+        for gi, f in enumerate(firsts):
+            last = firsts[gi + 1] if gi + 1 < len(firsts) else len(offs)
+            groups.append((0 if gi == 0 else offs[f], offs[last] if last < len(offs) else n, f, last - f))
+        self._group_events = [None] * len(groups)
+        self._pending_updates = [None] * len(groups)
+        plan = self
+        for k in range(len(groups) - 1, -1, -1):            # descending positions: earlier insert points stay valid
+            def wait_params(stream, k=k):
+                plan.launch_param_group(k, gated=False)      # (normally launched two groups earlier, below)
+                ev = plan._group_events[k]
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
+                    plan._group_events[k] = None
+                # start the update of group k+2 once the forward is HERE on the GPU: the early layers are HBM-bound like the
+                # optimizer, the 52x52 .. 13x13 layers whose parameters make up the bulk are MFMA-bound -- the update of a late
+                # group should run under those, not under the first layers
+                plan.launch_param_group(k + 2, gated=True)
+                return 0
+            wait_params.__name__ = "wait_params"
+            self.fwd.insert(self.layer_marks[groups[k][2]], (wait_params, ()))
+        self.param_groups = groups
+        return groups
 
     # ------------------------------------------------------------------ hipGraph capture of the launch lists
     def capture(self, which, stream=None):

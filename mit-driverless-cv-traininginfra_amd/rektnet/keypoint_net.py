@@ -75,6 +75,7 @@ class KeypointNet(nn.Module, FlatParamsMixin):
         self.precision = parse_precision(precision if precision is not None else os.environ.get("MDCV_PRECISION", "bf16"))
         self.use_graph = os.environ.get("MDCV_GRAPH", "0") == "1"
         self._plans = {}
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._param_sync())   # a pipelined optimizer step may be in flight
 
     def _initialize_weights(self):
         """kaiming-normal (fan_out, relu) conv weights, zero biases, BN weight 1 / bias 0 (reference :33-44)."""

@@ -324,9 +324,24 @@ class FlatParamsMixin:
         """(flat fp32 parameter buffer, flat fp32 gradient buffer) — what FusedAdam / the all-reduce operate on."""
         if not self._flat_ok():
             self._flatten()
+        self._param_sync()
         return self._pflat, self._gflat
 
+    def _param_sync(self):
+        """Orders the current stream behind a pipelined optimizer step (optim.py, pipeline=True) that may still be updating
+        parameter groups on the parameter stream.  Every reader of the parameters outside the pipelined forward goes through here."""
+        plan = getattr(self, "_pipe_plan", None)
+        if plan is None:
+            return
+        for k in range(len(plan._pending_updates)):
+            plan.launch_param_group(k, gated=False)
+        for k, ev in enumerate(plan._group_events):
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+                plan._group_events[k] = None
+
     def _run_backward(self, plan, gout):
+        self._last_train_plan = plan
         pl = self._plist
         keep = None
         if pl[0].grad is not None:                       # gradients were not reset to None: accumulate semantics
@@ -381,6 +396,7 @@ class Darknet(nn.Module, FlatParamsMixin):
         self.precision = parse_precision(precision if precision is not None else os.environ.get("MDCV_PRECISION", "bf16"))
         self.use_graph = os.environ.get("MDCV_GRAPH", "0") == "1"
         self._plans = {}
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._param_sync())   # a pipelined optimizer step may be in flight
 
     # ---- getters consumed by train.py / validate.py / detect.py (reference models.py:279-310)
     def get_start_weight_dim(self): return self.start_weights_dim
@@ -735,6 +751,7 @@ class Darknet(nn.Module, FlatParamsMixin):
                     pos += per * wide
 
     def save_weights(self, path, cutoff=-1):
+        self._param_sync()
         with open(path, "wb") as fp:
             self.header_info[3] = self.seen
             np.asarray(self.header_info, dtype=np.int32).tofile(fp)

@@ -573,3 +573,66 @@ def test_mini_darknet_with_fused_bn_backward_sums(monkeypatch):
     assert abs(outs[True][0] - outs[False][0]) <= 1e-6 * abs(outs[False][0])
     g0, g1 = outs[False][1], outs[True][1]
     assert float((g0 - g1).abs().max()) <= 2e-4 * float(g0.abs().max())
+
+
+def _train_steps(make_model, make_batch, pipeline, steps, lr):
+    from mdcv.optim import FusedAdam
+    torch.manual_seed(3)
+    model = make_model()
+    opt = FusedAdam(model, lr=lr, pipeline=pipeline)
+    losses = []
+    for i in range(steps):
+        opt.zero_grad()
+        loss = make_batch(model, i)
+        loss.backward()
+        opt.step()
+        if i == 2:                                   # an eval forward between steps reads the parameters through another plan
+            model.eval()
+            with torch.no_grad():
+                make_batch(model, i, eval_only=True)
+            model.train()
+        losses.append(float(loss))
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    return losses, sd
+
+
+def test_pipelined_adam_is_bit_identical_keypointnet():
+    """FusedAdam(pipeline=True) — update + re-pack in forward-ordered groups on a parameter stream, next forward waits group by
+    group — gives bit-identical losses and parameters to the plain single-launch step (same arithmetic, different stream)."""
+    from mdcv.rektnet.keypoint_net import KeypointNet
+    from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.rand(8, 3, 80, 80, generator=g).cuda() for _ in range(6)]
+    tp = torch.rand(8, 7, 2, generator=g).cuda() * 0.9
+    thm = torch.rand(8, 7, 80, 80, generator=g).cuda()
+
+    def batch(model, i, eval_only=False):
+        hm, pts = model(xs[i])
+        if eval_only:
+            return None
+        return crit(hm, pts, thm, tp)[2]
+    res = [_train_steps(lambda: KeypointNet(7, (80, 80), precision="bf16").cuda().train(), batch, pipe, 6, 1e-2) for pipe in (False, True)]
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_pipelined_adam_is_bit_identical_mini_darknet():
+    z = load("mini_darknet.npz")
+    g = torch.Generator().manual_seed(4)
+    x0 = T(z["x"])
+    xs = [(x0 * 0.5 + 0.5 * torch.rand(x0.shape, generator=g)).cuda() for _ in range(6)]
+    tg = T(z["targets"]).cuda()
+
+    def batch(model, i, eval_only=False):
+        if eval_only:
+            model(xs[i])
+            return None
+        return model(xs[i], tg)[0].sum()
+    res = [_train_steps(lambda: make_mini("bf16").train(), batch, pipe, 6, 1e-3) for pipe in (False, True)]
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
