@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-OPT_PIPELINE = os.environ.get("MDCV_OPT_PIPELINE", "1") == "1"   # FusedAdam(pipeline=True): see mdcv/optim.py
+OPT_PIPELINE = os.environ.get("MDCV_OPT_PIPELINE", "0") == "1"   # FusedAdam(pipeline=True), see mdcv/optim.py: bit-identical, measured neutral -> off
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 YOLO_TRAIN_GFLOP_PER_IMG = 197.59   # SURVEY.md §8d (conv only, fwd+dgrad+wgrad, classes=80, 416^2)
 REKT_TRAIN_GFLOP_PER_IMG = 11.872   # head conv counted once

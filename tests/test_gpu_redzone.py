@@ -1,0 +1,84 @@
+"""Memory-safety checks on the GPU: every output / scratch buffer of the conv kernels is allocated with a sentinel-filled guard
+region behind it; a kernel that writes one element past what the C-ABI size queries promise fails here.  (Found in round 1: the
+shift conv's last 256-row tile wrote a second BatchNorm partial row past the buffer whenever ceil(positions/128) was odd.)"""
+import numpy as np
+import pytest
+import torch
+
+from mdcv import _lib
+
+pytestmark = pytest.mark.gpu
+BF16 = _lib.BF16
+SENT = 24680.0
+GUARD = 8192
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def guarded(n, dtype):
+    t = torch.full((n + GUARD,), SENT, dtype=dtype, device="cuda")
+    return t
+
+
+def check(t, n, what):
+    tail = t[n:]
+    bad = int((tail != SENT).sum())
+    assert bad == 0, f"{what}: {bad} elements written past the end"
+
+
+# (B, H, W, Cin, Cout, k, stride, dil): odd and even partial-row counts, every kernel family (shift / glds / narrow / stream / kh-shared)
+GEOMS = [(32, 13, 13, 512, 1024, 3, 1, 1), (3, 52, 52, 128, 256, 3, 1, 1), (5, 26, 26, 256, 512, 3, 1, 1), (7, 13, 13, 128, 128, 3, 1, 1),
+         (3, 26, 26, 128, 256, 3, 2, 1), (2, 31, 29, 64, 32, 1, 1, 1), (3, 40, 40, 16, 16, 3, 1, 2), (2, 33, 20, 32, 64, 3, 1, 2),
+         (3, 80, 80, 64, 64, 3, 1, 1), (1, 17, 23, 64, 128, 3, 1, 1), (2, 19, 19, 128, 128, 3, 1, 1), (1, 64, 64, 8, 32, 3, 1, 1),
+         (9, 9, 11, 128, 256, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("geom", GEOMS, ids=str)
+def test_conv_kernels_stay_inside_their_buffers(geom):
+    L = _lib.lib()
+    B, H, W, Ci, Co, k, s, dil = geom
+    pad = dil * (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // s + 1, (W + 2 * pad - dil * (k - 1) - 1) // s + 1
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(B * H * W * Ci, device="cuda", generator=g).to(torch.bfloat16)
+    dy = torch.randn(B * Ho * Wo * Co, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(Co, Ci, k, k, device="cuda", generator=g) * 0.05
+    wf = torch.zeros(Co * k * k * Ci, dtype=torch.bfloat16, device="cuda")
+    wd = torch.zeros(Ci * k * k * Co, dtype=torch.bfloat16, device="cuda")
+    L.check(L.pack_weights(BF16, w.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, k, Co, Ci, st()), "pack")
+    # forward + BatchNorm partial rows
+    rows = L.conv2d_stats_rows_geom(BF16, B, Ho, Wo, Ci, Co, k, k, s, pad, dil, Ci)
+    ny, ns = B * Ho * Wo * Co, rows * 2 * Co
+    y, stt = guarded(ny, torch.bfloat16), guarded(ns, torch.float32)
+    L.check(L.conv2d(BF16, 0, x.data_ptr(), Ci, wf.data_ptr(), y.data_ptr(), Co, None, None, 0, stt.data_ptr(), B, H, W, Ci, Ho, Wo, Co,
+                     k, k, s, pad, dil, st()), "conv fwd")
+    torch.cuda.synchronize()
+    check(y, ny, "forward output"); check(stt, ns, "BatchNorm partial rows")
+    assert int((stt[:ns] == SENT).sum()) == 0, "a promised partial row was not written"
+    # the partial rows sum to the column sums of the output
+    ysum = y[:ny].float().reshape(-1, Co).sum(0).cpu().numpy()
+    psum = stt[:ns].reshape(rows, 2, Co)[:, 0].sum(0).cpu().numpy()
+    np.testing.assert_allclose(psum, ysum, rtol=2e-2, atol=2e-2 * max(1.0, float(np.abs(ysum).max())))
+    # data gradient
+    nx = B * H * W * Ci
+    dx = guarded(nx, torch.bfloat16)
+    L.check(L.conv2d(BF16, 1, dy.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, None, None, 0, None, B, Ho, Wo, Co, H, W, Ci,
+                     k, k, s, pad, dil, st()), "conv dgrad")
+    torch.cuda.synchronize()
+    check(dx, nx, "data gradient")
+    # weight gradient: every kernel the dispatch can pick
+    for variant in (0, 8, 9):
+        L.conv2d_wgrad_set_variant(variant)
+        try:
+            splits = L.conv2d_wgrad_splits_geom(BF16, B, H, W, Ci, Ho, Wo, Co, k, k, s, pad, dil, Co, Ci)
+            nws, ndw = splits * Co * k * k * Ci, Co * Ci * k * k
+            ws, dw = guarded(nws, torch.float32), guarded(ndw, torch.float32)
+            L.check(L.conv2d_wgrad(BF16, dy.data_ptr(), Co, x.data_ptr(), Ci, ws.data_ptr(), splits, dw.data_ptr(), 0, B, H, W, Ci, Ci,
+                                   Ho, Wo, Co, Co, k, k, s, pad, dil, st()), "wgrad")
+            torch.cuda.synchronize()
+            check(ws, nws, f"wgrad slabs (variant {variant})"); check(dw, ndw, f"weight gradient (variant {variant})")
+            assert torch.isfinite(dw[:ndw]).all()
+        finally:
+            L.conv2d_wgrad_set_variant(0)
