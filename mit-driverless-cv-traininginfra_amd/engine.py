@@ -19,6 +19,21 @@ from ._lib import F32, BF16, ACT_NONE, ACT_LEAKY, ACT_RELU  # noqa: F401
 
 
 _POISON = os.environ.get("MDCV_POISON", "0") == "1"     # debug: NaN-fill every uninitialised plan buffer (finds reads of unwritten memory)
+_REDZONE = int(os.environ.get("MDCV_REDZONE", "0"))     # debug: this many sentinel bytes behind every plan buffer; Plan.check_redzones()
+_RZ_BYTE = 0xA5
+
+
+def _alloc(n, dtype, device, zero, plan):
+    """Plan buffer of n elements; in redzone mode it is the front of a larger allocation whose tail holds a byte pattern."""
+    if not _REDZONE:
+        return (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=device)
+    es = torch.empty(0, dtype=dtype).element_size()
+    raw = torch.full((n * es + _REDZONE,), _RZ_BYTE, dtype=torch.uint8, device=device)
+    t = raw[:n * es].view(dtype)
+    if zero:
+        t.zero_()
+    plan.__dict__.setdefault("redzones", []).append((raw, n * es))
+    return t
 
 
 def pad8(c):
@@ -72,11 +87,11 @@ class ConvSpec:
         self.cin_pad = cin_pad if cin_pad is not None else pad8(self.cin)
         self.ktot = self.kh * self.kw * self.cin_pad
         dt = plan.tdtype
-        self.wf = torch.zeros(self.cout_pad * self.ktot, dtype=dt, device=plan.device)
+        self.wf = _alloc(self.cout_pad * self.ktot, dt, plan.device, True, plan)
         self.wd = None
         self.bias_pad = None
         if bias is not None:
-            self.bias_pad = torch.zeros(self.cout_pad, dtype=torch.float32, device=plan.device)
+            self.bias_pad = _alloc(self.cout_pad, torch.float32, plan.device, True, plan)
         plan.keep.append(self)     # the launch lists hold raw device pointers: the plan must own every buffer
 
     def out_hw(self, H, W):
@@ -90,10 +105,10 @@ class BnSpec:
         C = bn.num_features
         self.C = C
         dev = plan.device
-        z = lambda n=C: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
+        z = lambda n=C: _alloc(n, torch.float32, dev, True, plan)  # noqa: E731
         self.scale, self.shift, self.mean, self.invstd = z(), z(), z(), z()
         self.cA, self.cB, self.cC = z(), z(), z()
-        self.accum = torch.zeros(3 * C, dtype=torch.float64, device=dev)
+        self.accum = _alloc(3 * C, torch.float64, dev, True, plan)
         plan.keep.append(self)
 
 
@@ -114,6 +129,7 @@ class Plan:
         self.bytes = 0
         self.graph_fwd = self.graph_bwd = None
         self.pack_list = []
+        self.__dict__.setdefault("redzones", [])       # (raw uint8 allocation, payload bytes) in MDCV_REDZONE mode
         self.layer_marks = []              # forward-list position where each packed layer's launches begin
         self.param_groups = None           # pipelined parameter update (optim.py): [(lo, hi, first_layer, nlayers)] in forward order
         self._group_events = []            # one "parameters + packed operands of group k are final" event per group, or None
@@ -131,7 +147,7 @@ class Plan:
     # ------------------------------------------------------------------ buffers
     def new_act(self, B, H, W, C, zero=False):
         Cp = pad8(C)
-        buf = (torch.zeros if zero else torch.empty)(B * H * W * Cp, dtype=self.tdtype, device=self.device)
+        buf = _alloc(B * H * W * Cp, self.tdtype, self.device, zero, self)
         if not zero and _POISON:
             buf.fill_(float("nan"))
         self.keep.append(buf)
@@ -139,7 +155,7 @@ class Plan:
         return Act(buf, B, H, W, Cp, Cp)
 
     def f32(self, n, zero=True):
-        t = (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=self.device)
+        t = _alloc(n, torch.float32, self.device, zero, self)
         if not zero and _POISON:
             t.fill_(float("nan"))
         self.keep.append(t)
@@ -175,7 +191,7 @@ class Plan:
 
     def wgrad_ws(self):
         if self._ws is None or self._ws.numel() < self.ws_floats:
-            self._ws = torch.empty(max(self.ws_floats, 1), dtype=torch.float32, device=self.device)
+            self._ws = _alloc(max(self.ws_floats, 1), torch.float32, self.device, False, self)
         return self._ws
 
     # ------------------------------------------------------------------ launch lists
@@ -243,7 +259,7 @@ class Plan:
         """Registers the conv for the per-step weight re-layout; all layers are packed by ONE table-driven launch that
         `finish_pack()` places at the head of the forward list."""
         if need_dgrad and cs.wd is None:
-            cs.wd = torch.zeros(cs.cin_pad * cs.kh * cs.kw * cs.cout_pad, dtype=self.tdtype, device=self.device)
+            cs.wd = _alloc(cs.cin_pad * cs.kh * cs.kw * cs.cout_pad, self.tdtype, self.device, True, self)
         self.pack_list.append(cs)
         self.layer_marks.append(len(self.fwd))
         # (the fp32 bias goes to its padded operand buffer inside the same table-driven pack launch)
@@ -418,6 +434,14 @@ class Plan:
         pack_all.__name__ = "mdcv_pack_weights_batched"
         self.fwd.insert(position, (pack_all, ()))
         self.layer_marks = [m + 1 if m >= position else m for m in self.layer_marks]
+
+    def check_redzones(self):
+        """MDCV_REDZONE mode: number of plan buffers whose guard bytes were overwritten (0 = every kernel stayed inside)."""
+        bad = 0
+        for raw, n in self.redzones:
+            if int((raw[n:] != _RZ_BYTE).sum()):
+                bad += 1
+        return bad
 
     def launch_param_group(self, k, gated):
         """Enqueue a deferred group update (closure left by the optimizer).  gated: the parameter stream first waits for the

@@ -82,3 +82,78 @@ def test_conv_kernels_stay_inside_their_buffers(geom):
             assert torch.isfinite(dw[:ndw]).all()
         finally:
             L.conv2d_wgrad_set_variant(0)
+
+
+def _full_step_redzones(monkeypatch, build, step):
+    from mdcv import engine
+    monkeypatch.setattr(engine, "_REDZONE", 4096)
+    model = build()
+    for _ in range(2):
+        step(model)
+    torch.cuda.synchronize()
+    plans = list(model._plans.values())
+    assert plans and all(p.redzones for p in plans)
+    return sum(p.check_redzones() for p in plans), sum(len(p.redzones) for p in plans)
+
+
+def test_yolov3_train_step_stays_inside_every_plan_buffer(monkeypatch, tmp_path):
+    """Full yolo_baseline at 416x416, batch 32 (odd partial-row counts at 52/26/13), forward + backward + FusedAdam: the guard
+    bytes behind every activation / gradient / statistics / operand / scratch buffer of the plan are intact."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mdcv.yolo.models import Darknet
+    from mdcv.optim import FusedAdam
+    cfg = bench.write_yolo_cfg(str(tmp_path))
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(32, 3, 416, 416, generator=g).cuda()
+    tg = bench.synth_targets(32, 16, g).cuda()
+    state = {}
+
+    def build():
+        cwd = os.getcwd()
+        os.chdir(tmp_path)
+        try:
+            torch.manual_seed(0)
+            net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
+        finally:
+            os.chdir(cwd)
+        state["opt"] = FusedAdam(net, lr=1e-3)
+        return net
+
+    def step(net):
+        state["opt"].zero_grad()
+        net(x, tg)[0].sum().backward()
+        state["opt"].step()
+    bad, n = _full_step_redzones(monkeypatch, build, step)
+    assert bad == 0, f"{bad} of {n} plan buffers were written past their end"
+
+
+def test_rektnet_train_step_stays_inside_every_plan_buffer(monkeypatch):
+    import contextlib
+    import io
+    from mdcv.rektnet.keypoint_net import KeypointNet
+    from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+    from mdcv.optim import FusedAdam
+    with contextlib.redirect_stdout(io.StringIO()):
+        crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
+    g = torch.Generator().manual_seed(2)
+    B = 37                                            # odd everything
+    x = torch.rand(B, 3, 80, 80, generator=g).cuda()
+    thm = torch.rand(B, 7, 80, 80, generator=g).cuda()
+    tp = torch.rand(B, 7, 2, generator=g).cuda() * 0.9
+    state = {}
+
+    def build():
+        net = KeypointNet(7, (80, 80), precision="bf16").cuda().train()
+        state["opt"] = FusedAdam(net, lr=1e-2)
+        return net
+
+    def step(net):
+        state["opt"].zero_grad()
+        hm, pts = net(x)
+        crit(hm, pts, thm, tp)[2].backward()
+        state["opt"].step()
+    bad, n = _full_step_redzones(monkeypatch, build, step)
+    assert bad == 0, f"{bad} of {n} plan buffers were written past their end"
