@@ -368,10 +368,11 @@ class Plan:
                   dy2.ptr if dy2 is not None else None, dy2.ldc if dy2 is not None else 0, y1.M, y1.C, act, float(slope))
         return (dy1, dy2) if y2 is not None else dy1
 
-    # Opt-in (MDCV_BN_FUSE=1).  Measured on YOLOv3 416^2 B=32: the stand-alone reduce kernels it removes cost 0.95 ms per step, but
-    # the fused store loop adds 1.1 ms to the 66 data gradients (the y loads are HBM misses whose latency is exposed once per
-    # 128-row group at the end of each tile), so the default stays the two-pass form.
-    fuse_bn = os.environ.get("MDCV_BN_FUSE", "0") == "1"
+    # On by default (MDCV_BN_FUSE=0 restores the two-pass form).  YOLOv3 416^2 B=32: it removes 0.95 ms of stand-alone reduce kernels
+    # per step and adds ~1.1 ms to the 66 data gradients' store loops (the y loads are HBM misses whose latency is exposed once per
+    # 128-row group at the end of each tile) -- neutral while everything ran on one stream, +0.9 % (2039 -> 2058 img/s, same-box A/B)
+    # now that the weight gradients fill the MFMA pipe from the side stream and the main stream is what bounds the step.
+    fuse_bn = os.environ.get("MDCV_BN_FUSE", "1") == "1"
 
     def _fuse_bn_sums(self, dout, y, bs, act, slope, dgamma, dbeta):
         """Fold the BatchNorm-backward reduction over (dout, y) into the store loop of the data gradient that wrote `dout`.
