@@ -48,7 +48,7 @@ __device__ long long g_shift_ts[4 * 512];
 #endif
 
 int g_shift_ring = 3;
-int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row only ; 3: mixed rounds ; 4: 16 waves ; 5: 192-row tiles (tuning)   // weight-ring depth (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
+int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row only ; 3: mixed rounds ; 4: 16 waves ; 5: 192-row tiles where they save a round (= default) ; 6: never 192-row   // weight-ring depth (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -412,14 +412,16 @@ int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st,
 // twice as fast), so an isolated launch takes ceil(tiles / 256) x (time of one tile) and loses the CUs left without a tile in
 // the last round.  192-row tiles (wave tile 48 x 64) cut that loss and are 7-12 % faster in a tight loop on the 52^2 / 26^2
 // layers (scripts/conv_ab.py), but inside the training step the idle CUs are not wasted — the weight-gradient stream fills
-// them — and the 192-row tile's lower MFMA density per barrier makes the step 0.7 % slower, so they are a tuning option (plan 5)
-// and the default is 256-row tiles, 128-row tiles only for grids of at most 128 tiles.
+// them — and the 192-row tile's lower MFMA density per barrier made the step 0.7 % slower while the conv kernels shared the CUs evenly
+// with the rest; since the BatchNorm sums moved into the data gradients the main stream bounds the step and the 192-row plan is
+// +0.6 % (2043 -> 2055 img/s, same-box A/B), so it is the default where it saves a round (batch 32: the 26x26 layers); 128-row
+// tiles only for grids of at most 128 tiles; plan 6 restores 256-row-only.
 int shift_plan_bm(int Mq, int tiles_n, bool fused) {
   if (g_shift_plan == 1) return 256;
   if (g_shift_plan == 2) return 128;
   const int t256 = ((Mq + 255) / 256) * tiles_n;
   if (t256 <= 128) return 128;                       // (measured: 184- and 200-tile grids are still faster as 256-row tiles)
-  if (fused || g_shift_plan != 5) return 256;
+  if (fused || g_shift_plan == 6) return 256;       // plan 6: the old default (no 192-row tiles)
   const int t192 = ((Mq + 191) / 192) * tiles_n;
   const int c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
   return c192 < c256 ? 192 : 256;
