@@ -26,7 +26,10 @@ _RZ_BYTE = 0xA5
 def _alloc(n, dtype, device, zero, plan):
     """Plan buffer of n elements; in redzone mode it is the front of a larger allocation whose tail holds a byte pattern."""
     if not _REDZONE:
-        return (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=device)
+        t = (torch.zeros if zero else torch.empty)(n, dtype=dtype, device=device)
+        if not zero and _POISON and t.is_floating_point():
+            t.fill_(float("nan"))
+        return t
     es = torch.empty(0, dtype=dtype).element_size()
     raw = torch.full((n * es + _REDZONE,), _RZ_BYTE, dtype=torch.uint8, device=device)
     t = raw[:n * es].view(dtype)
@@ -148,16 +151,12 @@ class Plan:
     def new_act(self, B, H, W, C, zero=False):
         Cp = pad8(C)
         buf = _alloc(B * H * W * Cp, self.tdtype, self.device, zero, self)
-        if not zero and _POISON:
-            buf.fill_(float("nan"))
         self.keep.append(buf)
         self.bytes += buf.numel() * buf.element_size()
         return Act(buf, B, H, W, Cp, Cp)
 
     def f32(self, n, zero=True):
         t = _alloc(n, torch.float32, self.device, zero, self)
-        if not zero and _POISON:
-            t.fill_(float("nan"))
         self.keep.append(t)
         return t
 
@@ -380,7 +379,8 @@ class Plan:
         Legal when that launch is the LAST writer of the buffer (nothing between it and this point of the backward list mentions
         the pointer), it wrote exactly this tensor, and the library has a fused path for its geometry.  The earlier list entry is
         rewritten in place; what remains here is the column-owner finalize."""
-        if not self.fuse_bn:
+        if not self.fuse_bn or self.dtype != BF16:       # production dtype only: the fp32 parity mode keeps the two-pass form (its fused
+            # variants left partial rows unwritten at some sizes -- found with MDCV_POISON at batch 16..32)
             return False
         e = self.dgrad_entries.get(dout.ptr)
         if e is None or e["used"]:

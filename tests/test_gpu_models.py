@@ -556,13 +556,14 @@ def test_hipgraph_replay_matches_eager():
 
 
 def test_mini_darknet_with_fused_bn_backward_sums(monkeypatch):
-    """MDCV_BN_FUSE=1 (BatchNorm-backward sums folded into the data-gradient store loops) gives the same losses / gradients."""
+    """BatchNorm-backward sums folded into the data-gradient store loops (bf16 only, default on) vs the two-pass form
+    (MDCV_BN_FUSE=0): same losses, gradients equal up to the order of the fp32 partial sums."""
     from mdcv import engine
     z = load("mini_darknet.npz")
     outs = {}
     for fuse in (False, True):
         monkeypatch.setattr(engine.Plan, "fuse_bn", fuse)
-        net = make_mini("fp32")
+        net = make_mini("bf16")
         net.train()
         x, tg = T(z["x"]).cuda(), T(z["targets"]).cuda()
         out = net(x, tg)
@@ -570,9 +571,14 @@ def test_mini_darknet_with_fused_bn_backward_sums(monkeypatch):
         plan = [p for p in net._plans.values() if p.has_bwd][0]
         outs[fuse] = (float(out[0]), net.flat_parameters()[1].clone(), plan.fused_bn)
     assert outs[True][2] > 0 and outs[False][2] == 0
-    assert abs(outs[True][0] - outs[False][0]) <= 1e-6 * abs(outs[False][0])
+    assert outs[True][0] == outs[False][0]                       # the forward is the same code
     g0, g1 = outs[False][1], outs[True][1]
-    assert float((g0 - g1).abs().max()) <= 2e-4 * float(g0.abs().max())
+    assert float((g0 - g1).abs().max()) <= 1e-2 * float(g0.abs().max())    # bf16 activation gradients: last-bit coefficient changes move roundings
+    monkeypatch.setattr(engine.Plan, "fuse_bn", True)
+    net = make_mini("fp32")                                      # the fp32 parity mode never fuses
+    net.train()
+    net(T(z["x"]).cuda(), T(z["targets"]).cuda())[0].sum().backward()
+    assert [p for p in net._plans.values() if p.has_bwd][0].fused_bn == 0
 
 
 def _train_steps(make_model, make_batch, pipeline, steps, lr):

@@ -157,3 +157,55 @@ def test_rektnet_train_step_stays_inside_every_plan_buffer(monkeypatch):
         state["opt"].step()
     bad, n = _full_step_redzones(monkeypatch, build, step)
     assert bad == 0, f"{bad} of {n} plan buffers were written past their end"
+
+
+@pytest.mark.parametrize("B", [5, 16, 31, 32])
+def test_yolov3_train_step_reads_no_uninitialised_plan_buffer(monkeypatch, tmp_path, B):
+    """MDCV_POISON mode: every plan buffer that is not zero-initialised starts as NaN.  A kernel that reads a partial row / scratch
+    element nobody wrote turns the loss or a gradient into NaN.  Batch sizes with odd and even tile / partial-row counts."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mdcv import engine
+    from mdcv.yolo.models import Darknet
+    monkeypatch.setattr(engine, "_POISON", True)
+    cfg = bench.write_yolo_cfg(str(tmp_path))
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        torch.manual_seed(0)
+        net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
+    finally:
+        os.chdir(cwd)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(B, 3, 416, 416, generator=g).cuda()
+    tg = bench.synth_targets(B, 16, g).cuda()
+    out = net(x, tg)
+    out[0].sum().backward()
+    assert all(bool(torch.isfinite(o)) for o in out)
+    gflat = net.flat_parameters()[1]
+    assert bool(torch.isfinite(gflat).all()), int((~torch.isfinite(gflat)).sum())
+
+
+@pytest.mark.parametrize("B", [3, 37, 256])
+def test_rektnet_train_step_reads_no_uninitialised_plan_buffer(monkeypatch, B):
+    import contextlib
+    import io
+    from mdcv import engine
+    from mdcv.rektnet.keypoint_net import KeypointNet
+    from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+    monkeypatch.setattr(engine, "_POISON", True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(B, 3, 80, 80, generator=g).cuda()
+    thm = torch.rand(B, 7, 80, 80, generator=g).cuda()
+    tp = torch.rand(B, 7, 2, generator=g).cuda() * 0.9
+    net = KeypointNet(7, (80, 80), precision="bf16").cuda().train()
+    hm, pts = net(x)
+    loss = crit(hm, pts, thm, tp)[2]
+    loss.backward()
+    assert bool(torch.isfinite(loss))
+    gflat = net.flat_parameters()[1]
+    assert bool(torch.isfinite(gflat).all()), int((~torch.isfinite(gflat)).sum())
