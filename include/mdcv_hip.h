@@ -37,7 +37,7 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
 /* Data gradient (mode 1, same geometry arguments as mdcv_conv2d) that also writes the BatchNorm-backward partial sums of the layer
  * whose output gradient it produces: partial[row][0][c] = sum g, partial[row][1][c] = sum g*(y - mean), g = dz * act'(scale*y + shift),
  * one row per 128 output positions (y: that layer's raw conv output, same pixel/channel indexing as the gradient written to `out`).
- * _rows() = number of rows written, or 0 when the geometry cannot take the fused path.  Finish with mdcv_bn_bwd_finalize_rows. */
+ * _rows() = number of rows written, or 0 when the geometry / dtype (bf16 only) cannot take the fused path.  Finish with mdcv_bn_bwd_finalize_rows. */
 int mdcv_conv2d_dgrad_bnsums_rows(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
                                   int pad, int dil, int in_ldc);
 int mdcv_conv2d_dgrad_bnsums(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const void* addsrc,

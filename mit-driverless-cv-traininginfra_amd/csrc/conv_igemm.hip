@@ -678,7 +678,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
           fz.add(a.fuse, x, yq[u]);
         }
       }
-      fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (tile_m * BM + g0) >> 7);
+      if (tile_m * BM + g0 < a.M)                      // block-uniform: a 256-row tile's second group may start past the last pixel,
+        fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (tile_m * BM + g0) >> 7);   // and that row is not in the caller's buffer
     }
     return;
   }
@@ -1698,8 +1699,8 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
 // or 0 when this geometry cannot take the fused path (the caller then keeps mdcv_conv2d + mdcv_bn_act_bwd_reduce).
 int mdcv_conv2d_dgrad_bnsums_rows(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
                                   int pad, int dil, int in_ldc) {
-  const int es = dtype == MDCV_BF16 ? 2 : 4;
-  if (dtype != MDCV_BF16 && dtype != MDCV_F32) return 0;
+  const int es = 2;
+  if (dtype != MDCV_BF16) return 0;     // production dtype only: not every fp32 tile variant carries the fused store loop
   if ((long long)B * Hin * Win * in_ldc * es >= (1LL << 31) || (long long)Nout * KH * KW * Cin * es >= (1LL << 31)) return 0;
   if (Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc))
     return mdcv_shift_stats_rows(B, Hout, Wout);

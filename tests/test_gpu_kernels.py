@@ -479,6 +479,9 @@ def test_dgrad_with_fused_bn_sums(case, dt, act, with_add):
     gamma = (torch.rand(cip, generator=g) + 0.5).cuda()
     slope = 0.1
     rows = L.conv2d_dgrad_bnsums_rows(dt, B, Ho, Wo, cop, H, W, cip, k, k, s, p, d, cop)
+    if dt == F32:                                   # bf16 only: the query says so and the entry point refuses
+        assert rows == 0
+        return
     assert rows > 0
     P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     # reference path

@@ -209,3 +209,33 @@ def test_rektnet_train_step_reads_no_uninitialised_plan_buffer(monkeypatch, B):
     assert bool(torch.isfinite(loss))
     gflat = net.flat_parameters()[1]
     assert bool(torch.isfinite(gflat).all()), int((~torch.isfinite(gflat)).sum())
+
+
+# (B, channels of dx, H, W of dx, channels of dy, k, stride, pad): the last 256-row tile's second group starts past the last pixel
+FUSED_GEOMS = [(31, 256, 52, 52, 128, 1, 1, 0), (3, 128, 52, 52, 256, 3, 1, 1), (5, 64, 26, 26, 128, 3, 2, 1), (7, 512, 13, 13, 1024, 3, 1, 1),
+               (33, 128, 13, 13, 256, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("geom", FUSED_GEOMS, ids=str)
+def test_fused_dgrad_partial_rows_written_exactly(geom):
+    """mdcv_conv2d_dgrad_bnsums writes every row mdcv_conv2d_dgrad_bnsums_rows promises and nothing behind them."""
+    L = _lib.lib()
+    B, Ci, H, W, Co, k, s, p = geom
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    rows = L.conv2d_dgrad_bnsums_rows(BF16, B, Ho, Wo, Co, H, W, Ci, k, k, s, p, 1, Co)
+    assert rows > 0
+    assert L.conv2d_dgrad_bnsums_rows(_lib.F32, B, Ho, Wo, Co, H, W, Ci, k, k, s, p, 1, Co) == 0      # bf16 only
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dy = torch.randn(B * Ho * Wo * Co, device="cuda", generator=g).to(torch.bfloat16)
+    wd = (torch.randn(Ci * k * k * Co, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    y = torch.randn(B * H * W * Ci, device="cuda", generator=g).to(torch.bfloat16)
+    nx = B * H * W * Ci
+    dx = guarded(nx, torch.bfloat16)
+    sc, sh, mean = torch.ones(Ci, device="cuda"), torch.zeros(Ci, device="cuda"), torch.zeros(Ci, device="cuda")
+    part = torch.full(((rows + 64) * 2 * Ci,), float("nan"), device="cuda")
+    L.check(L.conv2d_dgrad_bnsums(BF16, dy.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, None, 0, B, Ho, Wo, Co, H, W, Ci, k, k, s, p, 1,
+                                  y.data_ptr(), Ci, sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), 1, 0.1, part.data_ptr(), st()), "fused dgrad")
+    torch.cuda.synchronize()
+    check(dx, nx, "data gradient")
+    assert not bool(torch.isnan(part[:rows * 2 * Ci]).any()), "a promised partial row was not written"
+    assert bool(torch.isnan(part[rows * 2 * Ci:]).all()), "a partial row was written past the buffer"
