@@ -10,6 +10,7 @@ GEOMS = [(32, 416, 8, 32, 3, 1, 1), (32, 416, 32, 64, 3, 2, 1), (32, 208, 64, 32
          (32, 13, 512, 1024, 3, 1, 1), (32, 13, 1024, 256, 1, 1, 1), (32, 26, 768, 256, 1, 1, 1), (32, 52, 384, 128, 1, 1, 1), (32, 26, 256, 128, 1, 1, 1), (32, 13, 512, 256, 1, 1, 1),
          (256, 80, 8, 16, 7, 1, 1), (256, 80, 16, 16, 3, 1, 2), (256, 80, 16, 16, 3, 1, 1), (256, 80, 16, 16, 1, 1, 1), (256, 80, 16, 32, 3, 1, 2), (256, 80, 32, 32, 3, 1, 1),
          (256, 80, 32, 64, 3, 1, 2), (256, 80, 64, 64, 3, 1, 1), (256, 80, 64, 128, 3, 1, 2), (256, 80, 128, 128, 3, 1, 1), (256, 80, 64, 128, 1, 1, 1),
+         (31, 52, 256, 128, 1, 1, 1), (31, 104, 128, 64, 1, 1, 1), (33, 26, 512, 256, 1, 1, 1), (31, 208, 64, 128, 3, 2, 1), (31, 104, 128, 256, 3, 2, 1), (31, 52, 128, 256, 3, 1, 1), (33, 13, 512, 1024, 3, 1, 1), (31, 26, 256, 512, 3, 1, 1), (255, 80, 64, 64, 3, 1, 1), (255, 80, 128, 128, 3, 1, 1), (255, 80, 16, 16, 1, 1, 1),
          (8, 416, 8, 32, 3, 1, 1), (8, 208, 64, 128, 3, 2, 1), (8, 52, 128, 256, 3, 1, 1), (2, 64, 8, 16, 3, 1, 1), (4, 13, 512, 1024, 3, 1, 1)]
 SENT = 12345.0
 for (B, H, Ci, Co, k, s, dil) in GEOMS:
