@@ -239,3 +239,32 @@ def test_fused_dgrad_partial_rows_written_exactly(geom):
     check(dx, nx, "data gradient")
     assert not bool(torch.isnan(part[:rows * 2 * Ci]).any()), "a promised partial row was not written"
     assert bool(torch.isnan(part[rows * 2 * Ci:]).all()), "a partial row was written past the buffer"
+
+
+@pytest.mark.parametrize("B,N,C,dense", [(32, 10647, 80, False), (3, 22743, 80, True), (5, 507, 1, True)])
+def test_detect_post_stays_inside_workspace_and_outputs(B, N, C, dense):
+    """validate.py post-processing at real sizes: guard bytes behind the workspace and every output array stay intact."""
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pred = torch.rand(B, N, 5 + C, device="cuda", generator=g)
+    pred[..., :4] *= 400.0
+    pred[..., 4] = torch.rand(B, N, device="cuda", generator=g) * (1.0 if dense else 0.55)      # dense: thousands above the threshold
+    tg = torch.zeros(B, 16, 5, device="cuda")
+    tg[:, :6, 1:] = torch.rand(B, 6, 4, device="cuda", generator=g) * 0.5 + 0.2
+    k = 200
+    RZ = 4096
+
+    def gbuf(nbytes):
+        raw = torch.full((nbytes + RZ,), 0xA5, dtype=torch.uint8, device="cuda")
+        return raw, nbytes
+    sizes = dict(boxes=B * k * 4 * 4, prob=B * k * 4, cls=B * k * 4, index=B * k * 8, correct=B * k, count=B * 4, stats=B * 4 * 4,
+                 ws=int(L.detect_post_workspace_bytes(B, N)))
+    bufs = {n: gbuf(sz) for n, sz in sizes.items()}
+    p = {n: raw.data_ptr() for n, (raw, _) in bufs.items()}
+    L.check(L.detect_post(pred.data_ptr(), B, N, C, tg.data_ptr(), 16, 0.5, 0.4, 0.5, 416.0, 416.0, k, p["boxes"], p["prob"], p["cls"],
+                          p["index"], p["correct"], p["count"], p["stats"], p["ws"], st()), "detect_post")
+    torch.cuda.synchronize()
+    for n, (raw, sz) in bufs.items():
+        assert int((raw[sz:] != 0xA5).sum()) == 0, f"{n}: written past the end"
+    count = bufs["count"][0][:B * 4].view(torch.int32)
+    assert int(count.min()) >= 0 and int(count.max()) <= k
