@@ -703,3 +703,42 @@ def test_full_yolov3_batch32_train_forward_backward_vs_oracle(precision, tol, tm
         assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.1, (i, float(a.norm()), float(b.norm()))
     rm = net.state_dict()["module_list.0.batch_norm_0.running_mean"].cpu().numpy()
     np.testing.assert_allclose(rm, orc.params["bn0.running_mean"].detach().numpy(), rtol=0, atol=2e-3 if precision == "bf16" else 1e-5)
+
+
+def test_full_yolov3_training_is_bit_reproducible(tmp_path):
+    """Two model instances in one process, same seeds, three train steps of the full yolo_baseline (batch 32, bf16, weight gradients on
+    the side stream, fused BatchNorm sums): identical losses and bit-identical parameters.  (No atomics on any data path; this is also
+    what exposed the out-of-bounds partial row in round 1: results depended on what the allocator had placed behind a buffer.)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mdcv.yolo.models import Darknet
+    from mdcv.optim import FusedAdam
+    cfg = bench.write_yolo_cfg(str(tmp_path))
+
+    def run():
+        cwd = os.getcwd()
+        os.chdir(tmp_path)
+        try:
+            torch.manual_seed(0)
+            net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
+        finally:
+            os.chdir(cwd)
+        opt = FusedAdam(net, lr=1e-3)
+        g = torch.Generator().manual_seed(1)
+        x = torch.rand(32, 3, 416, 416, generator=g).cuda()
+        tg = bench.synth_targets(32, 16, g).cuda()
+        junk = torch.rand(1 << 20, device="cuda")                 # perturbs the allocator between instances
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            out = net(x, tg)
+            out[0].sum().backward()
+            opt.step()
+            losses.append(out[0].detach().clone())
+        torch.cuda.synchronize()
+        del junk
+        return [float(v) for v in losses], net.flat_parameters()[0].clone()
+    (la, pa), (lb, pb) = run(), run()
+    assert la == lb, (la, lb)
+    assert torch.equal(pa, pb)
