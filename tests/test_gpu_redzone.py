@@ -268,3 +268,39 @@ def test_detect_post_stays_inside_workspace_and_outputs(B, N, C, dense):
         assert int((raw[sz:] != 0xA5).sum()) == 0, f"{n}: written past the end"
     count = bufs["count"][0][:B * 4].view(torch.int32)
     assert int(count.min()) >= 0 and int(count.max()) <= k
+
+
+def test_tiny_cfg_train_and_608_eval_under_poison_and_redzones(monkeypatch, tmp_path):
+    """The second shipped topology (max-pool sections, two heads) at 416x416 batch 16, and the eval-mode forward of yolo_baseline at
+    608x608: NaN-poisoned uninitialised buffers and guard bytes behind every plan buffer at the same time."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mdcv import engine
+    from mdcv.yolo.models import Darknet
+    from test_gpu_models import write_tiny_cfg
+    monkeypatch.setattr(engine, "_POISON", True)
+    monkeypatch.setattr(engine, "_REDZONE", 4096)
+    g = torch.Generator().manual_seed(7)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        torch.manual_seed(0)
+        tiny = Darknet(write_tiny_cfg(str(tmp_path), 416, 80), 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
+        full = Darknet(bench.write_yolo_cfg(str(tmp_path), size=608), 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().eval()
+    finally:
+        os.chdir(cwd)
+    x = torch.rand(16, 3, 416, 416, generator=g).cuda()
+    tg = bench.synth_targets(16, 16, g).cuda()
+    out = tiny(x, tg)
+    out[0].sum().backward()
+    assert all(bool(torch.isfinite(o)) for o in out)
+    assert bool(torch.isfinite(tiny.flat_parameters()[1]).all())
+    with torch.no_grad():
+        det = full(torch.rand(4, 3, 608, 608, generator=g).cuda())
+    assert det.shape == (4, 22743, 85) and bool(torch.isfinite(det).all())
+    torch.cuda.synchronize()
+    for net in (tiny, full):
+        for plan in net._plans.values():
+            assert plan.redzones and plan.check_redzones() == 0
