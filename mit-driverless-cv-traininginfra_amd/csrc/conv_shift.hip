@@ -317,36 +317,44 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
     const bf16_t* __restrict__ fy = reinterpret_cast<const bf16_t*>(a.fuse.y);
     float* fred = reinterpret_cast<float*>(smem + STAT_OFF);
     constexpr int PPG = 128 / Acc::RPP;                    // passes per 128-position group
-#pragma unroll 1
-    for (int g0 = 0; g0 < BM; g0 += 128) {
-      // all loads of the group first (staging, addsrc, y), then the arithmetic: the passes are independent
-      int pixv[PPG]; uint4 dq[PPG], aq[PPG], yq[PPG];
+    // The global loads (addsrc, y) of ALL groups are issued first: they are HBM misses, and with one batch of loads per 128-row
+    // group their latency was exposed once per group (0.95 ms per YOLOv3 step over the 66 fused data gradients); the accumulators
+    // are dead by now, so the registers are free.
+    constexpr int NG = BM / 128;
+    int pixv[NG][PPG]; uint4 aq[NG][PPG], yq[NG][PPG];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
       for (int u = 0; u < PPG; ++u) {
-        const int row = g0 + u * Acc::RPP + tid / VPRO;
-        pixv[u] = n < a.Nout ? rowpix[row] : -1;
-        dq[u] = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
-        if (pixv[u] >= 0) {
-          if (addsrc) aq[u] = *reinterpret_cast<const uint4*>(addsrc + ((size_t)pixv[u] * a.add_ldc + n));
-          yq[u] = *reinterpret_cast<const uint4*>(fy + ((size_t)pixv[u] * a.fuse.ldy + n));
+        const int row = gi * 128 + u * Acc::RPP + tid / VPRO;
+        pixv[gi][u] = n < a.Nout ? rowpix[row] : -1;
+        if (pixv[gi][u] >= 0) {
+          if (addsrc) aq[gi][u] = *reinterpret_cast<const uint4*>(addsrc + ((size_t)pixv[gi][u] * a.add_ldc + n));
+          yq[gi][u] = *reinterpret_cast<const uint4*>(fy + ((size_t)pixv[gi][u] * a.fuse.ldy + n));
         }
       }
 #pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int g0 = gi * 128;
+      uint4 dq[PPG];
+#pragma unroll
+      for (int u = 0; u < PPG; ++u) dq[u] = *reinterpret_cast<const uint4*>(smem + (g0 + u * Acc::RPP + tid / VPRO) * SROW + cv * 16);
+#pragma unroll
       for (int u = 0; u < PPG; ++u) {
-        if (pixv[u] >= 0) {
+        if (pixv[gi][u] >= 0) {
           float x[8];
           uint4 d = dq[u];
           ET<bf16_t>::unpack(d, x);
           if (addsrc) {
             float y[8];
-            ET<bf16_t>::unpack(aq[u], y);
+            ET<bf16_t>::unpack(aq[gi][u], y);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] += y[e];
             d = ET<bf16_t>::pack(x);
             ET<bf16_t>::unpack(d, x);                     // the sums see dz as stored
           }
-          *reinterpret_cast<uint4*>(out + ((size_t)pixv[u] * a.out_ldc + n)) = d;
-          fz.add(a.fuse, x, yq[u]);
+          *reinterpret_cast<uint4*>(out + ((size_t)pixv[gi][u] * a.out_ldc + n)) = d;
+          fz.add(a.fuse, x, yq[gi][u]);
         }
       }
       if (p0 + g0 < a.Mq) fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (p0 + g0) >> 7);   // block-uniform: rows past the stream do not exist
