@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 OPT_PIPELINE = os.environ.get("MDCV_OPT_PIPELINE", "0") == "1"   # FusedAdam(pipeline=True), see mdcv/optim.py: bit-identical, measured neutral -> off
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
-YOLO_TRAIN_GFLOP_PER_IMG = 197.59   # SURVEY.md §8d (conv only, fwd+dgrad+wgrad, classes=80, 416^2)
+YOLO_TRAIN_GFLOP_PER_IMG = 197.59   # SURVEY.md §8d (conv only, fwd+dgrad+wgrad, classes=80, 416^2; classes=1: 195.87)
 REKT_TRAIN_GFLOP_PER_IMG = 11.872   # head conv counted once
 REKT_TRAIN_MB_PER_IMG = 57.8
 
@@ -255,6 +255,7 @@ def main():
     ap.add_argument("--joint-batch", type=int, default=32, help="608x608 frames per GPU for the joint detect->keypoints workload")
     ap.add_argument("--post-batch", type=int, default=32, help="images per GPU for the detection post-processing workload")
     ap.add_argument("--yolo-batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--yolo-classes", type=int, default=80, help="80 = BASELINE config; 1 = the cone-realistic variant of SURVEY 8d (18-channel heads)")
     ap.add_argument("--rekt-batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", type=int, default=int(os.environ.get("MDCV_GRAPH", "0")))
@@ -298,7 +299,7 @@ def main():
     result = {}
     extra = {}
     tmp = tempfile.mkdtemp(prefix="mdcv_bench_")
-    cfg = write_yolo_cfg(tmp)
+    cfg = write_yolo_cfg(tmp, classes=a.yolo_classes)
 
     if a.workload in ("both", "yolo"):
         cwd = os.getcwd()
@@ -328,7 +329,7 @@ def main():
         loss = float(yolo_step()[0])
         result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
         extra["yolo"] = {"images_per_sec": ips, "ms_per_step": 1e3 * dt / a.steps, "global_batch": B * world, "final_loss": loss,
-                         "mfma_frac_step": ips * YOLO_TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_TFLOPS * world)}
+                         "mfma_frac_step": ips * (YOLO_TRAIN_GFLOP_PER_IMG if a.yolo_classes == 80 else 195.87) / 1e3 / (PEAK_BF16_TFLOPS * world)}
         if world > 1:                 # replicas must hold identical parameters after the reduced-gradient updates
             chk = net.flat_parameters()[0].double().sum().reshape(1)
             lo, hi = chk.clone(), chk.clone()
@@ -496,7 +497,7 @@ def main():
                        "images/sec joint detect->keypoints inference"), "value": result["value"], "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": result["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": {"yolo": "CVC-YOLOv3 yolo_baseline 416x416 classes=80, train step (fwd+bwd+Adam), %d img/GPU" % a.yolo_batch,
+            "config": {"workload": {"yolo": "CVC-YOLOv3 yolo_baseline 416x416 classes=%d, train step (fwd+bwd+Adam), %d img/GPU" % (a.yolo_classes, a.yolo_batch),
                                     "rektnet": "RektNet KeypointNet 80x80 train step (l1_softargmax+geo, Adam), %d img/GPU" % a.rekt_batch,
                                     "postprocess": "validate.py per-image loop (conf 0.8, NMS 0.25 top-200, AP) on [%d,10647,85] eval outputs"
                                                    % a.post_batch,
