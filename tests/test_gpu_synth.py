@@ -81,3 +81,52 @@ def test_training_steps_on_generated_batches():
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     _, x, tg = SyntheticCones(2, 96, 96, 8, 1, 1, 5).batch(0)
     assert x.is_cuda and tg.is_cuda and float(tg[:, 0, 3].min()) > 0
+
+
+def test_both_networks_train_on_the_synthetic_streams(tmp_path):
+    """End to end on the device: SyntheticCones -> Darknet (yolo_baseline, classes=1, 416x416, batch 32) and SyntheticConeCrops ->
+    KeypointNet + CrossRatioLoss (batch 256), bf16, FusedAdam: the losses fall by more than 10x within 150 steps and stay finite
+    (scripts/train_synth.py prints the curves: 64 -> 0.94 and 4.2 -> 0.17 after 300 steps)."""
+    import contextlib
+    import io
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mdcv.yolo.models import Darknet
+    from mdcv.rektnet.keypoint_net import KeypointNet
+    from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+    from mdcv.optim import FusedAdam
+    from mdcv.data.synth import SyntheticCones, SyntheticConeCrops
+    cfg = bench.write_yolo_cfg(str(tmp_path), classes=1)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        torch.manual_seed(0)
+        net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
+    finally:
+        os.chdir(cwd)
+    opt = FusedAdam(net, lr=1e-3)
+    losses = []
+    for _, x, tg in SyntheticCones(32, 416, 416, 16, 1, batches=150, seed=3):
+        opt.zero_grad()
+        out = net(x, tg)
+        out[0].sum().backward()
+        opt.step()
+        losses.append(out[0].detach())
+    ls = torch.stack(losses).flatten().cpu()
+    assert bool(torch.isfinite(ls).all()) and float(ls[-10:].mean()) < 0.1 * float(ls[0]), (float(ls[0]), float(ls[-10:].mean()))
+    with contextlib.redirect_stdout(io.StringIO()):
+        crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
+    kp = KeypointNet(7, (80, 80), precision="bf16").cuda().train()
+    opt = FusedAdam(kp, lr=1e-2)
+    losses = []
+    for x, hm_t, pts_t, _, _ in SyntheticConeCrops(256, 80, batches=150, seed=5):
+        opt.zero_grad()
+        hm, pts = kp(x)
+        loss = crit(hm, pts, hm_t, pts_t)[2]
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+    ls = torch.stack(losses).flatten().cpu()
+    assert bool(torch.isfinite(ls).all()) and float(ls[-10:].mean()) < 0.1 * float(ls[0]), (float(ls[0]), float(ls[-10:].mean()))
