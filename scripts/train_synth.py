@@ -22,6 +22,11 @@ for i, (_, x, tg) in enumerate(data):
         hist.append(float(out[0])); print("yolo step %4d loss %.4f parts %s" % (i, hist[-1], ["%.3f" % float(v) for v in out[1:]]), flush=True)
 torch.cuda.synchronize(); print("yolo: %d steps in %.1f s (%.0f img/s incl. data generation)" % (steps, time.perf_counter() - t0, 32 * steps / (time.perf_counter() - t0)))
 assert all(h == h for h in hist) and hist[-1] < 0.5 * hist[0], hist
+from mdcv.yolo.validate import validate                     # the reference's train.py runs validate() on its validation loader
+val = SyntheticCones(32, 416, 416, 16, 1, batches=8, seed=99)
+m = validate(dataloader=val, model=net, device=torch.device("cuda"))
+print("validate on 256 held-out synthetic images: mAP %.3f recall %.3f precision %.3f  (%.2f ms/img)" % (m[0], m[1], m[2], 1e3 * m[3]))
+net.train()
 with contextlib.redirect_stdout(io.StringIO()):
     crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
 kp = KeypointNet(7, (80, 80), precision="bf16").cuda().train()
