@@ -12,7 +12,7 @@ from mdcv.data.synth import SyntheticCones, SyntheticConeCrops
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 tmp = tempfile.mkdtemp(); cfg = bench.write_yolo_cfg(tmp, classes=1)
 cwd = os.getcwd(); os.chdir(tmp); torch.manual_seed(0)
-net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train(); os.chdir(cwd)
+net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision=os.environ.get("TS_PREC", "bf16")).cuda().train(); os.chdir(cwd)
 opt = FusedAdam(net, lr=1e-3)
 data = SyntheticCones(32, 416, 416, 16, 1, batches=steps, seed=3)
 t0 = time.perf_counter(); hist = []
