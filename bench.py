@@ -255,6 +255,7 @@ def main():
     ap.add_argument("--joint-batch", type=int, default=32, help="608x608 frames per GPU for the joint detect->keypoints workload")
     ap.add_argument("--post-batch", type=int, default=32, help="images per GPU for the detection post-processing workload")
     ap.add_argument("--yolo-batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--host-input", action="store_true", help="also time the step with the batch copied from pinned host memory (never `value`)")
     ap.add_argument("--yolo-classes", type=int, default=80, help="80 = BASELINE config; 1 = the cone-realistic variant of SURVEY 8d (18-channel heads)")
     ap.add_argument("--rekt-batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
@@ -328,7 +329,21 @@ def main():
         ips = B * world * a.steps / dt
         loss = float(yolo_step()[0])
         result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
-        extra["yolo"] = {"images_per_sec": ips, "ms_per_step": 1e3 * dt / a.steps, "global_batch": B * world, "final_loss": loss,
+        pcie = None
+        if a.host_input:       # what train.py's loop does with a DataLoader batch: pinned host tensors, .to(device, non_blocking=True)
+            xh, th = x.cpu().pin_memory(), tg.cpu().pin_memory()
+
+            def yolo_step_h2d():
+                xd, td = xh.to(device, non_blocking=True), th.to(device, non_blocking=True)
+                opt.zero_grad()
+                out = net(xd, td)
+                out[0].sum().backward()
+                red.finish()
+                opt.step()
+                return out
+            dth = timed_region(yolo_step_h2d, a.steps, a.warmup, device, world)
+            pcie = B * world * a.steps / dth
+        extra["yolo"] = {"images_per_sec_with_h2d_copy": pcie, "images_per_sec": ips, "ms_per_step": 1e3 * dt / a.steps, "global_batch": B * world, "final_loss": loss,
                          "mfma_frac_step": ips * (YOLO_TRAIN_GFLOP_PER_IMG if a.yolo_classes == 80 else 195.87) / 1e3 / (PEAK_BF16_TFLOPS * world)}
         if world > 1:                 # replicas must hold identical parameters after the reduced-gradient updates
             chk = net.flat_parameters()[0].double().sum().reshape(1)
