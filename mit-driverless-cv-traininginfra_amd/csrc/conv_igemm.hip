@@ -1794,6 +1794,9 @@ static bool use_wgrad_stream(int dtype, int B, int Hin, int Win, int Cin, int Ho
 // geometry-aware variant: the kernel mdcv_conv2d_wgrad will pick for this layer decides the split (use this one to size `ws`)
 int mdcv_conv2d_wgrad_splits_geom(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride,
                                   int pad, int dil, int dy_ldc, int x_ldc) {
+  if (g_wgrad_variant != 9 && g_wgrad_variant != 10 && Hin == Hout && Win == Wout &&
+      mdcv_wgrad_stem_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc))
+    return mdcv_wgrad_stem_splits(B, Hout, Wout);
   if (use_wgrad_stream(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc))
     return mdcv_wgrad_stream_splits(B, Hout, Wout, Cin, Cout, dil);
   if (use_wgrad_shift(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc))
@@ -1806,6 +1809,13 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
                       int Hout, int Wout, int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream) {
   if (!dy || !x || !ws || !dw_oihw) return MDCV_EARG;
   if ((Cin & 7) || (Cout & 7) || (dy_ldc & 7) || (x_ldc & 7) || splits < 1) return MDCV_EARG;
+  if (g_wgrad_variant != 9 && g_wgrad_variant != 10 && Hin == Hout && Win == Wout &&
+      mdcv_wgrad_stem_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc) &&
+      mdcv_wgrad_stem_splits_ok(splits, B, Hout, Wout)) {      // 7x7 stem with the input padded to 16 channels: LDS-ring kernel
+    const int rc = mdcv_wgrad_stem(dy, dy_ldc, x, x_ldc, ws, splits, B, Hout, Wout, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, 49, accumulate, (hipStream_t)stream);
+  }
   if (use_wgrad_stream(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc) &&
       mdcv_wgrad_stream_splits_ok(splits, B, Hout, Wout, Cin, Cout, dil)) {
     const int rc = mdcv_wgrad_stream(dy, dy_ldc, x, x_ldc, ws, splits, B, Hout, Wout, Cin, Cout, dil, (hipStream_t)stream);

@@ -303,6 +303,128 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// RektNet's stem: 7x7 / stride 1 / pad 3, 3 input channels (padded to 16 by the caller for this kernel) -> 16 output channels.
+// The im2col kernel filled 49 x the activations (163 us alone, 325 us inside the step, for a 79 MB problem).  Same stream / ring scheme
+// as above with three shared zero columns and rows; 16-channel rows (32 bytes: 8 consecutive rows = one bank period, no swizzle
+// needed); a wave owns one 32-position sub-step per 256-position step and all 49 taps (196 accumulator VGPRs): per kernel row it
+// reads 7 fragments, then 7 MFMAs.  The ring carries a 32-row MIRROR of its first rows behind its end, so a fragment's rows
+// r .. r+22 never wrap and the 14 reads of a kernel row are ONE address + immediate offsets (the per-read wrap arithmetic was the
+// largest cost of the first version).  The 8 per-wave partial sums meet in LDS in fixed order; slab ws[split][16][49*16], summed by
+// the generic slab reduce.
+__global__ __launch_bounds__(512) void wgrad7x7_stream_kernel(WgradStreamArgs a, unsigned dy_bytes, unsigned x_bytes) {
+  constexpr int RB = 32, RPI = 32, BP = 256, YSTAGE = BP * RB, KT = 7, NT = KT * KT, MIRROR = 32;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
+  if (logical >= a.splits) return;
+  const int split = logical;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, x_bytes, 0x00020000);
+  const int RS = a.RS, rmask = a.RS - 1;
+  unsigned char* const ring = smem;                          // RS + MIRROR rows
+  unsigned char* const stages = smem + (RS + MIRROR) * RB;
+  const unsigned ybase = (unsigned)((RS + MIRROR) * RB);
+  const int p_begin = split * a.pos_per_split;
+  const int p_end = min(a.Mq, p_begin + a.pos_per_split);
+  const int p_lo = p_begin - a.hpad;
+  const float inv_sq = 1.0f / (float)a.Sq, inv_wq = 1.0f / (float)a.Wq;
+  const unsigned ldy2 = (unsigned)a.dy_ldc * 2u, lx2 = (unsigned)a.x_ldc * 2u;
+  const int rr = lane >> 1;                                  // DMA: lane -> row rr of the 32-row chunk, 16-byte half lane & 1
+  const unsigned lane_c = (unsigned)((lane & 1) * 16);
+  auto pix_off = [&](int p, unsigned ld2, bool ok) -> unsigned {
+    ok = ok && p >= 0 && p < a.Mq;
+    const int pp = ok ? p : 0;
+    int img, rem, y, x;
+    fast_divmod(pp, a.Sq, inv_sq, img, rem);
+    fast_divmod(rem, a.Wq, inv_wq, y, x);
+    ok = ok && x < a.W && y < a.H;
+    return ok ? __umul24((unsigned)((img * a.H + y) * a.W + x), ld2) : OOB;
+  };
+  auto issue_x = [&](int p, int rho) {                       // 32 rows at ring row rho (a multiple of 32); ring row 0's chunk also feeds the mirror
+    const unsigned off = pix_off(p + rr, lx2, true);
+    const int vo = (int)(off == OOB ? OOB : off + lane_c);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + rho * RB), 16, vo, 0, 0, 0);
+    if (rho == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + RS * RB), 16, vo, 0, 0, 0);
+  };
+  auto issue = [&](int t, int rho_new) {                     // step t: 256 new activation rows and 256 dY rows, one chunk of each per wave
+    const int p0 = p_begin + t * BP;
+    issue_x(p0 + a.hpad + wave * RPI, (rho_new + wave * RPI) & rmask);
+    const int p = p0 + wave * RPI + rr;
+    const unsigned off = pix_off(p, ldy2, p < p_end);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t*)(stages + (t & 1) * YSTAGE + wave * 1024), 16,
+                                             (int)(off == OOB ? OOB : off + lane_c), 0, 0, 0);
+  };
+  const int t16 = lane & 15, kq = lane >> 4;
+  const int prow = kq * 4 + (t16 >> 2);
+  const unsigned lcol = (unsigned)((((t16 & 3) >> 1) << 4) + (t16 & 1) * 8);     // 8 bytes of the 32-byte row
+
+  f32x4_t acc[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nt = (p_end - p_begin + BP - 1) / BP;
+  {
+    const int nch = 2 * a.hpad / RPI;                        // the window below the first step's new rows
+    for (int c = wave; c < nch; c += 8) issue_x(p_lo + c * RPI, c * RPI);
+  }
+  if (nt > 0) issue(0, (2 * a.hpad) & rmask);
+  int rho0 = a.hpad & rmask, rho_new = (2 * a.hpad + BP) & rmask;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (two steps in flight measured the same: the step is read/VALU-bound)
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nt) issue(t + 1, rho_new);
+    rho_new = (rho_new + BP) & rmask;
+    // this wave's sub-step: positions p0 + 32*wave .. +31
+    const unsigned ya = ybase + (unsigned)((t & 1) * YSTAGE + (wave * 32 + prow) * RB) + lcol;
+    bf16x8_t fa;
+    {
+      const s16x4_t lo = lds_tr16<0>(ya), hi = lds_tr16<16 * RB>(ya);
+      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      fa = __builtin_bit_cast(bf16x8_t, v);
+    }
+    const int rs = rho0 + wave * 32 + prow - 3;              // ring row of this lane's first position at tap (kh = 3, kw = 0)
+#pragma unroll
+    for (int kh = 0; kh < KT; ++kh) {
+      bf16x8_t fb[KT];
+      const unsigned ad = (unsigned)(((rs + (kh - 3) * a.Wq) & rmask) * RB) + lcol;     // rows ad .. ad+22 are contiguous thanks to the mirror
+#define MDCV_RD(KW)                                                                                        \
+      { const s16x4_t lo = lds_tr16<(KW) * RB>(ad), hi = lds_tr16<((KW) + 16) * RB>(ad);                   \
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                        \
+        fb[KW] = __builtin_bit_cast(bf16x8_t, v); }
+      MDCV_RD(0) MDCV_RD(1) MDCV_RD(2) MDCV_RD(3) MDCV_RD(4) MDCV_RD(5) MDCV_RD(6)
+#undef MDCV_RD
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]) :: "memory");
+#pragma unroll
+      for (int kw = 0; kw < KT; ++kw) acc[kh * KT + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[kw], acc[kh * KT + kw], 0, 0, 0);
+    }
+    rho0 = (rho0 + BP) & rmask;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // the 8 waves' partial sums meet in LDS, wave 0 first (fixed order), then coalesced rows of the split's slab [16][49*16]
+  constexpr int OR = NT * 16 + 4;
+  float* so = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+  for (int w = 0; w < 8; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int idx = (kq * 4 + r4) * OR + k * 16 + t16;
+          so[idx] = w == 0 ? acc[k][r4] : so[idx] + acc[k][r4];
+        }
+    }
+    __syncthreads();
+  }
+  float* __restrict__ ws = a.ws + (size_t)split * 16 * a.Ktot;
+  for (int v = tid; v < 16 * (NT * 16 / 4); v += 512) {
+    const int row = v / (NT * 4), c4 = (v - row * (NT * 4)) * 4;
+    *reinterpret_cast<float4*>(ws + (size_t)row * a.Ktot + c4) = *reinterpret_cast<const float4*>(so + row * OR + c4);
+  }
+}
+
 struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; };
 int g_stream_d = 0;        // tuning hook: force the prefetch depth (1..3); 0 = per-configuration default
 int g_stream_blocks = 0;   // tuning hook: force the target block count; 0 = default
@@ -430,3 +552,58 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
 }
 
 void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_alt = d >= 4; g_stream_d = d & 3; g_stream_blocks = blocks; }
+
+// ---- 7x7 stem (see wgrad7x7_stream_kernel)
+static int stem_hpad(int W) { return (3 * (W + 3 + 1) + 31) / 32 * 32; }
+static int stem_ring_rows(int W) { int need = 2 * 256 + 2 * stem_hpad(W), rs = 256; while (rs < need) rs *= 2; return rs; }
+static int stem_lds(int W) {
+  const int ring = (stem_ring_rows(W) + 32) * 32 + 2 * 256 * 32, stage_out = 16 * (49 * 16 + 4) * 4;
+  return ring > stage_out ? ring : stage_out;
+}
+bool mdcv_wgrad_stem_eligible(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
+                              long long dy_ldc, long long x_ldc) {
+  if (dtype != MDCV_BF16 || KH != 7 || KW != 7 || stride != 1 || pad != 3 || dil != 1 || Cin != 16 || Cout != 16) return false;
+  if (H < 8 || W < 8 || stem_lds(W) > 160 * 1024) return false;
+  const long long Mq = (long long)B * (H + 3) * (W + 3);
+  if (Mq + 8192 >= (1LL << 24) || (long long)B * H * W >= (1LL << 24)) return false;
+  if ((long long)B * H * W * dy_ldc * 2 >= (1LL << 31) || (long long)B * H * W * x_ldc * 2 >= (1LL << 31)) return false;
+  return dy_ldc < (1 << 23) && x_ldc < (1 << 23);
+}
+int mdcv_wgrad_stem_splits(int B, int H, int W) {
+  const int Mq = B * (H + 3) * (W + 3);
+  int s = 256;
+  const int max_s = (Mq + 256 * 4 - 1) / (256 * 4);
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  const int pps = ((Mq + s - 1) / s + 255) / 256 * 256;
+  return (Mq + pps - 1) / pps;
+}
+bool mdcv_wgrad_stem_splits_ok(int splits, int B, int H, int W) {
+  if (splits < 1) return false;
+  const int Mq = B * (H + 3) * (W + 3);
+  const int pps = ((Mq + splits - 1) / splits + 255) / 256 * 256;
+  return (Mq + pps - 1) / pps == splits;
+}
+int mdcv_wgrad_stem(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, hipStream_t st) {
+  WgradStreamArgs a;
+  a.dy = dy; a.x = x; a.ws = ws; a.dy_ldc = dy_ldc; a.x_ldc = x_ldc;
+  a.H = H; a.W = W; a.Cin = 16; a.Cout = 16; a.Ktot = 49 * 16; a.dil = 1;
+  a.Wq = W + 3; a.Sq = (H + 3) * (W + 3); a.Mq = B * a.Sq;
+  a.hpad = stem_hpad(W);
+  a.RS = stem_ring_rows(W);
+  a.pos_per_split = ((a.Mq + splits - 1) / splits + 255) / 256 * 256;
+  if ((a.Mq + a.pos_per_split - 1) / a.pos_per_split != splits) return MDCV_EARG;
+  a.splits = splits;
+  a.xcd_chunk = (splits + 7) / 8;
+  const int lds = stem_lds(W);
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad7x7_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_lds = lds;
+  }
+  const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
+  hipLaunchKernelGGL(wgrad7x7_stream_kernel, dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}

@@ -276,22 +276,26 @@ class Plan:
                   stats_partial.data_ptr() if stats_partial is not None else None,
                   x.B, x.H, x.W, cs.cin_pad, y.H, y.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
 
-    def emit_conv_bwd(self, cs, xnode, y_shape_act, dy):
-        """dy: Act gradient of the raw conv output.  Emits wgrad (+bias grad) and, if the input needs it, dgrad."""
+    def emit_conv_bwd(self, cs, xnode, y_shape_act, dy, x_wgrad=None):
+        """dy: Act gradient of the raw conv output.  Emits wgrad (+bias grad) and, if the input needs it, dgrad.
+        x_wgrad: a copy of the conv's input with a wider channel padding for the weight gradient only (the 7x7 stem's LDS-ring
+        kernel wants 16-channel rows; forward keeps the 8-channel buffer)."""
         L, dt = self.L, self.dtype
         x = xnode.act
+        xw = x_wgrad if x_wgrad is not None else x
+        cin_w = xw.C if x_wgrad is not None else cs.cin_pad
         gw = self.param_grad(cs.weight)
-        splits = int(L.conv2d_wgrad_splits_geom(dt, x.B, x.H, x.W, cs.cin_pad, dy.H, dy.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad,
-                                                cs.dil, dy.ldc, x.ldc))
-        self.ws_floats = max(self.ws_floats, splits * cs.cout_pad * cs.ktot)
+        splits = int(L.conv2d_wgrad_splits_geom(dt, xw.B, xw.H, xw.W, cin_w, dy.H, dy.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad,
+                                                cs.dil, dy.ldc, xw.ldc))
+        self.ws_floats = max(self.ws_floats, splits * cs.cout_pad * cs.kh * cs.kw * cin_w)
         plan = self
 
-        def wgrad(stream, cs=cs, x=x, dy=dy, gw=gw, splits=splits):
+        def wgrad(stream, cs=cs, x=xw, dy=dy, gw=gw, splits=splits, cin_w=cin_w):
             return L.conv2d_wgrad(dt, dy.ptr, dy.ldc, x.ptr, x.ldc, plan.wgrad_ws().data_ptr(), splits, gw.data_ptr(), 0,
-                                  x.B, x.H, x.W, cs.cin_pad, cs.cin, dy.H, dy.W, cs.cout_pad, cs.cout, cs.kh, cs.kw,
+                                  x.B, x.H, x.W, cin_w, cs.cin, dy.H, dy.W, cs.cout_pad, cs.cout, cs.kh, cs.kw,
                                   cs.stride, cs.pad, cs.dil, stream)
         wgrad.__name__ = "conv2d_wgrad"
-        wgrad.info = (x.B, x.H, x.W, cs.cin_pad, dy.H, dy.W, cs.cout_pad, cs.kh, cs.stride, splits)
+        wgrad.info = (x.B, x.H, x.W, cin_w, dy.H, dy.W, cs.cout_pad, cs.kh, cs.stride, splits)
         self.bwd.append((wgrad, ()))
         if xnode.needs_grad:
             out, add = self.grad_target(xnode)

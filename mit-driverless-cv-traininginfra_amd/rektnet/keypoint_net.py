@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from ..engine import TNode, ConvSpec, BnSpec, parse_precision, ACT_RELU
+from ..engine import TNode, ConvSpec, BnSpec, parse_precision, ACT_RELU, BF16
 from ..yolo.models import _NetPlan, FlatParamsMixin, _bump_counters
 from .resnet import ResNet
 
@@ -125,6 +125,17 @@ class KeypointNet(nn.Module, FlatParamsMixin):
         xin, holder = plan.emit_input(B, 3, H, W)
         plan.pre.append(plan.fwd.pop())
         plan.in_holder = holder
+        plan.x16 = None
+        if os.environ.get("MDCV_STEM16", "1") == "1" and bn_train and not logits_only and plan.dtype == BF16 and self.conv.kernel_size == (7, 7) and self.conv.padding == (3, 3) \
+                and self.conv.out_channels == 16:
+            # second copy of the input with 16-channel rows: the stem's weight gradient runs the LDS-ring kernel on it (csrc/wgrad_stream.hip)
+            x16 = plan.new_act(B, H, W, 16)
+            plan.x16 = x16
+
+            def convert16(stream, x16=x16):
+                return L.nchw_to_nhwc(dt, holder["src"].data_ptr(), x16.ptr, B, 3, H, W, x16.ldc, x16.C, stream)
+            convert16.__name__ = "nchw_to_nhwc"
+            plan.pre.append((convert16, ()))
         plan.targets = None
         nbt = []
         recs = []
@@ -204,7 +215,7 @@ class KeypointNet(nn.Module, FlatParamsMixin):
             else:
                 _, cs0, bs0, xin_, y0, a0 = r
                 dy0 = plan.emit_bn_act_bwd(a0.grad, y0, bs0, ACT_RELU, 0.0)
-                plan.emit_conv_bwd(cs0, xin_, y0, dy0)
+                plan.emit_conv_bwd(cs0, xin_, y0, dy0, x_wgrad=plan.x16)
                 plan.emit_bias_grad(cs0, None, zero_only=True)
         plan.mark_ready()
         return plan

@@ -680,3 +680,39 @@ def test_wgrad_stream_accumulate_and_determinism():
         res.append(dw.cpu().numpy())
     assert np.array_equal(res[0], res[1])
     np.testing.assert_allclose(res[2], res[0] + 2.5, rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 80, 80), (3, 33, 20), (5, 9, 12), (1, 128, 96)], ids=str)
+def test_wgrad_stem_7x7_kernel(case):
+    """RektNet's 7x7 / pad 3 stem (3 real input channels in a 16-channel buffer, 16 output channels): LDS-ring kernel == torch ==
+    the generic kernel on the same buffers; accumulate flag; guard region behind the slabs."""
+    L = _lib.lib()
+    dt = BF16
+    B, H, W = case
+    Ci, Co = 3, 16
+    g = torch.Generator().manual_seed(H * 3 + W)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    w = torch.zeros(Co, Ci, 7, 7, requires_grad=True)
+    F.conv2d(rnd(dt, x), w, None, stride=1, padding=3).backward(rnd(dt, dy))
+    ref = w.grad.numpy()
+    xb, dyb = to_nhwc(x, dt, cpad=16), to_nhwc(dy, dt)
+    outs = {}
+    for variant in (0, 9):
+        L.conv2d_wgrad_set_variant(variant)
+        try:
+            splits = L.conv2d_wgrad_splits_geom(dt, B, H, W, 16, H, W, Co, 7, 7, 1, 3, 1, Co, 16)
+            n = splits * Co * 49 * 16
+            ws = torch.full((n + 4096,), float("nan"), dtype=torch.float32, device="cuda")
+            dw = torch.full((Co, Ci, 7, 7), 2.0, dtype=torch.float32, device="cuda")
+            L.check(L.conv2d_wgrad(dt, dyb.data_ptr(), Co, xb.data_ptr(), 16, ws.data_ptr(), splits, dw.data_ptr(), 1, B, H, W, 16, Ci,
+                                   H, W, Co, Co, 7, 7, 1, 3, 1, st()), "wgrad")
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(ws[n:]).all()), "slabs written past the end"
+            outs[variant] = dw.cpu().numpy() - 2.0
+        finally:
+            L.conv2d_wgrad_set_variant(0)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for v, got in outs.items():
+        np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * scale, err_msg=f"variant {v}")
+    np.testing.assert_allclose(outs[0], outs[9], rtol=1e-3, atol=1e-3 * scale)
