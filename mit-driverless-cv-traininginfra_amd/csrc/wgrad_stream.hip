@@ -373,7 +373,9 @@ __global__ __launch_bounds__(512) void wgrad7x7_stream_kernel(WgradStreamArgs a,
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (two steps in flight measured the same: the step is read/VALU-bound)
     __builtin_amdgcn_s_barrier();
+#ifndef MDCV_STEM_NODMA
     if (t + 1 < nt) issue(t + 1, rho_new);
+#endif
     rho_new = (rho_new + BP) & rmask;
     // this wave's sub-step: positions p0 + 32*wave .. +31
     const unsigned ya = ybase + (unsigned)((t & 1) * YSTAGE + (wave * 32 + prow) * RB) + lcol;
@@ -396,32 +398,35 @@ __global__ __launch_bounds__(512) void wgrad7x7_stream_kernel(WgradStreamArgs a,
 #undef MDCV_RD
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]) :: "memory");
 #pragma unroll
+#ifndef MDCV_STEM_NOMFMA
       for (int kw = 0; kw < KT; ++kw) acc[kh * KT + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[kw], acc[kh * KT + kw], 0, 0, 0);
+#endif
     }
     rho0 = (rho0 + BP) & rmask;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // the 8 waves' partial sums meet in LDS, wave 0 first (fixed order), then coalesced rows of the split's slab [16][49*16]
-  constexpr int OR = NT * 16 + 4;
-  float* so = reinterpret_cast<float*>(smem);
-#pragma unroll 1
-  for (int w = 0; w < 8; ++w) {
-    if (wave == w) {
+  // The 8 waves' partial sums (49 tiles of 16x16 each) meet in LDS one kernel row at a time: every wave stores its 7 tiles, then all
+  // 512 threads add the eight copies in fixed order (w = 0..7) and write the 16 x 112 floats of that kernel row to the split's slab.
+  // (Eight serialised accumulate rounds over all 49 tiles, as in the 3x3 kernel, cost 25-40 us here: 196 read-modify-writes per
+  //  lane per round with seven waves idle.)
+  float* so = reinterpret_cast<float*>(smem);                // [8 waves][7 kw][16 co][16 ci]
+  float* __restrict__ ws = a.ws + (size_t)split * 16 * a.Ktot;
 #pragma unroll
-      for (int k = 0; k < NT; ++k)
+  for (int kh = 0; kh < KT; ++kh) {
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int idx = (kq * 4 + r4) * OR + k * 16 + t16;
-          so[idx] = w == 0 ? acc[k][r4] : so[idx] + acc[k][r4];
-        }
+    for (int kw = 0; kw < KT; ++kw)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) so[((wave * KT + kw) * 16 + kq * 4 + r4) * 16 + t16] = acc[kh * KT + kw][r4];
+    __syncthreads();
+    for (int v = tid; v < 16 * KT * 16; v += 512) {          // v -> (co, kw, ci): 112 contiguous floats per output channel
+      const int co = v / (KT * 16), rem = v - co * (KT * 16), kw = rem >> 4, ci = rem & 15;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += so[((w * KT + kw) * 16 + co) * 16 + ci];
+      ws[(size_t)co * a.Ktot + (kh * KT + kw) * 16 + ci] = t;
     }
     __syncthreads();
-  }
-  float* __restrict__ ws = a.ws + (size_t)split * 16 * a.Ktot;
-  for (int v = tid; v < 16 * (NT * 16 / 4); v += 512) {
-    const int row = v / (NT * 4), c4 = (v - row * (NT * 4)) * 4;
-    *reinterpret_cast<float4*>(ws + (size_t)row * a.Ktot + c4) = *reinterpret_cast<const float4*>(so + row * OR + c4);
   }
 }
 
@@ -557,7 +562,7 @@ void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_alt = d >= 4; g_stream
 static int stem_hpad(int W) { return (3 * (W + 3 + 1) + 31) / 32 * 32; }
 static int stem_ring_rows(int W) { int need = 2 * 256 + 2 * stem_hpad(W), rs = 256; while (rs < need) rs *= 2; return rs; }
 static int stem_lds(int W) {
-  const int ring = (stem_ring_rows(W) + 32) * 32 + 2 * 256 * 32, stage_out = 16 * (49 * 16 + 4) * 4;
+  const int ring = (stem_ring_rows(W) + 32) * 32 + 2 * 256 * 32, stage_out = 8 * 7 * 256 * 4;
   return ring > stage_out ? ring : stage_out;
 }
 bool mdcv_wgrad_stem_eligible(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
