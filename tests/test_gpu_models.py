@@ -742,3 +742,23 @@ def test_full_yolov3_training_is_bit_reproducible(tmp_path):
     (la, pa), (lb, pb) = run(), run()
     assert la == lb, (la, lb)
     assert torch.equal(pa, pb)
+
+
+def test_bench_two_ranks_on_one_gpu_keep_replicas_in_sync():
+    """The N > 1 path of bench.py (one process per rank, gradients all-reduced bucket by bucket while backward and the side-stream
+    weight gradients still run, same optimizer step on every rank) with two ranks sharing this GPU over the gloo backend (RCCL refuses
+    two ranks on one device): the JSON line reports n_gpus 2 and identical parameters on both ranks after the timed steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MDCV_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "yolo", "--yolo-batch", "4",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-breakdown"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 8
+    assert line["workloads"]["yolo"]["replicas_in_sync"] is True
+    assert line["value"] > 0
