@@ -34,6 +34,12 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
                 const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
                 int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
                 int KH, int KW, int stride, int pad, int dil, void* stream);
+/* Inference forward (Darknet.forward / KeypointNet.forward in eval mode: conv -> BatchNorm(running stats) -> activation, models.py:48-72,
+ * resnet.py:22-27): out = act(conv(in) * scale[n] + shift[n]) (+ addsrc, e.g. the shortcut input), scale/shift from mdcv_bn_eval_coeffs
+ * (or scale = NULL: bias only).  act: MDCV_ACT_*.  The raw conv output never goes to HBM. */
+int mdcv_conv2d_affine_act(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const float* scale,
+                           const float* shift, const void* addsrc, int add_ldc, int act, float slope, int B, int Hin, int Win, int Cin,
+                           int Hout, int Wout, int Nout, int KH, int KW, int stride, int pad, int dil, void* stream);
 /* Data gradient (mode 1, same geometry arguments as mdcv_conv2d) that also writes the BatchNorm-backward partial sums of the layer
  * whose output gradient it produces: partial[row][0][c] = sum g, partial[row][1][c] = sum g*(y - mean), g = dz * act'(scale*y + shift),
  * one row per 128 output positions (y: that layer's raw conv output, same pixel/channel indexing as the gradient written to `out`).
@@ -81,6 +87,10 @@ int mdcv_bn_finalize(double* accum, double count, const float* gamma, const floa
                      float momentum, float eps, float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
 int mdcv_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                         float* scale, float* shift, int C, void* stream);
+/* the same for a conv that has its own bias in front of the BatchNorm (RektNet): shift also absorbs conv_bias * scale, so that
+ * mdcv_conv2d_affine_act(scale, shift) == BatchNorm_eval(conv + bias).  conv_bias may be NULL. */
+int mdcv_bn_eval_coeffs_bias(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                             const float* conv_bias, float* scale, float* shift, int C, void* stream);
 /* out = act(y1*s1+b1 [+ y2*s2+b2]) [+ resid] */
 int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const float* b1, const void* y2, int ld2, const float* s2,
                     const float* b2, const void* resid, int ldr, void* out, int ldo, int M, int C, int act, float slope, void* stream);

@@ -8,6 +8,10 @@
 #pragma once
 #include "common.h"
 
+// Inference epilogue of a forward conv: out = act(acc * oscale[n] + bias[n]) (+ addsrc) -- BatchNorm with running statistics and the
+// activation folded into the conv's store path (mdcv_conv2d_affine_act).  oscale == NULL: plain bias epilogue.
+struct EpiArgs { const float* oscale; int act; float slope; };
+
 struct BnFuseArgs {
   const void* y;            // raw conv output of the BatchNorm being differentiated, same [pixel][channel] indexing as dz; NULL = off
   const float* scale; const float* shift; const float* mean;

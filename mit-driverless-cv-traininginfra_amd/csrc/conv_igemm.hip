@@ -33,6 +33,7 @@ struct ConvArgs {
   int M, Ktot, tiles_n, sshift, tiles_total, xcd_chunk;
   int ph, pw, Hs, Ws, kh0, kw0, nkh, nkw;     // MODE 2 (stride-2 data gradient, one output-parity class per launch)
   BnFuseArgs fuse;                            // BatchNorm-backward sums folded into the store loop of a data gradient (fuse.y == NULL: off)
+  EpiArgs epi;                                // inference epilogue act(acc * oscale + bias) (oscale == NULL and act == 0: off)
 };
 
 // One K tile of MFMAs for a wave: FM x FN fragments of 16x16, KT k-steps of 64 bytes per LDS row (row pitch RB bytes).
@@ -193,7 +194,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
 
   // ---------------- epilogue ----------------
   const int n0 = tile_n * BN + wn * TN, m0 = tile_m * BM + wm * TM;
-  if (a.bias) {
+  if (a.epi.oscale || a.epi.act) {                         // inference: act(acc * scale + shift), once per tile, block-uniform branch
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + j * 16 + (lane & 15);
+      const float sc = (a.epi.oscale && n < a.Nout) ? a.epi.oscale[n] : 1.f;
+      const float bv = (a.bias && n < a.Nout) ? a.bias[n] : 0.f;
+      const float sl = a.epi.act == 1 ? a.epi.slope : (a.epi.act == 2 ? 0.f : 1.f);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r] * sc + bv;
+          acc[i][j][r] = v > 0.f ? v : v * sl;
+        }
+    }
+  } else if (a.bias) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = n0 + j * 16 + (lane & 15);
@@ -573,7 +589,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
 
   // ---------------- epilogue (same as the register-staged kernel) ----------------
   const int n0 = tile_n * BN + wn * TN, m0 = tile_m * BM + wm * TM;
-  if (a.bias) {
+  if (a.epi.oscale || a.epi.act) {                         // inference: act(acc * scale + shift), once per tile, block-uniform branch
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + j * 16 + (lane & 15);
+      const float sc = (a.epi.oscale && n < a.Nout) ? a.epi.oscale[n] : 1.f;
+      const float bv = (a.bias && n < a.Nout) ? a.bias[n] : 0.f;
+      const float sl = a.epi.act == 1 ? a.epi.slope : (a.epi.act == 2 ? 0.f : 1.f);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r] * sc + bv;
+          acc[i][j][r] = v > 0.f ? v : v * sl;
+        }
+    }
+  } else if (a.bias) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = n0 + j * 16 + (lane & 15);
@@ -1621,8 +1652,9 @@ extern "C" {
 static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc,
                        const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
                        int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
-                       int KH, int KW, int stride, int pad, int dil, const BnFuseArgs* fuse, void* stream) {
+                       int KH, int KW, int stride, int pad, int dil, const BnFuseArgs* fuse, void* stream, const EpiArgs* epi = nullptr) {
   if (!in || !w_packed || !out) return MDCV_EARG;
+  if (epi && (mode != 0 || stats_partial || fuse)) return MDCV_EARG;        // the inference epilogue is a forward-only, statistics-free path
   if ((Cin & 7) || (Nout & 7) || (in_ldc & 7) || (out_ldc & 7) || (addsrc && (add_ldc & 7))) return MDCV_EARG;
   if (stride != 1 && stride != 2) return MDCV_EARG;
   if (mode != 0 && mode != 1) return MDCV_EARG;
@@ -1634,6 +1666,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin; a.tiles_n = 0; a.sshift = stride == 2 ? 1 : 0; a.tiles_total = 0; a.xcd_chunk = 0;
   a.ph = a.pw = a.kh0 = a.kw0 = 0; a.Hs = Hout; a.Ws = Wout; a.nkh = KH; a.nkw = KW;
   a.fuse = fuse ? *fuse : BnFuseArgs{};
+  a.epi = epi ? *epi : EpiArgs{nullptr, 0, 0.f};
   if (a.M <= 0) return MDCV_OK;
   hipStream_t st = (hipStream_t)stream;
   // stride-2 data gradient: 4 launches, one per output-parity class, each visiting only its live taps (no masked MACs)
@@ -1664,7 +1697,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   // 3x3 / stride 1 / pad 1 on wide layers: nine shifted GEMMs over one LDS-resident activation chunk (conv_shift.hip)
   const bool shift_ok = Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc);
   if (shift_ok && (g_conv_variant < 0 || fuse))
-    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st);
+    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st, epi);
   if (fuse) {                                     // the fused store loop lives in the LDS-DMA kernels: never fall back to the staged ones
     if (!small) return MDCV_EARG;
     const int keep = g_conv_variant;
@@ -1697,6 +1730,17 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
 // layer that produced the tensor whose gradient this is:  partial[row][0][c] = sum g, partial[row][1][c] = sum g*(y - mean),
 // g = dz * act'(scale*y + shift), one row per 128 output positions.  rows() returns how many rows are written for a geometry,
 // or 0 when this geometry cannot take the fused path (the caller then keeps mdcv_conv2d + mdcv_bn_act_bwd_reduce).
+/* Inference forward: out = act(conv(in) * scale[n] + shift[n]) (+ addsrc).  BatchNorm with running statistics (scale/shift from
+ * mdcv_bn_eval_coeffs) and the activation run in the conv's store path: the raw conv output never goes to HBM. */
+int mdcv_conv2d_affine_act(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const float* scale,
+                           const float* shift, const void* addsrc, int add_ldc, int act, float slope, int B, int Hin, int Win, int Cin,
+                           int Hout, int Wout, int Nout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+  if (act < 0 || act > 2) return MDCV_EARG;
+  const EpiArgs e{scale, act, slope};
+  return conv2d_impl(dtype, 0, in, in_ldc, w_packed, out, out_ldc, shift, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Hout, Wout, Nout,
+                     KH, KW, stride, pad, dil, nullptr, stream, &e);
+}
+
 int mdcv_conv2d_dgrad_bnsums_rows(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
                                   int pad, int dil, int in_ldc) {
   const int es = 2;

@@ -11,6 +11,7 @@ struct ShiftArgs {
   int tiles_n, tiles_total, xcd_chunk;
   int p_base;                           // first stream position of this launch (multiple of 256)
   BnFuseArgs fuse;                      // BatchNorm-backward sums folded into the store loop (fuse.y == NULL: off)
+  EpiArgs epi;                          // inference epilogue (oscale == NULL and act == 0: off)
   int nchunks, wrow, nca;               // Cin/32 ; 9*Cin elements per weight row ; KiB-chunks per activation chunk
 };
 
@@ -18,5 +19,6 @@ bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int 
 int mdcv_shift_stats_rows(int B, int H, int W);                 // partial rows of the fused data-gradient sums (one per 128 positions)
 int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout);  // partial rows of the forward statistics (depends on the tile plan)
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
-                    int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st);
+                    int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st,
+                    const EpiArgs* epi = nullptr);
 void mdcv_shift_set_ring(int ring);

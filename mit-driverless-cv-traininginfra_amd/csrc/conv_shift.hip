@@ -223,7 +223,22 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
     rowpix[tid] = ok ? (img * a.H + y) * a.W + x : -1;
   }
   const int n0 = tile_n * BN + wn * TN;
-  if (a.bias) {
+  if (a.epi.oscale || a.epi.act) {                         // inference: act(acc * scale + shift), once per tile, block-uniform branch
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + j * 16 + (lane & 15);
+      const float sc = (a.epi.oscale && n < a.Nout) ? a.epi.oscale[n] : 1.f;
+      const float bv = (a.bias && n < a.Nout) ? a.bias[n] : 0.f;
+      const float sl = a.epi.act == 1 ? a.epi.slope : (a.epi.act == 2 ? 0.f : 1.f);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float v = acc[i][j][rr] * sc + bv;
+          acc[i][j][rr] = v > 0.f ? v : v * sl;
+        }
+    }
+  } else if (a.bias) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = n0 + j * 16 + (lane & 15);
@@ -476,9 +491,11 @@ int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout) {
 }
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
-                    int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st) {
+                    int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st,
+                    const EpiArgs* epi) {
   ShiftArgs a;
   if (fuse) a.fuse = *fuse; else a.fuse = BnFuseArgs{};
+  if (epi) a.epi = *epi; else a.epi = EpiArgs{nullptr, 0, 0.f};
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addsrc = addsrc; a.stats = stats;
   a.in_ldc = in_ldc; a.out_ldc = out_ldc; a.add_ldc = add_ldc;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Nout = Nout;

@@ -165,6 +165,17 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
   scale[c] = gamma[c] * is;
   shift[c] = beta[c] - rm[c] * gamma[c] * is;
 }
+// the same with the conv's own bias folded in: BN(conv + b) = conv * scale + (shift + b * scale)
+__global__ void bn_eval_coeffs_bias_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                           const float* __restrict__ rv, float eps, const float* __restrict__ conv_bias,
+                                           float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc + (conv_bias ? conv_bias[c] * sc : 0.f);
+}
 
 // ---------------------------------------------------------------- fused BN-apply + activation (+ second BN branch) (+ residual)
 struct BnActArgs {
@@ -703,6 +714,14 @@ int mdcv_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
                         float* scale, float* shift, int C, void* stream) {
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean,
                      running_var, eps, scale, shift, C);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_bn_eval_coeffs_bias(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                             const float* conv_bias, float* scale, float* shift, int C, void* stream) {
+  hipLaunchKernelGGL(bn_eval_coeffs_bias_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                     running_var, eps, conv_bias, scale, shift, C);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -336,6 +336,18 @@ class Plan:
         self.call(self.fwd, self.L.bn_eval_coeffs, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                   bn.running_var.data_ptr(), float(bn.eps), bs.scale.data_ptr(), bs.shift.data_ptr(), bs.C)
 
+    def emit_conv_bn_act_eval(self, cs, bs, x, out, act, slope, resid=None):
+        """Inference: conv -> BatchNorm(running statistics) -> activation (+ residual) as ONE launch: the coefficients (with the conv's
+        own bias folded into the shift) are refreshed by a tiny kernel, then the conv's store path applies them
+        (mdcv_conv2d_affine_act); the raw conv output never exists in HBM."""
+        bn = bs.bn
+        self.call(self.fwd, self.L.bn_eval_coeffs_bias, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                  bn.running_var.data_ptr(), float(bn.eps), cs.bias_pad.data_ptr() if cs.bias_pad is not None else None,
+                  bs.scale.data_ptr(), bs.shift.data_ptr(), bs.C)
+        self.call(self.fwd, self.L.conv2d_affine_act, self.dtype, x.ptr, x.ldc, cs.wf.data_ptr(), out.ptr, out.ldc, bs.scale.data_ptr(),
+                  bs.shift.data_ptr(), resid.ptr if resid is not None else None, resid.ldc if resid is not None else 0, act, float(slope),
+                  x.B, x.H, x.W, cs.cin_pad, out.H, out.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
+
     def emit_bn_act_fwd(self, y1, bs1, out, act, slope, y2=None, bs2=None, resid=None):
         self.call(self.fwd, self.L.bn_act_fwd, self.dtype, y1.ptr, y1.ldc, bs1.scale.data_ptr(), bs1.shift.data_ptr(),
                   y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,

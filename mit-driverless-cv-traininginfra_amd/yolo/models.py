@@ -203,6 +203,9 @@ class _DarknetTrainFn(torch.autograd.Function):
         return (None, None, None, None) + (None,) * len(model._plist)
 
 
+_EVAL_FUSE = os.environ.get("MDCV_EVAL_FUSE", "1") == "1"     # inference: conv + BatchNorm(running stats) + activation in one launch
+
+
 class _NetPlan(Plan):
     """engine.Plan + the per-network I/O buffers and the run_* entry points."""
 
@@ -552,18 +555,26 @@ class Darknet(nn.Module, FlatParamsMixin):
                         plan.emit_bn_stats(bs, y, partial, rows)
                         nbt.append(bn.num_batches_tracked)
                     else:
-                        plan.emit_conv_fwd(cs, cur.act, y)
-                        plan.emit_bn_eval(bs)
+                        one_launch = _EVAL_FUSE and not with_targets       # inference: BN + activation in the conv's store path
+                        if not one_launch:
+                            plan.emit_conv_fwd(cs, cur.act, y)
+                            plan.emit_bn_eval(bs)
                     if fuse:
                         rnode = outs[res(i + 1, int(defs[i + 1]["from"]))]
                         z = TNode(out_act(i + 1), name="short%d" % (i + 1))
-                        plan.emit_bn_act_fwd(y, bs, z.act, act_code, slope, resid=rnode.act)
+                        if not bn_train and one_launch:
+                            plan.emit_conv_bn_act_eval(cs, bs, cur.act, z.act, act_code, slope, resid=rnode.act)
+                        else:
+                            plan.emit_bn_act_fwd(y, bs, z.act, act_code, slope, resid=rnode.act)
                         fused_into[i + 1] = z
                         recs.append(("convbn", cs, bs, cur, y, z, rnode))
                         outs[i] = None
                     else:
                         z = TNode(out_act(i), name="conv%d" % i)
-                        plan.emit_bn_act_fwd(y, bs, z.act, act_code, slope)
+                        if not bn_train and one_launch:
+                            plan.emit_conv_bn_act_eval(cs, bs, cur.act, z.act, act_code, slope)
+                        else:
+                            plan.emit_bn_act_fwd(y, bs, z.act, act_code, slope)
                         recs.append(("convbn", cs, bs, cur, y, z, None))
                         outs[i] = z
                     cur = z

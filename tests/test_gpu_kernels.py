@@ -716,3 +716,51 @@ def test_wgrad_stem_7x7_kernel(case):
     for v, got in outs.items():
         np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * scale, err_msg=f"variant {v}")
     np.testing.assert_allclose(outs[0], outs[9], rtol=1e-3, atol=1e-3 * scale)
+
+
+# (B, Cin, H, W, Cout, k, stride, with_resid, act): shift kernel, 1x1 / stride-2 / narrow im2col tiles, every activation code
+AFFINE_CASES = [(3, 128, 26, 26, 256, 3, 1, True, 1), (2, 256, 13, 13, 128, 1, 1, False, 1), (2, 64, 30, 30, 128, 3, 2, False, 1),
+                (2, 16, 40, 40, 32, 3, 1, False, 2), (1, 32, 20, 17, 64, 3, 1, True, 0), (2, 8, 24, 24, 16, 7, 1, False, 2)]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", AFFINE_CASES, ids=[str(c) for c in AFFINE_CASES])
+def test_conv2d_affine_act_inference_epilogue(case, dt):
+    """mdcv_conv2d_affine_act == act(conv(x) * scale + shift) (+ residual) in torch, and == the two-pass form (mdcv_conv2d followed by
+    mdcv_bn_act_fwd) up to the bf16 rounding of the intermediate the fused form never stores."""
+    L = _lib.lib()
+    B, Ci, H, W, Co, k, s, with_resid, act = case
+    p = (k - 1) // 2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    g = torch.Generator().manual_seed(Ci + Co + k)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    scale = torch.rand(Co, generator=g) + 0.5
+    shift = torch.randn(Co, generator=g) * 0.3
+    resid = torch.randn(B, Co, Ho, Wo, generator=g) if with_resid else None
+    slope = 0.1
+    y = F.conv2d(rnd(dt, x), rnd(dt, w), None, stride=s, padding=p) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref = {0: y, 1: F.leaky_relu(y, slope), 2: F.relu(y)}[act]
+    if with_resid:
+        ref = ref + rnd(dt, resid)
+    cip, cop = pad8(Ci), pad8(Co)
+    xb = to_nhwc(x, dt)
+    wf, _ = pack(dt, w, need_d=False)
+    rb = to_nhwc(resid, dt) if with_resid else None
+    sc, sh = torch.zeros(cop), torch.zeros(cop)
+    sc[:Co], sh[:Co] = scale, shift
+    sc, sh = sc.cuda(), sh.cuda()
+    out = torch.full((B, Ho, Wo, cop), float("nan"), dtype=TD[dt], device="cuda")
+    L.check(L.conv2d_affine_act(dt, xb.data_ptr(), cip, wf.data_ptr(), out.data_ptr(), cop, sc.data_ptr(), sh.data_ptr(),
+                                rb.data_ptr() if rb is not None else None, cop, act, slope, B, H, W, cip, Ho, Wo, cop, k, k, s, p, 1, st()), "affine_act")
+    got = to_nchw(out, dt, Co).numpy()
+    tol = 1e-4 if dt == F32 else 2e-2
+    np.testing.assert_allclose(got, ref.numpy(), rtol=tol, atol=tol * max(1.0, float(ref.abs().max())))
+    # two-pass form on the same operands
+    ybuf = torch.empty(B, Ho, Wo, cop, dtype=TD[dt], device="cuda")
+    L.check(L.conv2d(dt, 0, xb.data_ptr(), cip, wf.data_ptr(), ybuf.data_ptr(), cop, None, None, 0, None, B, H, W, cip, Ho, Wo, cop, k, k, s, p, 1, st()))
+    out2 = torch.empty_like(out)
+    L.check(L.bn_act_fwd(dt, ybuf.data_ptr(), cop, sc.data_ptr(), sh.data_ptr(), None, 0, None, None, rb.data_ptr() if rb is not None else None,
+                         cop, out2.data_ptr(), cop, B * Ho * Wo, cop, act, slope, st()))
+    got2 = to_nchw(out2, dt, Co).numpy()
+    np.testing.assert_allclose(got, got2, rtol=tol, atol=tol * max(1.0, float(ref.abs().max())))
