@@ -98,10 +98,11 @@ class KeypointNet(nn.Module, FlatParamsMixin):
         B, _, H, W = x.shape
         if (H, W) != tuple(self.image_size):
             raise ValueError(f"KeypointNet was built for image_size={self.image_size}, got {(H, W)}")
-        key = (B, H, W, self.training, self.onnx_mode, self.precision, x.device.index)
+        infer = not self.training and not torch.is_grad_enabled() and not self.onnx_mode      # no backward can follow: one-launch conv+BN+ReLU
+        key = (B, H, W, self.training, self.onnx_mode, self.precision, x.device.index, infer)
         plan = self._plans.get(key)
         if plan is None:
-            plan = self._build_plan(x.device, B, H, W, self.training, self.onnx_mode)
+            plan = self._build_plan(x.device, B, H, W, self.training, self.onnx_mode, infer=infer)
             self._plans[key] = plan
         if self.onnx_mode:
             plan.run_forward(x)
@@ -113,7 +114,7 @@ class KeypointNet(nn.Module, FlatParamsMixin):
             hm, pts = plan.hm.clone(), plan.pts.clone()
         return hm, pts.view(-1, self.num_kpt, 2)
 
-    def _build_plan(self, device, B, H, W, bn_train, logits_only):
+    def _build_plan(self, device, B, H, W, bn_train, logits_only, infer=False):
         plan = _KpPlan(device, self.precision, bn_train, grad_sink=self._grad_view)
         plan.grad_offset = lambda p: self._goff[id(p)][0]
         plan.use_graph = self.use_graph
@@ -140,10 +141,16 @@ class KeypointNet(nn.Module, FlatParamsMixin):
         nbt = []
         recs = []
 
-        def conv_bn(conv, bn, xnode):
+        one_launch = infer and os.environ.get("MDCV_EVAL_FUSE", "1") == "1"
+
+        def conv_bn(conv, bn, xnode, relu_into=None):
+            """relu_into: the activation buffer of a conv -> BN -> ReLU chain; in inference plans the three run as one launch."""
             cs = ConvSpec(plan, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0], cin_pad=xnode.act.C)
             plan.emit_pack(cs, need_dgrad=xnode.needs_grad)
             bs = BnSpec(plan, bn)
+            if one_launch and relu_into is not None:
+                plan.emit_conv_bn_act_eval(cs, bs, xnode.act, relu_into, ACT_RELU, 0.0)
+                return cs, bs, None
             y = plan.new_act(B, H, W, conv.out_channels)
             if bn_train:
                 rows = plan.stats_rows(cs, xnode.act, y)
@@ -156,15 +163,17 @@ class KeypointNet(nn.Module, FlatParamsMixin):
                 plan.emit_bn_eval(bs)
             return cs, bs, y
 
-        cs0, bs0, y0 = conv_bn(self.conv, self.bn, xin)
         a = TNode(plan.new_act(B, H, W, 16), name="stem")
-        plan.emit_bn_act_fwd(y0, bs0, a.act, ACT_RELU, 0.0)
+        cs0, bs0, y0 = conv_bn(self.conv, self.bn, xin, relu_into=a.act)
+        if y0 is not None:
+            plan.emit_bn_act_fwd(y0, bs0, a.act, ACT_RELU, 0.0)
         recs.append(("stem", cs0, bs0, xin, y0, a))
         for blk in (self.res1, self.res2, self.res3, self.res4):
             x = a
-            cs1, bs1, y1 = conv_bn(blk.conv1, blk.bn1, x)
             mid = TNode(plan.new_act(B, H, W, blk.conv1.out_channels), name="mid")
-            plan.emit_bn_act_fwd(y1, bs1, mid.act, ACT_RELU, 0.0)
+            cs1, bs1, y1 = conv_bn(blk.conv1, blk.bn1, x, relu_into=mid.act)
+            if y1 is not None:
+                plan.emit_bn_act_fwd(y1, bs1, mid.act, ACT_RELU, 0.0)
             cs2, bs2, y2 = conv_bn(blk.conv2, blk.bn2, mid)
             css, bss, ys = conv_bn(blk.shortcut_conv, blk.shortcut_bn, x)
             out = TNode(plan.new_act(B, H, W, blk.conv2.out_channels), name="blk")
@@ -188,7 +197,9 @@ class KeypointNet(nn.Module, FlatParamsMixin):
         plan.dpts = torch.zeros(B, K, 2, dtype=torch.float32, device=device)
         plan.sdot = torch.zeros(B * K, dtype=torch.float32, device=device)
         plan.call(plan.fwd, L.softargmax_fwd, dt, lg.act.ptr, lg.act.ldc, B, K, H, W, plan.hm.data_ptr(), plan.pts.data_ptr())
-        plan.has_bwd = True
+        plan.has_bwd = not infer
+        if infer:                          # inference plan: forward list only (the raw conv outputs a backward would need do not exist)
+            return plan
 
         # ---------------- backward ----------------
         dlg, add = plan.grad_target(lg)
