@@ -194,22 +194,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
 
   // ---------------- epilogue ----------------
   const int n0 = tile_n * BN + wn * TN, m0 = tile_m * BM + wm * TM;
-  if (a.epi.oscale || a.epi.act) {                         // inference: act(acc * scale + shift), once per tile, block-uniform branch
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = n0 + j * 16 + (lane & 15);
-      const float sc = (a.epi.oscale && n < a.Nout) ? a.epi.oscale[n] : 1.f;
-      const float bv = (a.bias && n < a.Nout) ? a.bias[n] : 0.f;
-      const float sl = a.epi.act == 1 ? a.epi.slope : (a.epi.act == 2 ? 0.f : 1.f);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = acc[i][j][r] * sc + bv;
-          acc[i][j][r] = v > 0.f ? v : v * sl;
-        }
-    }
-  } else if (a.bias) {
+  if (a.bias) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = n0 + j * 16 + (lane & 15);
@@ -288,6 +273,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
 
 template <typename T, int MODE, int BM, int BN, int WM, int WN, int KT>
 int launch_conv(const ConvArgs& a0, hipStream_t st) {
+  if (a0.epi.oscale || a0.epi.act) return MDCV_EARG;          // the register-staged kernels carry no inference epilogue
+
   ConvArgs a = a0;
   constexpr int RB = 64 * KT + 16;
   constexpr int PIPE = 2 * (BM + BN) * RB;
@@ -376,7 +363,7 @@ template <> struct FragSwz<float> {
 typedef __attribute__((address_space(3))) void lds_void_t;
 int g_conv_no_ut = 0;    // tuning/A-B: 1 disables the uniform-tap address path
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE, bool EPI = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, unsigned in_bytes, unsigned w_bytes) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int VEC = ET<T>::VEC;
@@ -589,7 +576,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
 
   // ---------------- epilogue (same as the register-staged kernel) ----------------
   const int n0 = tile_n * BN + wn * TN, m0 = tile_m * BM + wm * TM;
-  if (a.epi.oscale || a.epi.act) {                         // inference: act(acc * scale + shift), once per tile, block-uniform branch
+  if constexpr (EPI) {                                     // inference instantiation (MODE 0): act(acc * scale + shift), once per tile (template
+    // parameter: as a runtime branch it cost the training step 2 %)
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = n0 + j * 16 + (lane & 15);
@@ -738,14 +726,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
   }
 }
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE, bool EPI = false>
 int launch_conv_glds_f(const ConvArgs& a0, hipStream_t st, int B) {
   ConvArgs a = a0;
   constexpr int PIPE = STAGES * (BM + BN) * 64;
   constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
   constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;   // + statistics / fused-sum scratch (NW*BN floats <= WM*2*BN)
   static bool attr_set = false;
-  auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN, STAGES, UT, FUSE>;
+  auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN, STAGES, UT, FUSE, EPI>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
@@ -766,6 +754,10 @@ int launch_conv_glds_ut(const ConvArgs& a, hipStream_t st, int B) {
   if constexpr (MODE != 0) {                    // the fused BatchNorm-backward sums exist for data gradients only
     if (a.fuse.y) return launch_conv_glds_f<T, MODE, BM, BN, WM, WN, STAGES, UT, true>(a, st, B);
   }
+  if constexpr (MODE == 0) {                    // inference epilogue (forward only)
+    if (a.epi.oscale || a.epi.act) return launch_conv_glds_f<T, MODE, BM, BN, WM, WN, STAGES, UT, false, true>(a, st, B);
+  }
+  if (a.epi.oscale || a.epi.act) return MDCV_EARG;
   return launch_conv_glds_f<T, MODE, BM, BN, WM, WN, STAGES, UT, false>(a, st, B);
 }
 

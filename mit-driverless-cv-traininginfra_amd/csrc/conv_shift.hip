@@ -54,7 +54,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 }  // namespace
 
-template <int MODE, int BM, int NPA, int BRING, bool FUSE, int WN>
+template <int MODE, int BM, int NPA, int BRING, bool FUSE, int WN, bool EPI = false>
 __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a, unsigned in_bytes, unsigned w_bytes) {
   constexpr int NW = WM * WN, TN = BN / WN, FN = TN / 16;
   constexpr int TM = BM / WM, FM = TM / 16;
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
     rowpix[tid] = ok ? (img * a.H + y) * a.W + x : -1;
   }
   const int n0 = tile_n * BN + wn * TN;
-  if (a.epi.oscale || a.epi.act) {                         // inference: act(acc * scale + shift), once per tile, block-uniform branch
+  if constexpr (EPI) {                                     // inference instantiation (MODE 0): act(acc * scale + shift), once per tile.  A
+    // template parameter, not a runtime branch: even this block-uniform test outside the store loops cost the training step 2 %
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int n = n0 + j * 16 + (lane & 15);
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 
 namespace {
 
-template <int MODE, int BM, int NPA, bool FUSE, int WN>
+template <int MODE, int BM, int NPA, bool FUSE, int WN, bool EPI = false>
 int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   constexpr int BRING = 3, NW = WM * WN;
   a.p_base = p_base;
@@ -393,7 +394,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics / fused-sum scratch (NW*BN floats)
   const int lds = pipe > epi ? pipe : epi;
   static int attr_lds = 0;
-  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE, WN>;
+  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE, WN, EPI>;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
@@ -409,6 +410,10 @@ int launch_shift(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, un
   if constexpr (MODE == 1 && WN == 2 && BM % 128 == 0) {   // the fused BatchNorm-backward sums exist for 8-wave data gradients only
     if (a.fuse.y) return launch_shift_f<MODE, BM, NPA, true, WN>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
+  if constexpr (MODE == 0 && WN == 2) {                    // inference epilogue: forward, 8-wave tiles
+    if (a.epi.oscale || a.epi.act) return launch_shift_f<MODE, BM, NPA, false, WN, true>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  }
+  if (a.epi.oscale || a.epi.act) return MDCV_EARG;          // no inference instantiation for this mode / wave layout
   return launch_shift_f<MODE, BM, NPA, false, WN>(a, p_base, tiles_m, st, in_bytes, w_bytes);
 }
 
