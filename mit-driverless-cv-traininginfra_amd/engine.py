@@ -389,6 +389,35 @@ class Plan:
     # now that the weight gradients fill the MFMA pipe from the side stream and the main stream is what bounds the step.
     fuse_bn = os.environ.get("MDCV_BN_FUSE", "1") == "1"
 
+    fuse_skip = int(os.environ.get("MDCV_BN_FUSE_SKIP", "13"))
+
+    def _fuse_pays(self, geom):
+        """Per-geometry choice between the fused sums and the stand-alone reduce pass (MDCV_BN_FUSE_SKIP = bit mask of the classes
+        that keep the stand-alone pass; 0: fuse every eligible data gradient).  The fused store loop runs at the END of every tile;
+        when the launch is a single round of workgroups over a large dx tensor nothing hides it and the stand-alone pass (full HBM
+        rate) wins.  Classes by pixels of dx (yolo_baseline 416^2 at batch 32 in brackets), chosen by same-box A/B of the whole
+        step (`scripts/ab_fuse_policy.sh`), not by the isolated per-launch times, which rank them differently."""
+        B, dyH, dyW, cdy, xH, xW, cdx, kh, kw, stride, pad, dil = geom
+        px = B * xH * xW
+        k = self.fuse_skip
+        if kh == 3 and stride == 1:
+            if 50000 <= px < 100000:       # [52^2 3x3, 11 layers]
+                return not (k & 1)
+            if 20000 <= px < 50000:        # [26^2 3x3, 11 layers]
+                return not (k & 2)
+            if px >= 300000:               # [104^2 3x3, 2 layers]
+                return not (k & 32)
+        if kh == 1:
+            if px >= 300000:               # [104^2 1x1, 2 layers]
+                return not (k & 4)
+            if 50000 <= px < 100000:       # [52^2 1x1, 10 layers]
+                return not (k & 16)
+            if 20000 <= px < 50000:        # [26^2 1x1, 11 layers]
+                return not (k & 64)
+        if stride == 2 and 300000 <= px < 1000000:   # [52^2 -> 104^2]
+            return not (k & 8)
+        return True
+
     def _fuse_bn_sums(self, dout, y, bs, act, slope, dgamma, dbeta):
         """Fold the BatchNorm-backward reduction over (dout, y) into the store loop of the data gradient that wrote `dout`.
 
@@ -408,6 +437,8 @@ class Plan:
             if dout.ptr in args:
                 return False
         L, dt = self.L, self.dtype
+        if not self._fuse_pays(e["geom"]):
+            return False
         rows = int(L.conv2d_dgrad_bnsums_rows(dt, *e["geom"], e["head"][1]))
         if rows <= 0 or rows > 4096:
             return False
