@@ -47,8 +47,8 @@ __device__ long long g_shift_ts[4 * 512];
 #define STS(k)
 #endif
 
-int g_shift_ring = 3;
-int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row only ; 3: mixed rounds ; 4: 16 waves ; 5: 192-row tiles where they save a round (= default) ; 6: never 192-row   // weight-ring depth (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
+int g_shift_ring = 4;   // weight-ring depth of sparse grids (<= 256 tiles); 3: off, 6: six slots, 5: four slots on every grid (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
+int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row only ; 3: mixed rounds ; 4: 16 waves ; 5: 192-row tiles where they save a round (= default) ; 6: never 192-row
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   for (int t = 0; t < LA; ++t) ISSUE_B(rw, t % 9, t / 9, t);
   // The chunk loop is unrolled over PERIOD chunks so that every ring slot, A buffer and wait count below is a compile-time
   // constant of (cc, tap): 9 * PERIOD is a multiple of BRING, and PERIOD is even or the A buffer index is taken from c.
-  constexpr int PERIOD = BRING == 3 ? 2 : 4;
+  constexpr int PERIOD = BRING == 4 ? 4 : 2;              // 3- and 6-slot rings: 18 steps ; 4 slots: 36
   static_assert((9 * PERIOD) % BRING == 0, "ring period");
   for (int c0 = 0; c0 < nch; c0 += PERIOD) {
 #pragma unroll
@@ -383,9 +383,18 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 
 namespace {
 
-template <int MODE, int BM, int NPA, bool FUSE, int WN, bool EPI = false>
+template <int MODE, int BM, int NPA, bool FUSE, int WN, bool EPI = false, int BRING = 3>
 int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
-  constexpr int BRING = 3, NW = WM * WN;
+  constexpr int NW = WM * WN;
+  // A grid that puts one workgroup on a CU has only the ring's lookahead in flight on that CU's L2 -> LDS path (latency-bound fill):
+  // such launches (batch 32: the 13x13 and 26x26 data gradients) take a 4-slot weight ring.  Same-box A/B of the YOLOv3 step:
+  // +0.45 .. 0.6 % (6 slots +0.35 %; 4 slots on EVERY grid -2.8 %: the 36-step unrolled period and the third workgroup's worth of LDS).
+  if constexpr (BRING == 3 && WN == 2 && !EPI) {
+    if (g_shift_ring == 6 && tiles_m * a.tiles_n <= 256)
+      return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 6>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+    if ((g_shift_ring == 4 && tiles_m * a.tiles_n <= 256) || g_shift_ring == 5)
+      return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 4>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  }
   a.p_base = p_base;
   a.tiles_total = tiles_m * a.tiles_n;
   a.xcd_chunk = (a.tiles_total + 7) / 8;
