@@ -658,15 +658,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
     const T* __restrict__ fy = reinterpret_cast<const T*>(a.fuse.y);
     float* fred = sstat;
     constexpr int PPG = 128 / Acc::RPP;                    // passes per 128-pixel group
-#pragma unroll 1
-    for (int g0 = 0; g0 < BM; g0 += 128) {
-      long long pixv[PPG]; uint4 dq[PPG], aq[PPG], yq[PPG];
+    // The global loads (addsrc, y) of ALL groups of the tile are issued before the first group is processed (like the shift kernel):
+    // they are HBM misses, the accumulators are dead by now, and one batch per group exposed their latency once per group.
+    constexpr int NG = BM / 128 > 0 ? BM / 128 : 1;
+    long long pixv[NG][PPG]; uint4 aq[NG][PPG], yq[NG][PPG];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
       for (int u = 0; u < PPG; ++u) {
-        const int row = g0 + u * Acc::RPP + tid / VPRO;
+        const int row = gi * 128 + u * Acc::RPP + tid / VPRO;
         const int m = tile_m * BM + row;
-        pixv[u] = -1;
-        dq[u] = *reinterpret_cast<const uint4*>(smem + row * SROW + cv * 16);
+        pixv[gi][u] = -1;
         if (m < a.M && n < a.Nout) {
           long long pix = m;
           if (MODE == 2) {
@@ -674,27 +676,33 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
             const int ha = rem / Wrow, wb = rem - ha * Wrow;
             pix = ((long long)img * a.Hout + (a.ph + 2 * ha)) * a.Wout + (a.pw + 2 * wb);
           }
-          pixv[u] = pix;
-          if (addsrc) aq[u] = *reinterpret_cast<const uint4*>(addsrc + (pix * a.add_ldc + n));
-          yq[u] = *reinterpret_cast<const uint4*>(fy + (pix * a.fuse.ldy + n));
+          pixv[gi][u] = pix;
+          if (addsrc) aq[gi][u] = *reinterpret_cast<const uint4*>(addsrc + (pix * a.add_ldc + n));
+          yq[gi][u] = *reinterpret_cast<const uint4*>(fy + (pix * a.fuse.ldy + n));
         }
       }
 #pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int g0 = gi * 128;
+      uint4 dq[PPG];
+#pragma unroll
+      for (int u = 0; u < PPG; ++u) dq[u] = *reinterpret_cast<const uint4*>(smem + (g0 + u * Acc::RPP + tid / VPRO) * SROW + cv * 16);
+#pragma unroll
       for (int u = 0; u < PPG; ++u) {
-        if (pixv[u] >= 0) {
+        if (pixv[gi][u] >= 0) {
           float x[VEC];
           uint4 d = dq[u];
           ET<T>::unpack(d, x);
           if (addsrc) {
             float y[VEC];
-            ET<T>::unpack(aq[u], y);
+            ET<T>::unpack(aq[gi][u], y);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) x[e] += y[e];
             d = ET<T>::pack(x);
             ET<T>::unpack(d, x);
           }
-          *reinterpret_cast<uint4*>(out + (pixv[u] * a.out_ldc + n)) = d;
-          fz.add(a.fuse, x, yq[u]);
+          *reinterpret_cast<uint4*>(out + (pixv[gi][u] * a.out_ldc + n)) = d;
+          fz.add(a.fuse, x, yq[gi][u]);
         }
       }
       if (tile_m * BM + g0 < a.M)                      // block-uniform: a 256-row tile's second group may start past the last pixel,
