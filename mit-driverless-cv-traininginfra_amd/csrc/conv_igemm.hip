@@ -778,6 +778,8 @@ int launch_conv_glds(const ConvArgs& a, hipStream_t st, int B) {
   return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, false>(a, st, B);
 }
 
+int g_conv_deep_small = 8;   // 128x128 and 128x64 tiles take the 3-stage DMA ring from this many K steps (set_variant 60 + nk_min; 60 = never).
+                             // Same-box A/B of the YOLOv3 step: never 2031, from 4 steps 2045, from 8 2050, from 16 2045, from 32 2034 img/s
 int g_conv_fuse_small = 0;   // tuning (set_variant 95 / 94): fused-sum data gradients with a short K loop take 128x128 two-stage tiles (4 workgroups per CU)
 int g_conv_midgrid = 0;    // tuning (set_variant 97 / 96): 256x128 tiles already from 300 tiles of 128x128 (1x1 layers at 52x52)
 int g_conv_variant = -1;   // -1: heuristic ; >= 0: forced tile configuration for wide layers (tuning / A-B benchmarking)
@@ -795,6 +797,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
       const int nk = a.Ktot / (4 * ET<T>::VEC);      // long K loops profit from the 3-stage DMA ring (scripts/bench_conv.py)
       v = t128 >= (g_conv_midgrid ? 300 : 1024) ? 11 : (nk >= 100 ? 9 : (t128 >= 300 ? 6 : 7));
       if (g_conv_fuse_small && MODE != 0 && a.fuse.y && nk <= 8 && v == 11) v = 6;
+      if (g_conv_deep_small && nk >= g_conv_deep_small && (v == 6 || v == 7)) v += 3;   // 3-stage ring for the mid / sparse grids too
     }
     if (v >= 6 && !small) v = (v == 8 || v == 11 || v == 13) ? 2 : ((v == 7 || v == 10) ? 4 : 0);
     if (v == 6) return launch_conv_glds<T, MODE, 128, 128, 2, 2>(a, st, B);
@@ -1795,6 +1798,7 @@ int mdcv_conv2d_set_variant(int v) {
   if (v <= -3 && v >= -13) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11 16-wave workgroups, -12 192-row tiles where they save a round
   if (v == 97 || v == 96) { g_conv_midgrid = v == 97; return MDCV_OK; }
   if (v == 95 || v == 94) { g_conv_fuse_small = v == 95; return MDCV_OK; }
+  if (v >= 60 && v < 93) { g_conv_deep_small = v - 60; return MDCV_OK; }
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
   g_conv_variant = v == 99 ? -1 : v;
   return MDCV_OK;
