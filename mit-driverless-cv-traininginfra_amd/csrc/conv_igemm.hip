@@ -778,6 +778,8 @@ int launch_conv_glds(const ConvArgs& a, hipStream_t st, int B) {
   return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, false>(a, st, B);
 }
 
+int g_conv_deep_narrow = 1;  // 128x64 tiles of the 33..64-channel layers take the 3-stage ring from this many K steps (set_variant 30 + nk_min;
+                             // 30 = never).  Same-box A/B: RektNet 29.93k -> 30.17k img/s, YOLOv3 +0.3 %
 int g_conv_deep_small = 8;   // 128x128 and 128x64 tiles take the 3-stage DMA ring from this many K steps (set_variant 60 + nk_min; 60 = never).
                              // Same-box A/B of the YOLOv3 step: never 2031, from 4 steps 2045, from 8 2050, from 16 2045, from 32 2034 img/s
 int g_conv_fuse_small = 0;   // tuning (set_variant 95 / 94): fused-sum data gradients with a short K loop take 128x128 two-stage tiles (4 workgroups per CU)
@@ -820,6 +822,8 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
     return launch_conv<T, MODE, 128, 128, 2, 2, 1>(a, st);
   }
   const bool dma = small && g_conv_variant != 0;      // variant 0 forces the register-staged kernels everywhere (A/B)
+  if (dma && a.Nout > 32 && g_conv_deep_narrow && a.Ktot / (4 * ET<T>::VEC) >= g_conv_deep_narrow)   // (the 32- and 16-wide tiles have
+    return launch_conv_glds<T, MODE, 128, 64, 2, 2, 3>(a, st, B);                                    //  fewer weight chunks than waves)
   if (a.Nout > 32) return dma ? launch_conv_glds<T, MODE, 128, 64, 2, 2>(a, st, B) : launch_conv<T, MODE, 128, 64, 2, 2, (BF ? 2 : 1)>(a, st);
   if (a.Nout > 16) return dma ? launch_conv_glds<T, MODE, 128, 32, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 32, 4, 1, (BF ? 2 : 1)>(a, st);
   return dma ? launch_conv_glds<T, MODE, 128, 16, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 16, 4, 1, (BF ? 2 : 1)>(a, st);
@@ -1799,6 +1803,7 @@ int mdcv_conv2d_set_variant(int v) {
   if (v == 97 || v == 96) { g_conv_midgrid = v == 97; return MDCV_OK; }
   if (v == 95 || v == 94) { g_conv_fuse_small = v == 95; return MDCV_OK; }
   if (v >= 60 && v < 93) { g_conv_deep_small = v - 60; return MDCV_OK; }
+  if (v >= 30 && v < 60) { g_conv_deep_narrow = v - 30; return MDCV_OK; }
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
   g_conv_variant = v == 99 ? -1 : v;
   return MDCV_OK;

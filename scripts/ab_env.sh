@@ -7,6 +7,6 @@ for rep in 1 2 3; do
     ee=$e; [ "$e" = "-" ] && ee=""
     env $ee python bench.py --workload $wl --no-cpu-baseline --no-breakdown --steps 40 --warmup 10 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$e] rep $rep', round(d['value'], 1))" | tee -a gpurun_out/ab/ab.txt
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$e] rep $rep', ' '.join('%s %.1f' % (k, v['images_per_sec']) for k, v in d['workloads'].items()))" | tee -a gpurun_out/ab/ab.txt
   done
 done
