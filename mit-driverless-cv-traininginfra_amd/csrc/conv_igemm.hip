@@ -371,9 +371,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int CA = BM / 16, CB = BN / 16;               // 1 KiB chunks per operand tile
   constexpr int NPA = (CA + NW - 1) / NW, NPB = (CB + NW - 1) / NW;
-  constexpr int PIPE = STAGES * (BM + BN) * 64;
+  // The deep ring waits with counted vmcnt, so every wave must issue the same number of DMAs per K tile: when an operand tile has
+  // fewer 1 KiB chunks than there are waves (32- and 16-channel weight tiles), the surplus waves fill a 1 KiB sink with zeros.
+  constexpr bool UNEVEN = STAGES > 2 && (CA % NW != 0 || CB % NW != 0);
+  constexpr int SINK = STAGES * (BM + BN) * 64;
+  constexpr int PIPE = SINK + (UNEVEN ? 1024 : 0);
   constexpr int GD = NPA + NPB;                           // LDS-DMA instructions every wave issues per K tile (deep pipeline: exact)
-  static_assert(STAGES == 2 || (CA % NW == 0 && CB % NW == 0), "counted vmcnt needs the same DMA count in every wave");
   constexpr int SROW = BN * (int)sizeof(T) + 16;
   constexpr int STAGE = BM * SROW;
   constexpr int STAT_OFF = PIPE > STAGE ? PIPE : STAGE;
@@ -454,6 +457,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
         const bool ok = rv[p] & kvalid & ((unsigned)hi < (unsigned)a.Hin) & ((unsigned)wi < (unsigned)a.Win);
         const unsigned off = ok ? (unsigned)(rowoff[p] + tapoff) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_t*)(sA + chunk * 1024), 16, off, 0, 0, 0);
+      } else if (UNEVEN) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_t*)(smem + SINK), 16, OOB, 0, 0, 0);
       }
     }
     const int kw_full = MODE == 2 ? ((a.kh0 + 2 * s_kh) * a.KW + a.kw0 + 2 * s_kw) * a.Cin + s_c0 : kt * BK;
@@ -464,6 +469,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
       if (CB % NW == 0 || chunk < CB) {
         const unsigned off = (nv[p] & kvalid) ? (unsigned)(nboff[p] + koff) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(sB + chunk * 1024), 16, off, 0, 0, 0);
+      } else if (UNEVEN) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(smem + SINK), 16, OOB, 0, 0, 0);
       }
     }
   };
@@ -490,6 +497,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
         ok = ok & ((unsigned)hi < (unsigned)a.Hin) & ((unsigned)wi < (unsigned)a.Win);
         const unsigned off = ok ? (unsigned)(((ib[p] + hi * a.Win + wi) * a.in_ldc + kc) * (int)sizeof(T)) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_t*)(sA + chunk * 1024), 16, off, 0, 0, 0);
+      } else if (UNEVEN) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_t*)(smem + SINK), 16, OOB, 0, 0, 0);
       }
     }
     // weight row = [KH][KW][Cin] of the FULL kernel; MODE 2 visits the sub-lattice of taps
@@ -502,6 +511,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
         const int n = tile_n * BN + chunk * 16 + lrow;
         const unsigned off = ((n < a.Nout) & kvalid & (k < wrow)) ? (unsigned)((n * wrow + k) * (int)sizeof(T)) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(sB + chunk * 1024), 16, off, 0, 0, 0);
+      } else if (UNEVEN) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(smem + SINK), 16, OOB, 0, 0, 0);
       }
     }
   };
@@ -737,7 +748,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
 template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE, bool EPI = false>
 int launch_conv_glds_f(const ConvArgs& a0, hipStream_t st, int B) {
   ConvArgs a = a0;
-  constexpr int PIPE = STAGES * (BM + BN) * 64;
+  constexpr int NWV = WM * WN;
+  constexpr int PIPE = STAGES * (BM + BN) * 64 + ((STAGES > 2 && ((BM / 16) % NWV != 0 || (BN / 16) % NWV != 0)) ? 1024 : 0);   // + the DMA sink
   constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
   constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;   // + statistics / fused-sum scratch (NW*BN floats <= WM*2*BN)
   static bool attr_set = false;
@@ -778,6 +790,7 @@ int launch_conv_glds(const ConvArgs& a, hipStream_t st, int B) {
   return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, false>(a, st, B);
 }
 
+int g_conv_deep_narrow32 = 0; // tuning (set_variant 22 / 23): also the 128x32 and 128x16 tiles (surplus waves DMA zeros into a sink)
 int g_conv_deep_narrow = 1;  // 128x64 tiles of the 33..64-channel layers take the 3-stage ring from this many K steps (set_variant 30 + nk_min;
                              // 30 = never).  Same-box A/B: RektNet 29.93k -> 30.17k img/s, YOLOv3 +0.3 %
 int g_conv_deep_small = 8;   // 128x128 and 128x64 tiles take the 3-stage DMA ring from this many K steps (set_variant 60 + nk_min; 60 = never).
@@ -822,15 +835,30 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
     return launch_conv<T, MODE, 128, 128, 2, 2, 1>(a, st);
   }
   const bool dma = small && g_conv_variant != 0;      // variant 0 forces the register-staged kernels everywhere (A/B)
-  if (dma && a.Nout > 32 && g_conv_deep_narrow && a.Ktot / (4 * ET<T>::VEC) >= g_conv_deep_narrow)   // (the 32- and 16-wide tiles have
-    return launch_conv_glds<T, MODE, 128, 64, 2, 2, 3>(a, st, B);                                    //  fewer weight chunks than waves)
+  if (dma && g_conv_deep_narrow && a.Ktot / (4 * ET<T>::VEC) >= g_conv_deep_narrow) {
+    if (a.Nout > 32) return launch_conv_glds<T, MODE, 128, 64, 2, 2, 3>(a, st, B);
+    if (g_conv_deep_narrow32) {
+      if (a.Nout > 16) return launch_conv_glds<T, MODE, 128, 32, 4, 1, 3>(a, st, B);
+      return launch_conv_glds<T, MODE, 128, 16, 4, 1, 3>(a, st, B);
+    }
+  }
   if (a.Nout > 32) return dma ? launch_conv_glds<T, MODE, 128, 64, 2, 2>(a, st, B) : launch_conv<T, MODE, 128, 64, 2, 2, (BF ? 2 : 1)>(a, st);
   if (a.Nout > 16) return dma ? launch_conv_glds<T, MODE, 128, 32, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 32, 4, 1, (BF ? 2 : 1)>(a, st);
   return dma ? launch_conv_glds<T, MODE, 128, 16, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 16, 4, 1, (BF ? 2 : 1)>(a, st);
 }
 
+int g_conv_deep_s2 = 1;      // (set_variant 20 = off; +0.6 % on the YOLOv3 step, same-box A/B) 3-stage ring for the parity-class launches of the stride-2 data gradients
+
 template <typename T>
 int dispatch_dgrad_s2(const ConvArgs& a, hipStream_t st, int B) {
+  if (g_conv_deep_s2 && a.Nout > 32) {
+    const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
+    if (a.Nout > 64) {
+      if (sizeof(T) == 2 && t128 >= 1024) return launch_conv_glds<T, 2, (sizeof(T) == 2 ? 256 : 128), 128, (sizeof(T) == 2 ? 4 : 2), 2, 3>(a, st, B);
+      if (t128 >= 300) return launch_conv_glds<T, 2, 128, 128, 2, 2, 3>(a, st, B);
+    }
+    return launch_conv_glds<T, 2, 128, 64, 2, 2, 3>(a, st, B);
+  }
   if (a.Nout > 64) {
     const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
     if (sizeof(T) == 2 && t128 >= 1024) return launch_conv_glds<T, 2, (sizeof(T) == 2 ? 256 : 128), 128, (sizeof(T) == 2 ? 4 : 2), 2>(a, st, B);
@@ -1804,6 +1832,8 @@ int mdcv_conv2d_set_variant(int v) {
   if (v == 95 || v == 94) { g_conv_fuse_small = v == 95; return MDCV_OK; }
   if (v >= 60 && v < 93) { g_conv_deep_small = v - 60; return MDCV_OK; }
   if (v >= 30 && v < 60) { g_conv_deep_narrow = v - 30; return MDCV_OK; }
+  if (v == 20 || v == 21) { g_conv_deep_s2 = v - 20; return MDCV_OK; }
+  if (v == 22 || v == 23) { g_conv_deep_narrow32 = v - 22; return MDCV_OK; }
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
   g_conv_variant = v == 99 ? -1 : v;
   return MDCV_OK;
