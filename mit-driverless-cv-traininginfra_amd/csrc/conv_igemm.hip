@@ -790,6 +790,9 @@ int launch_conv_glds(const ConvArgs& a, hipStream_t st, int B) {
   return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, false>(a, st, B);
 }
 
+int g_conv_tall_mask = 7;     // (set_variant 24 + mask) 1: Nout <= 16, 2: <= 32, 4: <= 64
+int g_conv_tall_narrow = 256; // 256-row tiles for Nout <= 64 from this many Ki output positions (set_variant 2000 + M_min/1024; 2000 = off): half as
+                              // many workgroup prologues / epilogues on the 80^2 x 256 and 208^2..416^2 x 32 tensors.  Same-box A/B: RektNet +0.65 %, YOLOv3 +0.2 %
 int g_conv_deep_narrow32 = 0; // tuning (set_variant 22 / 23): also the 128x32 and 128x16 tiles (surplus waves DMA zeros into a sink)
 int g_conv_deep_narrow = 1;  // 128x64 tiles of the 33..64-channel layers take the 3-stage ring from this many K steps (set_variant 30 + nk_min;
                              // 30 = never).  Same-box A/B: RektNet 29.93k -> 30.17k img/s, YOLOv3 +0.3 %
@@ -835,6 +838,13 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
     return launch_conv<T, MODE, 128, 128, 2, 2, 1>(a, st);
   }
   const bool dma = small && g_conv_variant != 0;      // variant 0 forces the register-staged kernels everywhere (A/B)
+  if constexpr (BF) {
+    if (dma && g_conv_tall_narrow && a.M >= g_conv_tall_narrow * 1024) {   // tall tiles for the narrow layers of large images
+      if (a.Nout > 32) { if (g_conv_tall_mask & 4) return launch_conv_glds<T, MODE, 256, 64, 4, 2, 3>(a, st, B); }
+      else if (a.Nout > 16) { if (g_conv_tall_mask & 2) return launch_conv_glds<T, MODE, 256, 32, 4, 1>(a, st, B); }
+      else if (g_conv_tall_mask & 1) return launch_conv_glds<T, MODE, 256, 16, 4, 1>(a, st, B);
+    }
+  }
   if (dma && g_conv_deep_narrow && a.Ktot / (4 * ET<T>::VEC) >= g_conv_deep_narrow) {
     if (a.Nout > 32) return launch_conv_glds<T, MODE, 128, 64, 2, 2, 3>(a, st, B);
     if (g_conv_deep_narrow32) {
@@ -1834,6 +1844,8 @@ int mdcv_conv2d_set_variant(int v) {
   if (v >= 30 && v < 60) { g_conv_deep_narrow = v - 30; return MDCV_OK; }
   if (v == 20 || v == 21) { g_conv_deep_s2 = v - 20; return MDCV_OK; }
   if (v == 22 || v == 23) { g_conv_deep_narrow32 = v - 22; return MDCV_OK; }
+  if (v >= 2000) { g_conv_tall_narrow = v - 2000; return MDCV_OK; }
+  if (v >= 24 && v < 30) { g_conv_tall_mask = v - 24; return MDCV_OK; }
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
   g_conv_variant = v == 99 ? -1 : v;
   return MDCV_OK;
