@@ -813,7 +813,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
     if (v < 0) {   // measured on MI355X (scripts/bench_conv.py): tall tiles once the grid is >= 4 waves of CUs, half-width tiles
       const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);   // when 128x128 would leave CUs idle
       const int nk = a.Ktot / (4 * ET<T>::VEC);      // long K loops profit from the 3-stage DMA ring (scripts/bench_conv.py)
-      v = t128 >= (g_conv_midgrid ? 300 : 1024) ? 11 : (nk >= 100 ? 9 : (t128 >= 300 ? 6 : 7));
+      v = t128 >= (g_conv_midgrid ? g_conv_midgrid : 1024) ? 11 : (nk >= 100 ? 9 : (t128 >= 300 ? 6 : 7));
       if (g_conv_fuse_small && MODE != 0 && a.fuse.y && nk <= 8 && v == 11) v = 6;
       if (g_conv_deep_small && nk >= g_conv_deep_small && (v == 6 || v == 7)) v += 3;   // 3-stage ring for the mid / sparse grids too
     }
@@ -857,10 +857,18 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
   return dma ? launch_conv_glds<T, MODE, 128, 16, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 16, 4, 1, (BF ? 2 : 1)>(a, st);
 }
 
+int g_conv_tall_s2 = 1;      // (set_variant 18 = off; +0.3 % on the YOLOv3 step) the tall narrow tiles for the parity-class launches too
 int g_conv_deep_s2 = 1;      // (set_variant 20 = off; +0.6 % on the YOLOv3 step, same-box A/B) 3-stage ring for the parity-class launches of the stride-2 data gradients
 
 template <typename T>
 int dispatch_dgrad_s2(const ConvArgs& a, hipStream_t st, int B) {
+  if constexpr (sizeof(T) == 2) {
+    if (g_conv_tall_s2 && g_conv_tall_narrow && a.Nout <= 64 && a.M >= g_conv_tall_narrow * 1024) {
+      if (a.Nout > 32) return launch_conv_glds<T, 2, 256, 64, 4, 2, 3>(a, st, B);
+      if (a.Nout > 16) return launch_conv_glds<T, 2, 256, 32, 4, 1>(a, st, B);
+      return launch_conv_glds<T, 2, 256, 16, 4, 1>(a, st, B);
+    }
+  }
   if (g_conv_deep_s2 && a.Nout > 32) {
     const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
     if (a.Nout > 64) {
@@ -1838,13 +1846,15 @@ int mdcv_conv2d_wgrad_set_variant(int v) {   /* tuning hook; 1000 + 100*d + bloc
 }
 int mdcv_conv2d_set_variant(int v) {
   if (v <= -3 && v >= -13) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11 16-wave workgroups, -12 192-row tiles where they save a round
-  if (v == 97 || v == 96) { g_conv_midgrid = v == 97; return MDCV_OK; }
+  if (v == 97 || v == 96) { g_conv_midgrid = v == 97 ? 300 : 0; return MDCV_OK; }
+  if (v >= 3000 && v < 9000) { g_conv_midgrid = v - 3000; return MDCV_OK; }   // 3000 + first t128 that takes 256x128 tiles
   if (v == 95 || v == 94) { g_conv_fuse_small = v == 95; return MDCV_OK; }
   if (v >= 60 && v < 93) { g_conv_deep_small = v - 60; return MDCV_OK; }
   if (v >= 30 && v < 60) { g_conv_deep_narrow = v - 30; return MDCV_OK; }
   if (v == 20 || v == 21) { g_conv_deep_s2 = v - 20; return MDCV_OK; }
+  if (v == 18 || v == 19) { g_conv_tall_s2 = v - 18; return MDCV_OK; }
   if (v == 22 || v == 23) { g_conv_deep_narrow32 = v - 22; return MDCV_OK; }
-  if (v >= 2000) { g_conv_tall_narrow = v - 2000; return MDCV_OK; }
+  if (v >= 2000 && v < 3000) { g_conv_tall_narrow = v - 2000; return MDCV_OK; }
   if (v >= 24 && v < 30) { g_conv_tall_mask = v - 24; return MDCV_OK; }
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
   g_conv_variant = v == 99 ? -1 : v;
