@@ -390,6 +390,7 @@ class Plan:
     fuse_bn = os.environ.get("MDCV_BN_FUSE", "1") == "1"
 
     fuse_skip = int(os.environ.get("MDCV_BN_FUSE_SKIP", "13"))
+    fuse_max_rows = int(os.environ.get("MDCV_BN_FUSE_MAXROWS", "4096"))   # partial rows the column-owner finalize is asked to sum
 
     def _fuse_pays(self, geom):
         """Per-geometry choice between the fused sums and the stand-alone reduce pass (MDCV_BN_FUSE_SKIP = bit mask of the classes
@@ -440,7 +441,7 @@ class Plan:
         if not self._fuse_pays(e["geom"]):
             return False
         rows = int(L.conv2d_dgrad_bnsums_rows(dt, *e["geom"], e["head"][1]))
-        if rows <= 0 or rows > 4096:
+        if rows <= 0 or rows > self.fuse_max_rows:
             return False
         fn0, _ = self.bwd[e["idx"]]
         assert fn0 is L.conv2d
