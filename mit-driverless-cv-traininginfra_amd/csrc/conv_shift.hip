@@ -48,6 +48,9 @@ __device__ long long g_shift_ts[4 * 512];
 #endif
 
 int g_shift_ring = 4;   // weight-ring depth of sparse grids (<= 256 tiles); 3: off, 6: six slots, 5: four slots on every grid (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
+int g_shift_wmax = 80;  // widest image row the shift kernel takes (set_variant(-15) -> 62, (-14) -> 80).  Up to 62 the chunk is 384 rows (3 DMAs per
+                        // wave); 63..80 take a fourth and still fit two workgroups on a CU: RektNet's 128->128 layers at 80x80 +3.1 % on its step,
+                        // the 76x76 layers of the 608^2 detector +1 % on the joint pipeline (same-box A/B)
 int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row only ; 3: mixed rounds ; 4: 16 waves ; 5: 192-row tiles where they save a round (= default) ; 6: never 192-row
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -491,7 +494,7 @@ int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, uns
 bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc) {
   if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || dil != 1) return false;
   if ((Cin & 31) || Cin < 32 || (Nout & 127)) return false;
-  if (H < 8 || W < 8 || W > 62) return false;                  // chunk rows 256 + 2(W+1) + 2 <= 384: 2 workgroups per CU
+  if (H < 8 || W < 8 || W > g_shift_wmax) return false;        // 62: chunk rows 256 + 2(W+1) + 2 <= 384; up to 86 two workgroups still fit a CU
   if ((long long)B * (H + 1) * (W + 1) + 1024 >= (1LL << 30)) return false;
   if ((long long)B * H * W * in_ldc * 2 >= (1LL << 31) || (long long)Nout * 9 * Cin * 2 >= (1LL << 31)) return false;
   return true;
@@ -523,7 +526,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   return mode == 0 ? launch_shift_mode<0>(a, st, in_bytes, w_bytes) : launch_shift_mode<1>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);
