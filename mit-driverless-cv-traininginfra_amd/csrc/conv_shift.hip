@@ -48,6 +48,8 @@ __device__ long long g_shift_ts[4 * 512];
 #endif
 
 int g_shift_ring = 4;   // weight-ring depth of sparse grids (<= 256 tiles); 3: off, 6: six slots, 5: four slots on every grid (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
+int g_shift_n64 = 1;    // 64-channel layers run a 64-wide tile column (set_variant(-18) off / (-17) on): RektNet's 64->64 layers 210 -> 168 us forward,
+                        // 211 -> 153 us data gradient; +0.5 % on its step (same-box A/B)
 int g_shift_wmax = 80;  // widest image row the shift kernel takes (set_variant(-15) -> 62, (-14) -> 80).  Up to 62 the chunk is 384 rows (3 DMAs per
                         // wave); 63..80 take a fourth and still fit two workgroups on a CU: RektNet's 128->128 layers at 80x80 +3.1 % on its step,
                         // the 76x76 layers of the 608^2 detector +1 % on the joint pipeline (same-box A/B)
@@ -57,8 +59,10 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 }  // namespace
 
-template <int MODE, int BM, int NPA, int BRING, bool FUSE, int WN, bool EPI = false>
+template <int MODE, int BM, int NPA, int BRING, bool FUSE, int WN, bool EPI = false, int BN_ = 128>
 __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a, unsigned in_bytes, unsigned w_bytes) {
+  // output channels per tile: 128, or 64 for 64-channel layers (wave tile (BM/4) x 32; waves 4..7 send their weight DMA to the sink)
+  constexpr int BN = BN_, BTILE = BN * 64, SROW = BN * 2 + 16;
   constexpr int NW = WM * WN, TN = BN / WN, FN = TN / 16;
   constexpr int TM = BM / WM, FM = TM / 16;
   static_assert(!FUSE || (WN == 2 && BM % 128 == 0), "the fused sums: 8 waves, one partial row per 128 positions");
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   unsigned bvo;                                            // the weight tile is 8 KiB-chunks: waves 8..15 (16-wave variant) fill the sink
   {
     const int n = tile_n * BN + wave * 16 + lrow;
-    bvo = (wave < 8 && n < a.Nout) ? (unsigned)((n * a.wrow + kv * 8) * 2) : OOB;
+    bvo = (wave < BN / 16 && n < a.Nout) ? (unsigned)((n * a.wrow + kv * 8) * 2) : OOB;
   }
   // ---- per-tap fragment offsets (activation rows shifted by the tap displacement)
   const int r = lane & 15, q = lane >> 4;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
     }                                                                                                               \
   } while (0)
 #define ISSUE_B(RS, TAP, CHUNK, SLOT)                                                                               \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + (wave < 8 ? BBASE + (SLOT) * BTILE + wave * 1024 : SINK)), 16, (int)bvo, \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + (wave < BN / 16 ? BBASE + (SLOT) * BTILE + wave * 1024 : SINK)), 16, (int)bvo, \
                                            ((TAP) * a.Cin + (CHUNK) * 32) * 2, 0, 0)
 
   f32x4_t acc[FM][FN];
@@ -386,17 +390,18 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 
 namespace {
 
-template <int MODE, int BM, int NPA, bool FUSE, int WN, bool EPI = false, int BRING = 3>
+template <int MODE, int BM, int NPA, bool FUSE, int WN, bool EPI = false, int BRING = 3, int BN_ = 128>
 int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   constexpr int NW = WM * WN;
+  constexpr int BN = BN_, BTILE = BN * 64, SROW = BN * 2 + 16;
   // A grid that puts one workgroup on a CU has only the ring's lookahead in flight on that CU's L2 -> LDS path (latency-bound fill):
   // such launches (batch 32: the 13x13 and 26x26 data gradients) take a 4-slot weight ring.  Same-box A/B of the YOLOv3 step:
   // +0.45 .. 0.6 % (6 slots +0.35 %; 4 slots on EVERY grid -2.8 %: the 36-step unrolled period and the third workgroup's worth of LDS).
   if constexpr (BRING == 3 && WN == 2 && !EPI) {
     if (g_shift_ring == 6 && tiles_m * a.tiles_n <= 256)
-      return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 6>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 6, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
     if ((g_shift_ring == 4 && tiles_m * a.tiles_n <= 256) || g_shift_ring == 5)
-      return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 4>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 4, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
   a.p_base = p_base;
   a.tiles_total = tiles_m * a.tiles_n;
@@ -406,7 +411,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics / fused-sum scratch (NW*BN floats)
   const int lds = pipe > epi ? pipe : epi;
   static int attr_lds = 0;
-  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE, WN, EPI>;
+  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE, WN, EPI, BN_>;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
@@ -417,35 +422,37 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   return MDCV_OK;
 }
 
-template <int MODE, int BM, int NPA, int WN>
+template <int MODE, int BM, int NPA, int WN, int BN_>
 int launch_shift(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   if constexpr (MODE == 1 && WN == 2 && BM % 128 == 0) {   // the fused BatchNorm-backward sums exist for 8-wave data gradients only
-    if (a.fuse.y) return launch_shift_f<MODE, BM, NPA, true, WN>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+    if (a.fuse.y) return launch_shift_f<MODE, BM, NPA, true, WN, false, 3, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
   if constexpr (MODE == 0 && WN == 2) {                    // inference epilogue: forward, 8-wave tiles
-    if (a.epi.oscale || a.epi.act) return launch_shift_f<MODE, BM, NPA, false, WN, true>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+    if (a.epi.oscale || a.epi.act) return launch_shift_f<MODE, BM, NPA, false, WN, true, 3, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
   if (a.epi.oscale || a.epi.act) return MDCV_EARG;          // no inference instantiation for this mode / wave layout
-  return launch_shift_f<MODE, BM, NPA, false, WN>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  return launch_shift_f<MODE, BM, NPA, false, WN, false, 3, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
 }
 
 // 16-wave workgroups (4 x 4 waves of (BM/4) x 32) were tried for grids that put at most one workgroup on a CU (idea: 4 waves per
 // SIMD from one workgroup hide the K-step latencies like two co-resident 8-wave workgroups).  Measured slower everywhere
 // (26x26 dgrad 54.4 vs 50.4 us, 13x13 forward 56.1 vs 52.2 us: the 16-wave barrier and the extra fragment reads cost more than
 // the latency hiding gains), so the variant is only reachable through the tuning hook (plan 4).
-template <int MODE, int BM>
+template <int MODE, int BM, int BN_>
 int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   const int nca = (BM + 2 * a.Wq + 2 + 15) / 16;
-  const bool wide = g_shift_plan == 4 && !a.fuse.y;
-  if (wide) {
-    const int npa = (nca + 15) / 16;
-    if (npa <= 1) return launch_shift<MODE, BM, 1, 4>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-    return launch_shift<MODE, BM, 2, 4>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  if constexpr (BN_ == 128) {
+    const bool wide = g_shift_plan == 4 && !a.fuse.y;
+    if (wide) {
+      const int npa = (nca + 15) / 16;
+      if (npa <= 1) return launch_shift<MODE, BM, 1, 4, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      return launch_shift<MODE, BM, 2, 4, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+    }
   }
   const int npa = (nca + 7) / 8;
-  if (npa <= 2) return launch_shift<MODE, BM, 2, 2>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-  if (npa == 3) return launch_shift<MODE, BM, 3, 2>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-  return launch_shift<MODE, BM, 4, 2>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  if (npa <= 2) return launch_shift<MODE, BM, 2, 2, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  if (npa == 3) return launch_shift<MODE, BM, 3, 2, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  return launch_shift<MODE, BM, 4, 2, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
 }
 
 // Tile plan.  Inside a busy CU the K loop is MFMA-bound whether one or two workgroups share it (a lone workgroup simply runs
@@ -467,11 +474,11 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused) {
   return c192 < c256 ? 192 : 256;
 }
 
-template <int MODE>
+template <int MODE, int BN_>
 int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   const int SLOTS = 512;
   const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr);
-  if (bm == 192) return launch_shift_bm<MODE, 192>(a, 0, (a.Mq + 191) / 192, st, in_bytes, w_bytes);
+  if (bm == 192) return launch_shift_bm<MODE, 192, BN_>(a, 0, (a.Mq + 191) / 192, st, in_bytes, w_bytes);
   const int big_m = (a.Mq + 255) / 256;
   const int t_big = big_m * a.tiles_n;
   int nbig_m = bm == 128 ? 0 : big_m;
@@ -480,11 +487,11 @@ int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, uns
     nbig_m = (rem > 0 && rem <= SLOTS / 2) ? full / a.tiles_n : big_m;
   }
   if (nbig_m > 0) {
-    const int rc = launch_shift_bm<MODE, 256>(a, 0, nbig_m, st, in_bytes, w_bytes);
+    const int rc = launch_shift_bm<MODE, 256, BN_>(a, 0, nbig_m, st, in_bytes, w_bytes);
     if (rc) return rc;
   }
   const int p_base = nbig_m * 256;
-  if (p_base < a.Mq) return launch_shift_bm<MODE, 128>(a, p_base, (a.Mq - p_base + 127) / 128, st, in_bytes, w_bytes);
+  if (p_base < a.Mq) return launch_shift_bm<MODE, 128, BN_>(a, p_base, (a.Mq - p_base + 127) / 128, st, in_bytes, w_bytes);
   return MDCV_OK;
 }
 
@@ -493,7 +500,7 @@ int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, uns
 // ---- host side (internal linkage across the library's objects: declared in conv_shift.h)
 bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc) {
   if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || dil != 1) return false;
-  if ((Cin & 31) || Cin < 32 || (Nout & 127)) return false;
+  if ((Cin & 31) || Cin < 32 || ((Nout & 127) && !(Nout == 64 && g_shift_n64))) return false;   // 128-wide tiles, or one 64-wide tile column
   if (H < 8 || W < 8 || W > g_shift_wmax) return false;        // 62: chunk rows 256 + 2(W+1) + 2 <= 384; up to 86 two workgroups still fit a CU
   if ((long long)B * (H + 1) * (W + 1) + 1024 >= (1LL << 30)) return false;
   if ((long long)B * H * W * in_ldc * 2 >= (1LL << 31) || (long long)Nout * 9 * Cin * 2 >= (1LL << 31)) return false;
@@ -504,7 +511,7 @@ int mdcv_shift_stats_rows(int B, int H, int W) { return (int)(((long long)B * (H
 // rows of the FORWARD statistics buffer: one per 128 stream positions, or one per tile when the plan picks 192-row tiles
 int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout) {
   const int Mq = B * (H + 1) * (W + 1);
-  return shift_plan_bm(Mq, Nout / BN, false) == 192 ? (Mq + 191) / 192 : (Mq + 127) / 128;
+  return shift_plan_bm(Mq, Nout == 64 ? 1 : Nout / BN, false) == 192 ? (Mq + 191) / 192 : (Mq + 127) / 128;
 }
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
@@ -517,16 +524,17 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   a.in_ldc = in_ldc; a.out_ldc = out_ldc; a.add_ldc = add_ldc;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Nout = Nout;
   a.Wq = W + 1; a.Sq = (H + 1) * (W + 1); a.Mq = B * a.Sq;
-  a.tiles_n = Nout / BN;
+  a.tiles_n = Nout == 64 ? 1 : Nout / BN;
   a.tiles_total = 0; a.xcd_chunk = 0; a.nca = 0; a.p_base = 0;
   a.nchunks = Cin / 32;
   a.wrow = 9 * Cin;
   const unsigned in_bytes = (unsigned)((long long)B * H * W * in_ldc * 2);
   const unsigned w_bytes = (unsigned)((long long)Nout * 9 * Cin * 2);
-  return mode == 0 ? launch_shift_mode<0>(a, st, in_bytes, w_bytes) : launch_shift_mode<1>(a, st, in_bytes, w_bytes);
+  if (Nout == 64) return mode == 0 ? launch_shift_mode<0, 64>(a, st, in_bytes, w_bytes) : launch_shift_mode<1, 64>(a, st, in_bytes, w_bytes);
+  return mode == 0 ? launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes) : launch_shift_mode<1, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring == 17 || ring == 18) { g_shift_n64 = ring == 17; return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

@@ -764,3 +764,44 @@ def test_conv2d_affine_act_inference_epilogue(case, dt):
                          cop, out2.data_ptr(), cop, B * Ho * Wo, cop, act, slope, st()))
     got2 = to_nchw(out2, dt, Co).numpy()
     np.testing.assert_allclose(got, got2, rtol=tol, atol=tol * max(1.0, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("case", [(4, 64, 26, 26, 64), (3, 32, 30, 17, 64), (2, 64, 80, 80, 64), (33, 64, 13, 13, 64)])
+def test_shift_conv_64_wide_tile_column(case):
+    """64-channel layers through the shift kernel's 64-wide tile column (tuning variant -17) == the im2col kernel (-18): forward with
+    BatchNorm statistics, data gradient with and without addsrc."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, H, W, Co = case
+    gg = torch.Generator().manual_seed(B + Ci + W)
+    x = torch.randn(B, Ci, H, W, generator=gg)
+    w = torch.randn(Co, Ci, 3, 3, generator=gg) / (Ci * 9) ** 0.5
+    w2 = torch.randn(Ci, Co, 3, 3, generator=gg) / (Co * 9) ** 0.5      # a layer whose INPUT has 64 channels: its data gradient has N = 64
+    xb = to_nhwc(x, dt)
+    wf, wd = pack(dt, w)
+    wf2, wd2 = pack(dt, w2)
+    dyb = to_nhwc(torch.randn(B, Ci, H, W, generator=gg), dt)
+    addb = to_nhwc(torch.randn(B, Co, H, W, generator=gg), dt)
+    outs = {}
+    for v in (-18, -17):
+        L.conv2d_set_variant(v)
+        try:
+            y = torch.full((B, H, W, Co), float("nan"), dtype=TD[dt], device="cuda")
+            rows = L.conv2d_stats_rows_geom(dt, B, H, W, Ci, Co, 3, 3, 1, 1, 1, Ci)
+            stats = torch.zeros(rows, 2, Co, device="cuda")
+            L.check(L.conv2d(dt, 0, xb.data_ptr(), Ci, wf.data_ptr(), y.data_ptr(), Co, None, None, 0, stats.data_ptr(),
+                             B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, st()), "conv")
+            dx = torch.full((B, H, W, Co), float("nan"), dtype=TD[dt], device="cuda")
+            L.check(L.conv2d(dt, 1, dyb.data_ptr(), Ci, wd2.data_ptr(), dx.data_ptr(), Co, None, addb.data_ptr(), Co, None,
+                             B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, st()), "dgrad")
+            torch.cuda.synchronize()
+            outs[v] = (y.float().cpu(), stats.sum(0).cpu(), dx.float().cpu())
+        finally:
+            L.conv2d_set_variant(-18)
+    ref = F.conv2d(rnd(dt, x), rnd(dt, w), None, stride=1, padding=1).permute(0, 2, 3, 1)
+    for v in outs:
+        assert torch.isfinite(outs[v][0]).all() and torch.isfinite(outs[v][2]).all(), v
+        torch.testing.assert_close(outs[v][0], ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(outs[-17][0], outs[-18][0], rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(outs[-17][2], outs[-18][2], rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(outs[-17][1], outs[-18][1], rtol=2e-3, atol=0.5)
