@@ -48,8 +48,8 @@ __device__ long long g_shift_ts[4 * 512];
 #endif
 
 int g_shift_ring = 4;   // weight-ring depth of sparse grids (<= 256 tiles); 3: off, 6: six slots, 5: four slots on every grid (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
-int g_shift_n64 = 1;    // 64-channel layers run a 64-wide tile column (set_variant(-18) off / (-17) on): RektNet's 64->64 layers 210 -> 168 us forward,
-                        // 211 -> 153 us data gradient; +0.5 % on its step (same-box A/B)
+int g_shift_n64 = 2;    // 64- and 32-channel layers run one narrow tile column (set_variant(-18) off / (-17) 64 only / (-19) 64 and 32): RektNet's
+                        // 64->64 layers 210 -> 168 us forward, 211 -> 153 us data gradient, +0.5 % on its step; the 32->32 layers another +0.35 %
 int g_shift_wmax = 80;  // widest image row the shift kernel takes (set_variant(-15) -> 62, (-14) -> 80).  Up to 62 the chunk is 384 rows (3 DMAs per
                         // wave); 63..80 take a fourth and still fit two workgroups on a CU: RektNet's 128->128 layers at 80x80 +3.1 % on its step,
                         // the 76x76 layers of the 608^2 detector +1 % on the joint pipeline (same-box A/B)
@@ -500,7 +500,7 @@ int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, uns
 // ---- host side (internal linkage across the library's objects: declared in conv_shift.h)
 bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc) {
   if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || dil != 1) return false;
-  if ((Cin & 31) || Cin < 32 || ((Nout & 127) && !(Nout == 64 && g_shift_n64))) return false;   // 128-wide tiles, or one 64-wide tile column
+  if ((Cin & 31) || Cin < 32 || ((Nout & 127) && !(Nout == 64 && g_shift_n64) && !(Nout == 32 && g_shift_n64 == 2))) return false;   // 128-wide tiles, or one 64-wide tile column
   if (H < 8 || W < 8 || W > g_shift_wmax) return false;        // 62: chunk rows 256 + 2(W+1) + 2 <= 384; up to 86 two workgroups still fit a CU
   if ((long long)B * (H + 1) * (W + 1) + 1024 >= (1LL << 30)) return false;
   if ((long long)B * H * W * in_ldc * 2 >= (1LL << 31) || (long long)Nout * 9 * Cin * 2 >= (1LL << 31)) return false;
@@ -511,7 +511,7 @@ int mdcv_shift_stats_rows(int B, int H, int W) { return (int)(((long long)B * (H
 // rows of the FORWARD statistics buffer: one per 128 stream positions, or one per tile when the plan picks 192-row tiles
 int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout) {
   const int Mq = B * (H + 1) * (W + 1);
-  return shift_plan_bm(Mq, Nout == 64 ? 1 : Nout / BN, false) == 192 ? (Mq + 191) / 192 : (Mq + 127) / 128;
+  return shift_plan_bm(Mq, Nout <= 64 ? 1 : Nout / BN, false) == 192 ? (Mq + 191) / 192 : (Mq + 127) / 128;
 }
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
@@ -524,17 +524,18 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   a.in_ldc = in_ldc; a.out_ldc = out_ldc; a.add_ldc = add_ldc;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Nout = Nout;
   a.Wq = W + 1; a.Sq = (H + 1) * (W + 1); a.Mq = B * a.Sq;
-  a.tiles_n = Nout == 64 ? 1 : Nout / BN;
+  a.tiles_n = Nout <= 64 ? 1 : Nout / BN;
   a.tiles_total = 0; a.xcd_chunk = 0; a.nca = 0; a.p_base = 0;
   a.nchunks = Cin / 32;
   a.wrow = 9 * Cin;
   const unsigned in_bytes = (unsigned)((long long)B * H * W * in_ldc * 2);
   const unsigned w_bytes = (unsigned)((long long)Nout * 9 * Cin * 2);
+  if (Nout == 32) return mode == 0 ? launch_shift_mode<0, 32>(a, st, in_bytes, w_bytes) : launch_shift_mode<1, 32>(a, st, in_bytes, w_bytes);
   if (Nout == 64) return mode == 0 ? launch_shift_mode<0, 64>(a, st, in_bytes, w_bytes) : launch_shift_mode<1, 64>(a, st, in_bytes, w_bytes);
   return mode == 0 ? launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes) : launch_shift_mode<1, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring == 17 || ring == 18) { g_shift_n64 = ring == 17; return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

@@ -766,10 +766,11 @@ def test_conv2d_affine_act_inference_epilogue(case, dt):
     np.testing.assert_allclose(got, got2, rtol=tol, atol=tol * max(1.0, float(ref.abs().max())))
 
 
-@pytest.mark.parametrize("case", [(4, 64, 26, 26, 64), (3, 32, 30, 17, 64), (2, 64, 80, 80, 64), (33, 64, 13, 13, 64)])
+@pytest.mark.parametrize("case", [(4, 64, 26, 26, 64), (3, 32, 30, 17, 64), (2, 64, 80, 80, 64), (33, 64, 13, 13, 64),
+                                  (4, 32, 26, 26, 32), (2, 64, 80, 80, 32), (33, 32, 13, 13, 32)])
 def test_shift_conv_64_wide_tile_column(case):
-    """64-channel layers through the shift kernel's 64-wide tile column (tuning variant -17) == the im2col kernel (-18): forward with
-    BatchNorm statistics, data gradient with and without addsrc."""
+    """64- (and, variant -19, 32-) channel layers through the shift kernel's narrow tile column == the im2col kernel (-18): forward
+    with BatchNorm statistics, data gradient with addsrc."""
     L = _lib.lib()
     dt = BF16
     B, Ci, H, W, Co = case
@@ -784,7 +785,7 @@ def test_shift_conv_64_wide_tile_column(case):
     addb = to_nhwc(torch.randn(B, Co, H, W, generator=gg), dt)
     outs = {}
     for v in (-18, -17):
-        L.conv2d_set_variant(v)
+        L.conv2d_set_variant(v if Co != 32 or v == -18 else -19)
         try:
             y = torch.full((B, H, W, Co), float("nan"), dtype=TD[dt], device="cuda")
             rows = L.conv2d_stats_rows_geom(dt, B, H, W, Ci, Co, 3, 3, 1, 1, 1, Ci)
@@ -797,7 +798,7 @@ def test_shift_conv_64_wide_tile_column(case):
             torch.cuda.synchronize()
             outs[v] = (y.float().cpu(), stats.sum(0).cpu(), dx.float().cpu())
         finally:
-            L.conv2d_set_variant(-18)
+            L.conv2d_set_variant(-19)               # the library default
     ref = F.conv2d(rnd(dt, x), rnd(dt, w), None, stride=1, padding=1).permute(0, 2, 3, 1)
     for v in outs:
         assert torch.isfinite(outs[v][0]).all() and torch.isfinite(outs[v][2]).all(), v
