@@ -1752,7 +1752,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   // 3x3 / stride 1 / pad 1 on wide layers: nine shifted GEMMs over one LDS-resident activation chunk (conv_shift.hip)
   const bool shift_ok = Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc);
   if (shift_ok && (g_conv_variant < 0 || fuse))
-    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st, epi);
+    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st, epi, dil);
   if (fuse) {                                     // the fused store loop lives in the LDS-DMA kernels: never fall back to the staged ones
     if (!small) return MDCV_EARG;
     const int keep = g_conv_variant;
@@ -1762,7 +1762,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
     return rc;
   }
   if (shift_ok && stats_partial) {   // forced generic kernel on a shift-eligible geometry (A/B runs): the caller sized the partial
-    const int r0 = cdiv(a.M, 128), r1 = mdcv_shift_fwd_stats_rows(B, Hout, Wout, Nout);   // rows for the shift kernel; zero the unused tail
+    const int r0 = cdiv(a.M, 128), r1 = mdcv_shift_fwd_stats_rows(B, Hout, Wout, Nout, dil);   // rows for the shift kernel; zero the unused tail
     if (r1 > r0) {
       hipError_t e = hipMemsetAsync(stats_partial + (size_t)r0 * 2 * Nout, 0, (size_t)(r1 - r0) * 2 * Nout * sizeof(float), st);
       if (e != hipSuccess) return (int)e;
@@ -1802,7 +1802,7 @@ int mdcv_conv2d_dgrad_bnsums_rows(int dtype, int B, int Hin, int Win, int Cin, i
   if (dtype != MDCV_BF16) return 0;     // production dtype only: not every fp32 tile variant carries the fused store loop
   if ((long long)B * Hin * Win * in_ldc * es >= (1LL << 31) || (long long)Nout * KH * KW * Cin * es >= (1LL << 31)) return 0;
   if (Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc))
-    return mdcv_shift_stats_rows(B, Hout, Wout);
+    return mdcv_shift_stats_rows(B, Hout, Wout, dil);
   if (stride == 2 && dil == 1) {
     int rows = 0;
     for (int cls = 0; cls < 4; ++cls) {
@@ -1833,7 +1833,7 @@ int mdcv_conv2d_stats_rows(int M) { return cdiv(M, 128); }
 // rows for a given forward geometry: the 3x3 stride-1 shift kernel walks a padded position stream and writes more rows
 int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil,
                                 int in_ldc) {
-  if (mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc)) return mdcv_shift_fwd_stats_rows(B, Hout, Wout, Nout);
+  if (mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc)) return mdcv_shift_fwd_stats_rows(B, Hout, Wout, Nout, dil);
   return cdiv(B * Hout * Wout, 128);
 }
 
@@ -1845,7 +1845,7 @@ int mdcv_conv2d_wgrad_set_variant(int v) {   /* tuning hook; 1000 + 100*d + bloc
   return MDCV_OK;
 }
 int mdcv_conv2d_set_variant(int v) {
-  if (v <= -3 && v >= -19) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11 16-wave workgroups, -12 192-row tiles where they save a round
+  if (v <= -3 && v >= -22) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11 16-wave workgroups, -12 192-row tiles where they save a round
   if (v == 97 || v == 96) { g_conv_midgrid = v == 97 ? 300 : 0; return MDCV_OK; }
   if (v >= 3000 && v < 9000) { g_conv_midgrid = v - 3000; return MDCV_OK; }   // 3000 + first t128 that takes 256x128 tiles
   if (v == 95 || v == 94) { g_conv_fuse_small = v == 95; return MDCV_OK; }

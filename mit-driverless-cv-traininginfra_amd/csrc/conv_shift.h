@@ -7,18 +7,19 @@ struct ShiftArgs {
   const void* in; const void* w; void* out; const float* bias; const void* addsrc; float* stats;
   int in_ldc, out_ldc, add_ldc;
   int B, H, W, Cin, Nout;
-  int Wq, Sq, Mq;                       // W+1, (H+1)(W+1), B*Sq: the padded position stream
+  int Wq, Sq, Mq;                       // W+dil, (H+dil)(W+dil), B*Sq: the padded position stream
   int tiles_n, tiles_total, xcd_chunk;
   int p_base;                           // first stream position of this launch (multiple of 256)
+  int dil;                              // dilation (1 or 2): the stream carries `dil` shared zero columns per image row and zero rows per image
   BnFuseArgs fuse;                      // BatchNorm-backward sums folded into the store loop (fuse.y == NULL: off)
   EpiArgs epi;                          // inference epilogue (oscale == NULL and act == 0: off)
   int nchunks, wrow, nca;               // Cin/32 ; 9*Cin elements per weight row ; KiB-chunks per activation chunk
 };
 
 bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc);
-int mdcv_shift_stats_rows(int B, int H, int W);                 // partial rows of the fused data-gradient sums (one per 128 positions)
-int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout);  // partial rows of the forward statistics (depends on the tile plan)
+int mdcv_shift_stats_rows(int B, int H, int W, int dil = 1);                 // partial rows of the fused data-gradient sums (one per 128 positions)
+int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil = 1);  // partial rows of the forward statistics (depends on the tile plan)
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
                     int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st,
-                    const EpiArgs* epi = nullptr);
+                    const EpiArgs* epi = nullptr, int dil = 1);
 void mdcv_shift_set_ring(int ring);

@@ -48,6 +48,8 @@ __device__ long long g_shift_ts[4 * 512];
 #endif
 
 int g_shift_ring = 4;   // weight-ring depth of sparse grids (<= 256 tiles); 3: off, 6: six slots, 5: four slots on every grid (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
+int g_shift_dil2 = 1;   // dilation-2 layers (stream padded with two shared zero columns / rows): 1 = where it pays (below), 2 = every eligible
+                        // layer (set_variant(-20)), 0 = never (set_variant(-21)), set_variant(-22) restores 1
 int g_shift_n64 = 2;    // 64- and 32-channel layers run one narrow tile column (set_variant(-18) off / (-17) 64 only / (-19) 64 and 32): RektNet's
                         // 64->64 layers 210 -> 168 us forward, 211 -> 153 us data gradient, +0.5 % on its step; the 32->32 layers another +0.35 %
 int g_shift_wmax = 80;  // widest image row the shift kernel takes (set_variant(-15) -> 62, (-14) -> 80).  Up to 62 the chunk is 384 rows (3 DMAs per
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 #pragma unroll
   for (int k = 0; k < NPA; ++k) {
     const int j = (wave + k * NW) * 16 + lrow;             // LDS row of the activation chunk
-    const int t = p0 + j - (a.Wq + 1);
+    const int t = p0 + j - a.dil * (a.Wq + 1);
     bool ok = t >= 0 && t < a.Mq;
     const int tt = ok ? t : 0;
     const int img = tt / a.Sq, rem = tt - img * a.Sq;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int kh = tap / 3, kw = tap - kh * 3;
-    const int d = MODE == 0 ? kh * a.Wq + kw : (2 - kh) * a.Wq + (2 - kw);
+    const int d = a.dil * (MODE == 0 ? kh * a.Wq + kw : (2 - kh) * a.Wq + (2 - kw));
     const int row = wm * TM + d + r;
     offA[tap] = row * 64 + ((q ^ swz(row)) << 4);
   }
@@ -406,7 +408,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   a.p_base = p_base;
   a.tiles_total = tiles_m * a.tiles_n;
   a.xcd_chunk = (a.tiles_total + 7) / 8;
-  a.nca = (BM + 2 * a.Wq + 2 + 15) / 16;                   // KiB-chunks (16 stream rows each) of one activation chunk
+  a.nca = (BM + 2 * a.dil * (a.Wq + 1) + 15) / 16;         // KiB-chunks (16 stream rows each) of one activation chunk
   const int pipe = 2 * a.nca * 1024 + BRING * BTILE + 1024;
   const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics / fused-sum scratch (NW*BN floats)
   const int lds = pipe > epi ? pipe : epi;
@@ -440,7 +442,7 @@ int launch_shift(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, un
 // the latency hiding gains), so the variant is only reachable through the tuning hook (plan 4).
 template <int MODE, int BM, int BN_>
 int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
-  const int nca = (BM + 2 * a.Wq + 2 + 15) / 16;
+  const int nca = (BM + 2 * a.dil * (a.Wq + 1) + 15) / 16;
   if constexpr (BN_ == 128) {
     const bool wide = g_shift_plan == 4 && !a.fuse.y;
     if (wide) {
@@ -452,7 +454,8 @@ int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st,
   const int npa = (nca + 7) / 8;
   if (npa <= 2) return launch_shift<MODE, BM, 2, 2, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   if (npa == 3) return launch_shift<MODE, BM, 3, 2, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-  return launch_shift<MODE, BM, 4, 2, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  if (npa == 4) return launch_shift<MODE, BM, 4, 2, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  return launch_shift<MODE, BM, 5, 2, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);   // dilation 2 at 80 pixels per row
 }
 
 // Tile plan.  Inside a busy CU the K loop is MFMA-bound whether one or two workgroups share it (a lone workgroup simply runs
@@ -463,7 +466,14 @@ int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st,
 // with the rest; since the BatchNorm sums moved into the data gradients the main stream bounds the step and the 192-row plan is
 // +0.6 % (2043 -> 2055 img/s, same-box A/B), so it is the default where it saves a round (batch 32: the 26x26 layers); 128-row
 // tiles only for grids of at most 128 tiles; plan 6 restores 256-row-only.
-int shift_plan_bm(int Mq, int tiles_n, bool fused) {
+int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128) {
+  if (halo > 0 && !fused) {   // dilation 2: the halo (2 * dil * (Wq + 1) rows) dominates the LDS footprint; tallest tile that leaves two workgroups on a CU
+    for (int bm = 256; bm >= 128; bm -= 64) {
+      const int nca = (bm + halo + 15) / 16;
+      if (2 * nca * 1024 + 3 * bn * 64 + 1024 <= 80 * 1024) return bm;
+    }
+    return 256;
+  }
   if (g_shift_plan == 1) return 256;
   if (g_shift_plan == 2) return 128;
   const int t256 = ((Mq + 255) / 256) * tiles_n;
@@ -477,7 +487,7 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused) {
 template <int MODE, int BN_>
 int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   const int SLOTS = 512;
-  const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr);
+  const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr, a.dil == 2 ? 2 * a.dil * (a.Wq + 1) : 0, BN_);
   if (bm == 192) return launch_shift_bm<MODE, 192, BN_>(a, 0, (a.Mq + 191) / 192, st, in_bytes, w_bytes);
   const int big_m = (a.Mq + 255) / 256;
   const int t_big = big_m * a.tiles_n;
@@ -499,31 +509,35 @@ int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, uns
 
 // ---- host side (internal linkage across the library's objects: declared in conv_shift.h)
 bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc) {
-  if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || dil != 1) return false;
+  if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != dil || (dil != 1 && !(dil == 2 && g_shift_dil2))) return false;
+  // dilation 2 pays where the halo-heavy chunk is amortised over >= 2 channel chunks and two workgroups still fit a CU (narrow tiles):
+  // RektNet data gradient 128->64 412 -> 332 us, 64->32 193 -> 183 us; forward 64->128 (128-wide tile, one workgroup per CU) 281 -> 360 us
+  if (dil == 2 && g_shift_dil2 == 1 && !(Nout <= 64 && Cin >= 64)) return false;
   if ((Cin & 31) || Cin < 32 || ((Nout & 127) && !(Nout == 64 && g_shift_n64) && !(Nout == 32 && g_shift_n64 == 2))) return false;   // 128-wide tiles, or one 64-wide tile column
   if (H < 8 || W < 8 || W > g_shift_wmax) return false;        // 62: chunk rows 256 + 2(W+1) + 2 <= 384; up to 86 two workgroups still fit a CU
-  if ((long long)B * (H + 1) * (W + 1) + 1024 >= (1LL << 30)) return false;
+  if ((long long)B * (H + dil) * (W + dil) + 1024 >= (1LL << 30)) return false;
   if ((long long)B * H * W * in_ldc * 2 >= (1LL << 31) || (long long)Nout * 9 * Cin * 2 >= (1LL << 31)) return false;
   return true;
 }
 
-int mdcv_shift_stats_rows(int B, int H, int W) { return (int)(((long long)B * (H + 1) * (W + 1) + 127) / 128); }
+int mdcv_shift_stats_rows(int B, int H, int W, int dil) { return (int)(((long long)B * (H + dil) * (W + dil) + 127) / 128); }
 // rows of the FORWARD statistics buffer: one per 128 stream positions, or one per tile when the plan picks 192-row tiles
-int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout) {
-  const int Mq = B * (H + 1) * (W + 1);
-  return shift_plan_bm(Mq, Nout <= 64 ? 1 : Nout / BN, false) == 192 ? (Mq + 191) / 192 : (Mq + 127) / 128;
+int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil) {
+  const int Mq = B * (H + dil) * (W + dil);
+  const int bn = Nout <= 64 ? Nout : BN;
+  return shift_plan_bm(Mq, Nout <= 64 ? 1 : Nout / BN, false, dil == 2 ? 2 * dil * (W + dil + 1) : 0, bn) == 192 ? (Mq + 191) / 192 : (Mq + 127) / 128;
 }
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
                     int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st,
-                    const EpiArgs* epi) {
+                    const EpiArgs* epi, int dil) {
   ShiftArgs a;
   if (fuse) a.fuse = *fuse; else a.fuse = BnFuseArgs{};
   if (epi) a.epi = *epi; else a.epi = EpiArgs{nullptr, 0, 0.f};
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addsrc = addsrc; a.stats = stats;
   a.in_ldc = in_ldc; a.out_ldc = out_ldc; a.add_ldc = add_ldc;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Nout = Nout;
-  a.Wq = W + 1; a.Sq = (H + 1) * (W + 1); a.Mq = B * a.Sq;
+  a.dil = dil; a.Wq = W + dil; a.Sq = (H + dil) * (W + dil); a.Mq = B * a.Sq;
   a.tiles_n = Nout <= 64 ? 1 : Nout / BN;
   a.tiles_total = 0; a.xcd_chunk = 0; a.nca = 0; a.p_base = 0;
   a.nchunks = Cin / 32;
@@ -535,7 +549,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   return mode == 0 ? launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes) : launch_shift_mode<1, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

@@ -806,3 +806,49 @@ def test_shift_conv_64_wide_tile_column(case):
     torch.testing.assert_close(outs[-17][0], outs[-18][0], rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(outs[-17][2], outs[-18][2], rtol=1e-2, atol=2e-2)
     torch.testing.assert_close(outs[-17][1], outs[-18][1], rtol=2e-3, atol=0.5)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 80, 80, 128), (2, 32, 80, 80, 64), (3, 64, 26, 26, 64), (4, 32, 30, 17, 32), (33, 128, 13, 13, 128)])
+def test_shift_conv_dilation2(case):
+    """Dilation-2 / pad-2 layers through the shift kernel (variant -20: stream with two shared zero columns / rows) == the im2col kernel
+    (-21) == torch: forward with BatchNorm statistics, data gradient with addsrc."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, H, W, Co = case
+    gg = torch.Generator().manual_seed(B + Ci + W + 2)
+    x = torch.randn(B, Ci, H, W, generator=gg)
+    w = torch.randn(Co, Ci, 3, 3, generator=gg) / (Ci * 9) ** 0.5
+    xb = to_nhwc(x, dt)
+    wf, wd = pack(dt, w)
+    dy = torch.randn(B, Co, H, W, generator=gg)
+    dyb = to_nhwc(dy, dt)
+    add = torch.randn(B, Ci, H, W, generator=gg)
+    addb = to_nhwc(add, dt)
+    outs = {}
+    for v in (-21, -20):
+        L.conv2d_set_variant(v)
+        try:
+            y = torch.full((B, H, W, Co), float("nan"), dtype=TD[dt], device="cuda")
+            rows = L.conv2d_stats_rows_geom(dt, B, H, W, Ci, Co, 3, 3, 1, 2, 2, Ci)
+            stats = torch.zeros(rows, 2, Co, device="cuda")
+            L.check(L.conv2d(dt, 0, xb.data_ptr(), Ci, wf.data_ptr(), y.data_ptr(), Co, None, None, 0, stats.data_ptr(),
+                             B, H, W, Ci, H, W, Co, 3, 3, 1, 2, 2, st()), "conv")
+            dx = torch.full((B, H, W, Ci), float("nan"), dtype=TD[dt], device="cuda")
+            L.check(L.conv2d(dt, 1, dyb.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, None, addb.data_ptr(), Ci, None,
+                             B, H, W, Co, H, W, Ci, 3, 3, 1, 2, 2, st()), "dgrad")
+            torch.cuda.synchronize()
+            outs[v] = (y.float().cpu(), stats.sum(0).cpu(), dx.float().cpu())
+        finally:
+            L.conv2d_set_variant(-22)               # the library default
+    xr = rnd(dt, x).requires_grad_(True)
+    ref = F.conv2d(xr, rnd(dt, w), None, stride=1, padding=2, dilation=2)
+    ref.backward(rnd(dt, dy))
+    refdx = (xr.grad + rnd(dt, add)).permute(0, 2, 3, 1)
+    ref = ref.detach().permute(0, 2, 3, 1)
+    for v in outs:
+        assert torch.isfinite(outs[v][0]).all() and torch.isfinite(outs[v][2]).all(), v
+        torch.testing.assert_close(outs[v][0], ref, rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(outs[v][2], refdx, rtol=2e-2, atol=4e-2)
+    torch.testing.assert_close(outs[-20][0], outs[-21][0], rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(outs[-20][2], outs[-21][2], rtol=1e-2, atol=2e-2)
+    torch.testing.assert_close(outs[-20][1], outs[-21][1], rtol=2e-3, atol=0.5)
