@@ -767,7 +767,7 @@ def test_conv2d_affine_act_inference_epilogue(case, dt):
 
 
 @pytest.mark.parametrize("case", [(4, 64, 26, 26, 64), (3, 32, 30, 17, 64), (2, 64, 80, 80, 64), (33, 64, 13, 13, 64),
-                                  (4, 32, 26, 26, 32), (2, 64, 80, 80, 32), (33, 32, 13, 13, 32)])
+                                  (4, 32, 26, 26, 32), (2, 64, 80, 80, 32), (33, 32, 13, 13, 32), (2, 128, 104, 104, 64), (1, 32, 97, 104, 32)])
 def test_shift_conv_64_wide_tile_column(case):
     """64- (and, variant -19, 32-) channel layers through the shift kernel's narrow tile column == the im2col kernel (-18): forward
     with BatchNorm statistics, data gradient with addsrc."""
