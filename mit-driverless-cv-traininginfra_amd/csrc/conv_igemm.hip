@@ -796,6 +796,7 @@ int g_conv_tall_narrow = 256; // 256-row tiles for Nout <= 64 from this many Ki 
 int g_conv_deep_narrow32 = 0; // tuning (set_variant 22 / 23): also the 128x32 and 128x16 tiles (surplus waves DMA zeros into a sink)
 int g_conv_deep_narrow = 1;  // 128x64 tiles of the 33..64-channel layers take the 3-stage ring from this many K steps (set_variant 30 + nk_min;
                              // 30 = never).  Same-box A/B: RektNet 29.93k -> 30.17k img/s, YOLOv3 +0.3 %
+int g_conv_deep4 = 0;        // tuning (set_variant 9000 + nk_min; 9000 = off): 4-stage ring for grids of at most 512 tiles of 128x128
 int g_conv_deep_small = 8;   // 128x128 and 128x64 tiles take the 3-stage DMA ring from this many K steps (set_variant 60 + nk_min; 60 = never).
                              // Same-box A/B of the YOLOv3 step: never 2031, from 4 steps 2045, from 8 2050, from 16 2045, from 32 2034 img/s
 int g_conv_fuse_small = 0;   // tuning (set_variant 95 / 94): fused-sum data gradients with a short K loop take 128x128 two-stage tiles (4 workgroups per CU)
@@ -816,6 +817,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
       v = t128 >= (g_conv_midgrid ? g_conv_midgrid : 1024) ? 11 : (nk >= 100 ? 9 : (t128 >= 300 ? 6 : 7));
       if (g_conv_fuse_small && MODE != 0 && a.fuse.y && nk <= 8 && v == 11) v = 6;
       if (g_conv_deep_small && nk >= g_conv_deep_small && (v == 6 || v == 7)) v += 3;   // 3-stage ring for the mid / sparse grids too
+      if (g_conv_deep4 && nk >= g_conv_deep4 && t128 <= 512 && (v == 9 || v == 10)) v = v == 9 ? 12 : 14;   // sparse grids: 4 stages
     }
     if (v >= 6 && !small) v = (v == 8 || v == 11 || v == 13) ? 2 : ((v == 7 || v == 10) ? 4 : 0);
     if (v == 6) return launch_conv_glds<T, MODE, 128, 128, 2, 2>(a, st, B);
@@ -823,6 +825,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
     if (v == 9) return launch_conv_glds<T, MODE, 128, 128, 2, 2, 3>(a, st, B);
     if (v == 10) return launch_conv_glds<T, MODE, 128, 64, 2, 2, 3>(a, st, B);
     if (v == 12) return launch_conv_glds<T, MODE, 128, 128, 2, 2, 4>(a, st, B);
+    if (v == 14) return launch_conv_glds<T, MODE, 128, 64, 2, 2, 4>(a, st, B);
     if (BF) {   // 8-wave / deep-K tiles only exist in the production dtype
       if (v == 8) return launch_conv_glds<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2>(a, st, B);
       if (v == 11) return launch_conv_glds<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, 3>(a, st, B);
@@ -1847,6 +1850,7 @@ int mdcv_conv2d_wgrad_set_variant(int v) {   /* tuning hook; 1000 + 100*d + bloc
 int mdcv_conv2d_set_variant(int v) {
   if (v <= -3 && v >= -24) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11 16-wave workgroups, -12 192-row tiles where they save a round
   if (v == 97 || v == 96) { g_conv_midgrid = v == 97 ? 300 : 0; return MDCV_OK; }
+  if (v >= 9000 && v < 9999) { g_conv_deep4 = v - 9000; return MDCV_OK; }
   if (v >= 3000 && v < 9000) { g_conv_midgrid = v - 3000; return MDCV_OK; }   // 3000 + first t128 that takes 256x128 tiles
   if (v == 95 || v == 94) { g_conv_fuse_small = v == 95; return MDCV_OK; }
   if (v >= 60 && v < 93) { g_conv_deep_small = v - 60; return MDCV_OK; }
