@@ -762,3 +762,49 @@ def test_bench_two_ranks_on_one_gpu_keep_replicas_in_sync():
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 8
     assert line["workloads"]["yolo"]["replicas_in_sync"] is True
     assert line["value"] > 0
+
+
+def test_rccl_allreduce_path_single_rank():
+    """The N > 1 exchange as the driver's multi-GPU run uses it -- backend "nccl" (= RCCL), buckets all-reduced on the comm stream while
+    backward and the side-stream weight gradients still run -- exercised on this one GPU with a world of one rank: SUM over one rank is the
+    identity, so the step must equal the plain step bit for bit.  (Two RCCL ranks cannot share a device; the two-rank run above uses gloo.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, tempfile, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import bench
+from mdcv.yolo.models import Darknet
+from mdcv.optim import FusedAdam
+from mdcv.parallel import GradAllReducer
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+tmp = tempfile.mkdtemp()
+cfg = bench.write_yolo_cfg(tmp)
+os.chdir(tmp)
+g = torch.Generator().manual_seed(3)
+x = torch.rand(4, 3, 416, 416, generator=g).cuda()
+tg = bench.synth_targets(4, 16, g).cuda()
+res = []
+for use_rccl in (False, True):
+    torch.manual_seed(0)
+    net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
+    opt = FusedAdam(net, lr=1e-3)
+    red = GradAllReducer.attach(net, bucket_mb=32.0, allreduce_fn=(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)) if use_rccl else None)
+    for _ in range(3):
+        opt.zero_grad()
+        out = net(x, tg)
+        out[0].sum().backward()
+        red.finish()
+        opt.step()
+    torch.cuda.synchronize()
+    res.append((float(out[0]), net.flat_parameters()[0].clone(), len(red.log)))
+dist.destroy_process_group()
+assert res[1][2] >= 4, res[1][2]                 # several buckets went through RCCL
+assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+print("RCCL_OK", res[1][2])
+""" % root
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
