@@ -249,8 +249,8 @@ def cpu_baseline_post(out_np, tg_np, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="both", choices=["both", "yolo", "rektnet", "postprocess", "joint"])
     ap.add_argument("--joint-batch", type=int, default=32, help="608x608 frames per GPU for the joint detect->keypoints workload")
     ap.add_argument("--post-batch", type=int, default=32, help="images per GPU for the detection post-processing workload")
