@@ -1848,7 +1848,7 @@ int mdcv_conv2d_wgrad_set_variant(int v) {   /* tuning hook; 1000 + 100*d + bloc
   return MDCV_OK;
 }
 int mdcv_conv2d_set_variant(int v) {
-  if (v <= -3 && v >= -24) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11 16-wave workgroups, -12 192-row tiles where they save a round
+  if (v <= -3 && v >= -26) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11 16-wave workgroups, -12 192-row tiles where they save a round
   if (v == 97 || v == 96) { g_conv_midgrid = v == 97 ? 300 : 0; return MDCV_OK; }
   if (v >= 9000 && v < 9999) { g_conv_deep4 = v - 9000; return MDCV_OK; }
   if (v >= 3000 && v < 9000) { g_conv_midgrid = v - 3000; return MDCV_OK; }   // 3000 + first t128 that takes 256x128 tiles

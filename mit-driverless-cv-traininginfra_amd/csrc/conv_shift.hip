@@ -50,6 +50,7 @@ __device__ long long g_shift_ts[4 * 512];
 int g_shift_ring = 4;   // weight-ring depth of sparse grids (<= 256 tiles); 3: off, 6: six slots, 5: four slots on every grid (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
 int g_shift_wmax_narrow = 104; // rows up to 104 pixels for the 64- / 32-wide tiles (their smaller weight ring keeps two workgroups on a CU): the data gradients of
                                // YOLOv3's 104x104 64->128 layers, +0.3 % on its step (set_variant(-24) off, (-23) on)
+int g_shift_wmax_n32 = 0;   // tuning (set_variant(-25) -> 208, (-26) -> off): 32-wide tiles on rows up to 208 pixels (128-row tiles)
 int g_shift_dil2 = 1;   // dilation-2 layers (stream padded with two shared zero columns / rows): 1 = where it pays (below), 2 = every eligible
                         // layer (set_variant(-20)), 0 = never (set_variant(-21)), set_variant(-22) restores 1
 int g_shift_n64 = 2;    // 64- and 32-channel layers run one narrow tile column (set_variant(-18) off / (-17) 64 only / (-19) 64 and 32): RektNet's
@@ -469,7 +470,8 @@ int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st,
 // +0.6 % (2043 -> 2055 img/s, same-box A/B), so it is the default where it saves a round (batch 32: the 26x26 layers); 128-row
 // tiles only for grids of at most 128 tiles; plan 6 restores 256-row-only.
 int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128) {
-  if (halo > 0 && !fused) {   // dilation 2: the halo (2 * dil * (Wq + 1) rows) dominates the LDS footprint; tallest tile that leaves two workgroups on a CU
+  if (halo > 0 && !fused && 2 * ((256 + halo + 15) / 16) * 1024 + 3 * bn * 64 + 1024 > 80 * 1024) {
+    // dilation 2 / very wide rows: the halo (2 * dil * (Wq + 1) rows) dominates the LDS footprint; tallest tile that leaves two workgroups on a CU
     for (int bm = 256; bm >= 128; bm -= 64) {
       const int nca = (bm + halo + 15) / 16;
       if (2 * nca * 1024 + 3 * bn * 64 + 1024 <= 80 * 1024) return bm;
@@ -489,7 +491,7 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128) {
 template <int MODE, int BN_>
 int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   const int SLOTS = 512;
-  const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr, a.dil == 2 ? 2 * a.dil * (a.Wq + 1) : 0, BN_);
+  const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr, 2 * a.dil * (a.Wq + 1), BN_);
   if (bm == 192) return launch_shift_bm<MODE, 192, BN_>(a, 0, (a.Mq + 191) / 192, st, in_bytes, w_bytes);
   const int big_m = (a.Mq + 255) / 256;
   const int t_big = big_m * a.tiles_n;
@@ -516,7 +518,7 @@ bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int 
   // RektNet data gradient 128->64 412 -> 332 us, 64->32 193 -> 183 us; forward 64->128 (128-wide tile, one workgroup per CU) 281 -> 360 us
   if (dil == 2 && g_shift_dil2 == 1 && !(Nout <= 64 && Cin >= 64)) return false;
   if ((Cin & 31) || Cin < 32 || ((Nout & 127) && !(Nout == 64 && g_shift_n64) && !(Nout == 32 && g_shift_n64 == 2))) return false;   // 128-wide tiles, or one 64-wide tile column
-  if (H < 8 || W < 8 || (W > g_shift_wmax && !(g_shift_wmax_narrow && Nout <= 64 && W <= g_shift_wmax_narrow))) return false;        // 62: chunk rows 256 + 2(W+1) + 2 <= 384; up to 86 two workgroups still fit a CU
+  if (H < 8 || W < 8 || (W > g_shift_wmax && !(g_shift_wmax_narrow && Nout <= 64 && W <= g_shift_wmax_narrow) && !(g_shift_wmax_n32 && Nout <= 32 && W <= g_shift_wmax_n32))) return false;        // 62: chunk rows 256 + 2(W+1) + 2 <= 384; up to 86 two workgroups still fit a CU
   if ((long long)B * (H + dil) * (W + dil) + 1024 >= (1LL << 30)) return false;
   if ((long long)B * H * W * in_ldc * 2 >= (1LL << 31) || (long long)Nout * 9 * Cin * 2 >= (1LL << 31)) return false;
   return true;
@@ -527,7 +529,7 @@ int mdcv_shift_stats_rows(int B, int H, int W, int dil) { return (int)(((long lo
 int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil) {
   const int Mq = B * (H + dil) * (W + dil);
   const int bn = Nout <= 64 ? Nout : BN;
-  return shift_plan_bm(Mq, Nout <= 64 ? 1 : Nout / BN, false, dil == 2 ? 2 * dil * (W + dil + 1) : 0, bn) == 192 ? (Mq + 191) / 192 : (Mq + 127) / 128;
+  return shift_plan_bm(Mq, Nout <= 64 ? 1 : Nout / BN, false, 2 * dil * (W + dil + 1), bn) == 192 ? (Mq + 191) / 192 : (Mq + 127) / 128;
 }
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
@@ -551,7 +553,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   return mode == 0 ? launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes) : launch_shift_mode<1, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);
