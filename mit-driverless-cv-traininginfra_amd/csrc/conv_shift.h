@@ -1,4 +1,4 @@
-// Internal interface between conv_igemm.hip (dispatch of mdcv_conv2d) and conv_shift.hip (3x3 stride-1 shift-GEMM kernel).
+// Internal interface between conv_igemm.hip (dispatch of mdcv_conv2d) and conv_shift.hip (3x3 stride-1 shift-GEMM kernel, dilation 1 or 2).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bn_fuse.h"

@@ -1,4 +1,4 @@
-// 3x3 / stride 1 / pad 1 convolution (forward and data gradient) as NINE SHIFTED GEMMs over one LDS-resident activation chunk.
+// 3x3 / stride 1 / pad = dilation convolution (forward and data gradient) as NINE SHIFTED GEMMs over one LDS-resident activation chunk.
 //
 // Why: the im2col kernel (conv_igemm.hip) fills LDS with a fresh A tile for every tap, i.e. every activation pixel travels
 // L2 -> LDS nine times.  Measured on MI355X that fill path saturates at ~30 GB/s per CU (~12.6 B/clk/CU), which is exactly what
@@ -13,6 +13,11 @@
 // (kh,kw) for stream positions [p0, p0+256) is rows [d, d+256) of ONE LDS chunk holding stream rows [p0, p0+256+2(W+1)+2),
 // d = kh*(W+1)+kw (forward) or (2-kh)*(W+1)+(2-kw) (data gradient).  Junk positions cost (H+1)(W+1)/(HW) - 1 extra MACs
 // (4 % at 52x52, 8 % at 26x26, 16 % at 13x13).
+//
+// Dilation 2 (pad 2) uses the same scheme with TWO shared zero columns per image row and two shared zero rows per image:
+//   p = img * (H+dil)(W+dil) + y * (W+dil) + x, tap displacement dil * (kh*(W+dil) + kw), halo 2*dil*(W+dil+1) rows.
+// Output channels per tile: 128, or one 64- / 32-wide tile column for 64- / 32-channel layers (template parameter BN_; the narrow
+// tiles' smaller weight ring also leaves room for rows up to 104 pixels with two workgroups on a CU).
 //
 // Pipeline.  256(M) x 128(N) tile, 8 waves of 64x64, K step = 32 channels of one tap.  The activation chunk (NPA KiB-chunks
 // per wave) is double buffered per 32-channel chunk; the weight tiles (8 KiB per step) go through a 3-slot ring; since
