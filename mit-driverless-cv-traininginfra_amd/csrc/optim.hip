@@ -97,8 +97,9 @@ int mdcv_graph_begin(void* stream) { return (int)hipStreamBeginCapture((hipStrea
 int mdcv_graph_end(void* stream, void** graph_exec) {
   hipGraph_t g; hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g); if (e != hipSuccess) return (int)e;
   hipGraphExec_t ge; e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-  hipGraphDestroy(g);
+  const hipError_t ed = hipGraphDestroy(g);               // the template graph is not needed once instantiated (or on failure)
   if (e != hipSuccess) return (int)e;
+  if (ed != hipSuccess) return (int)ed;
   *graph_exec = (void*)ge;
   return MDCV_OK;
 }
