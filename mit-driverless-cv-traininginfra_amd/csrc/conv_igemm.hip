@@ -23,7 +23,6 @@
 
 namespace {
 
-constexpr int ROWB = 80;  // LDS bytes per tile row of the wgrad kernel (64 payload + 16 pad)
 
 struct ConvArgs {
   const void* in; const void* w; void* out; const float* bias; const void* addsrc; float* stats;
@@ -1168,7 +1167,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(WgradArgs a, unsign
   const int prow = kq * 4 + (t >> 2);                       // pixel row of the first transpose read (second: +16)
   const int sub = (t & 1) * 8;                              // 8-byte half of the 16-byte column
   const int qlo = (t & 3) >> 1;                             // which 16-byte column of the fragment's pair
-  const int g0 = 2 * (prow & 7), g1 = g0;                   // swizzle of the two reads (same pixel & 7)
+  const int g0 = 2 * (prow & 7);                            // swizzle of the two reads (same pixel & 7)
   auto frag = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {
     const int row0 = ks * 32 + prow;
     const int c = 2 * F + qlo;
@@ -1496,7 +1495,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
   const int t = lane & 15, kq = lane >> 4;
   const int prow = kq * 4 + (t >> 2);                       // conflict-free K-slot <-> pixel-row mapping (see conv_wgrad_dma_kernel)
   const int sub = (t & 1) * 8, qlo = (t & 3) >> 1;
-  const int g0 = 2 * (prow & 7), g1 = g0;
+  const int g0 = 2 * (prow & 7);
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   auto fragB = [&](const unsigned char* tile, int ks, int F) -> bf16x8_t {
     const int row0 = ks * 32 + prow, c = 2 * F + qlo;

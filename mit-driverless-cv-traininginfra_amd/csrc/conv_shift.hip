@@ -29,10 +29,9 @@
 
 namespace {
 
-constexpr int BN = 128, WM = 4;     // waves: 4 (M) x WN (N), WN = 2 (8 waves, wave tile (BM/4) x 64) or 4 (16 waves, (BM/4) x 32)
-constexpr int BTILE = BN * 64;                            // one weight tile of the ring: 8 KiB
+constexpr int BN = 128, WM = 4;     // default tile width ; waves: 4 (M) x WN (N), WN = 2 (8 waves, wave tile (BM/4) x 64) or 4 (16 waves, (BM/4) x 32)
+// (per instantiation: BTILE = BN * 64 bytes per weight tile of the ring, SROW = BN * 2 + 16 bytes epilogue staging pitch)
 constexpr unsigned OOB = 0x80000000u;
-constexpr int SROW = BN * 2 + 16;                          // epilogue staging pitch (bf16)
 
 // 16-byte slot of logical k-vector q in a 64-byte tile row: q ^ swz(row).  ds_read_b128 is serviced in 16-lane groups that hold
 // rows i..i+3 and i+12..i+15 of one k-vector and rows i+4..i+11 of its neighbour (q^1); with swz = 2*((row>>2)&1) the four rows

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_shift_kernel(WgradShiftArgs a, u
   const int qlo = (t & 3) >> 1;
   auto frag = [&](const unsigned char* tile, int row0, int F) -> bf16x8_t {   // rows row0 .. row0+3 and row0+16 .. row0+19 of this lane group
     const int c = 2 * F + qlo;
-    const int g0 = 2 * (row0 & 7), g1 = g0;
+    const int g0 = 2 * (row0 & 7);
     const unsigned ad = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)tile + (unsigned)(row0 * 256 + ((c ^ g0) << 4) + sub);
     const s16x4_t lo = lds_tr16_asm<0>(ad);                    // asm reads: see conv_igemm.hip (no compiler-forced DMA drain)
     const s16x4_t hi = lds_tr16_asm<16 * 256>(ad);
