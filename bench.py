@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3        # MI355X fp32 MFMA (v_mfma_f32_16x16x4_f32: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz), the parity-mode kernels
 OPT_PIPELINE = os.environ.get("MDCV_OPT_PIPELINE", "0") == "1"   # FusedAdam(pipeline=True), see mdcv/optim.py: bit-identical, measured neutral -> off
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 YOLO_TRAIN_GFLOP_PER_IMG = 197.59   # SURVEY.md §8d (conv only, fwd+dgrad+wgrad, classes=80, 416^2; classes=1: 195.87)
@@ -102,32 +103,88 @@ def conv_flops(args):
 LAUNCH_DUMP = []
 
 
+def _es(dt):
+    return 2 if dt == 1 else 4
+
+
+def call_work(name, args):
+    """(algorithmic FLOPs, algorithmic HBM bytes) of one library call of a launch list (0 where not modelled).
+    Convolutions: 2*M*N*K of the problem the call is given (padded channels as the kernel sees them; a stride-2 data gradient counts
+    one MAC per (dy pixel, tap, ci, co)).  BatchNorm / activation passes: every operand tensor once."""
+    if name == "mdcv_conv2d":
+        return conv_flops(args), 0.0
+    if name == "mdcv_conv2d_dgrad_bnsums":
+        Bq, Hin, Win, Cin, Hout, Wout, Nout, KH, KW = args[8:17]
+        return 2.0 * Bq * Hin * Win * Cin * KH * KW * Nout, 0.0
+    if name == "conv2d_wgrad":               # info = (B, Hin, Win, Cin_pad, Hout, Wout, Cout_pad, k, stride, splits)
+        B, Hin, Win, Cin, Hout, Wout, Cout, k = args[:8]
+        return 2.0 * B * Hout * Wout * Cout * k * k * Cin, 0.0
+    if name == "mdcv_bn_act_fwd":            # (dt, y1, ld1, s1, b1, y2, ld2, s2, b2, resid, ldr, out, ldo, M, C, act, slope)
+        n = 2 + (args[5] is not None) + (args[9] is not None)
+        return 0.0, float(_es(args[0]) * args[13] * args[14] * n)
+    if name == "mdcv_bn_act_bwd_apply":      # (dt, dout, ldd, y1, ld1, s1, b1, cA, cB, cC, dy1, ldy1, y2, ld2, ..., dy2, ldy2, M, C, act, slope)
+        n = 3 + 2 * (args[12] is not None)
+        return 0.0, float(_es(args[0]) * args[-4] * args[-3] * n)
+    if name == "mdcv_bn_act_bwd_reduce_finalize":   # (dt, dout, ldd, y1, ld1, ..., y2 @11, ..., M @17, C @18, ...)
+        n = 2 + (args[11] is not None)
+        return 0.0, float(_es(args[0]) * args[17] * args[18] * n)
+    return 0.0, 0.0
+
+
+def _is_main_kernel(sym):
+    """the kernel of a multi-kernel call that does the call's algorithmic work (not a slab / partial-row reduction or finalize)"""
+    return not any(t in sym for t in ("reduce", "colfinal", "finalize"))
+
+
+def short_symbol(sym):
+    """`void (anonymous namespace)::conv_glds_kernel<...>((anonymous namespace)::ConvArgs, ...)` -> `conv_glds_kernel<...>`"""
+    s = sym.replace("(anonymous namespace)::", "")
+    if s.startswith("void "):
+        s = s[5:]
+    depth = 0
+    for i, ch in enumerate(s):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return s[:i]
+    return s
+
+
 def kernel_breakdown(model, plan, step_fn):
-    """One extra, untimed step with a HIP event after every launch (on the launch stream): per-kernel time and the
-    dominant kernel's achieved rate."""
+    """One extra, untimed, SERIAL step (weight gradients on the main stream too) with HIP events on the launch stream around every
+    library call and, inside the library, around every kernel (engine.run_timed(kernels=True)).
+    Returns (per-call {name: [calls, ms, flops]}, per-kernel {symbol: dict(launches, ms, flops, bytes)})."""
     from mdcv.engine import run_timed
-    rec = {}
+    rec, krec = {}, {}
 
     def add(lst):
-        for name, ms, args in lst:
+        for name, ms, args, kern in lst:
+            fl, by = call_work(name, args)
             r = rec.setdefault(name, [0, 0.0, 0.0])
             r[0] += 1
             r[1] += ms
+            r[2] += fl
+            main = [(k, t) for k, t in kern if _is_main_kernel(k)]
+            tmain = sum(t for _, t in main) or 1.0
+            for k, t in kern:
+                e = krec.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+                e["launches"] += 1
+                e["ms"] += t
+                if (k, t) in main:                     # a call's work goes to its main kernel(s), split by duration when there are several
+                    e["flops"] += fl * t / tmain       # (the four parity-class launches of a stride-2 data gradient)
+                    e["bytes"] += by * t / tmain
             if name == "mdcv_conv2d":
-                r[2] += conv_flops(args)
                 LAUNCH_DUMP.append((name, ms, [int(v) if isinstance(v, int) else 0 for v in args[11:23]] + [int(args[1])]))
             elif name == "mdcv_conv2d_dgrad_bnsums":      # data gradient with the producer's BatchNorm-backward sums in its store loop
-                Bq, Hin, Win, Cin, Hout, Wout, Nout, KH, KW = args[8:17]
-                r[2] += 2.0 * Bq * Hin * Win * Cin * KH * KW * Nout
                 LAUNCH_DUMP.append((name, ms, [int(v) for v in args[8:20]] + [1]))
             elif name == "conv2d_wgrad":
-                LAUNCH_DUMP.append((name, ms, list(args)))
+                LAUNCH_DUMP.append((name, ms, list(args), [(short_symbol(k), t) for k, t in kern]))
             elif name.startswith("mdcv_bn_act") or name in ("mdcv_partial_reduce",):
                 LAUNCH_DUMP.append((name, ms, [int(v) for v in args if isinstance(v, int) and 0 < v < (1 << 31)][-6:]))
     orig_run = plan.run
 
     def run_and_time(lst, stream=None):
-        add(run_timed(plan, lst, stream))
+        add(run_timed(plan, lst, stream, kernels=True))
     plan.run = run_and_time
     g = plan.use_graph
     plan.use_graph = False
@@ -137,11 +194,45 @@ def kernel_breakdown(model, plan, step_fn):
     finally:
         plan.run = orig_run
         plan.use_graph = g
-    return rec
+    return rec, krec
 
 
-def wgrad_flops_total(model):
-    return None
+def roofline_objects(krec, precision, traffic):
+    """`roofline` = the ONE kernel symbol with the largest share of the step's kernel time among the kernels whose algorithmic work
+    is modelled; `roofline_kernels` = every modelled kernel symbol (MFMA-bound convolutions / weight gradients in TFLOP/s, HBM-bound
+    BatchNorm passes in GB/s), largest total time first.  Durations are the in-library HIP-event brackets of the instrumented step."""
+    peak_f = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
+    rows = []
+    for sym, e in krec.items():
+        if e["launches"] == 0 or e["ms"] <= 0 or (e["flops"] == 0 and e["bytes"] == 0):
+            continue
+        mf = e["flops"] > 0
+        ach = (e["flops"] / (e["ms"] * 1e-3) / 1e12) if mf else (e["bytes"] / (e["ms"] * 1e-3) / 1e9)
+        peak = peak_f if mf else PEAK_HBM_GBS
+        row = {"kernel": short_symbol(sym), "symbol": sym, "bound": "mfma" if mf else "hbm", "launches": e["launches"],
+               "avg_us": 1e3 * e["ms"] / e["launches"], "total_ms": e["ms"], "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mf else "GB/s",
+               "frac": ach / peak, ("flops_per_launch" if mf else "bytes_per_launch"): (e["flops"] if mf else e["bytes"]) / e["launches"]}
+        t = (traffic or {}).get("kernels", {}).get(short_symbol(sym)) if traffic else None
+        row["traffic"] = (t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) if t else None
+        rows.append(row)
+    rows.sort(key=lambda r: -r["total_ms"])
+    top = dict(rows[0]) if rows else None
+    return top, rows
+
+
+def load_traffic():
+    """Newest profiles/rNN_pmc_hbm_traffic.json (scripts/profile_round.sh) -- only if it was measured with THIS tree's kernels."""
+    import glob
+    from mdcv._fingerprint import kernel_fingerprint
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic.json")))
+    if not files:
+        return None, "no profiles/rNN_pmc_hbm_traffic.json"
+    t = json.load(open(files[-1]))
+    fp = kernel_fingerprint()
+    if t.get("fingerprint") != fp:
+        return None, f"{os.path.basename(files[-1])} was measured with kernel fingerprint {t.get('fingerprint')}, this tree is {fp}: stale, not quoted"
+    t["_file"] = os.path.basename(files[-1])
+    return t, None
 
 
 CPU_THREADS = 16     # measured on the GPU box host (256 logical cores): torch-CPU conv training peaks at 16 threads for these
@@ -158,7 +249,7 @@ def cpu_baseline_yolo(cfg_path, workdir, budget_s=25.0):
         orc = yo.DarknetOracle(cfg_path, anchors=yo.VANILLA_ANCHORS, seed=0)
     finally:
         os.chdir(cwd)
-    B = 2
+    B = 4                                   # the CPU leg of the YOLOv3 step is batch 4
     g = torch.Generator().manual_seed(17)
     x = torch.rand(B, 3, 416, 416, generator=g)
     tg = synth_targets(B, 16, g)
@@ -166,7 +257,7 @@ def cpu_baseline_yolo(cfg_path, workdir, budget_s=25.0):
     opt = torch.optim.Adam(params, lr=1e-3)
     times = []
     t_start = time.perf_counter()
-    for it in range(4):
+    for it in range(3):
         t0 = time.perf_counter()
         opt.zero_grad()
         out = orc.forward(x, tg)
@@ -176,7 +267,7 @@ def cpu_baseline_yolo(cfg_path, workdir, budget_s=25.0):
         if time.perf_counter() - t_start > budget_s and it >= 1:
             break
     steady = times[1:] if len(times) > 1 else times
-    return {"value": B / (sum(steady) / len(steady)), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": B / (sum(steady) / len(steady)), "unit": "images/sec", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"YOLOv3 416^2 classes=80 fp32 CPU oracle, batch {B}, {len(steady)} timed train steps after 1 warm-up (Adam)"}
 
 
@@ -202,7 +293,7 @@ def cpu_baseline_rektnet(budget_s=12.0):
         if time.perf_counter() - t_start > budget_s and it >= 1:
             break
     steady = times[1:]
-    return {"value": B / (sum(steady) / len(steady)), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": B / (sum(steady) / len(steady)), "unit": "images/sec", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"RektNet 80^2 fp32 CPU oracle, batch {B}, {len(steady)} timed train steps after 1 warm-up (Adam, l1_softargmax+geo)"}
 
 
@@ -264,23 +355,40 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--dump-launches", default="")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-fp32", action="store_true", help="skip the same-precision-as-the-reference (fp32 kernels) YOLOv3 rate")
     a = ap.parse_args()
     global CPU_THREADS
     if a.cpu_threads:
         CPU_THREADS = a.cpu_threads
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the MDCV hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
-    dev_index = local % ndev                      # (MDCV_DIST_BACKEND=gloo lets several ranks share one GPU for testing)
+    backend = os.environ.get("MDCV_DIST_BACKEND", "nccl")      # "nccl" == RCCL on ROCm ; "gloo" lets several ranks share one GPU (tests)
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > ndev and backend == "nccl":
+        raise SystemExit(f"bench.py --gpus {a.gpus}: this node shows {ndev} GPU(s) and RCCL takes one rank per device; refusing to run "
+                         f"fewer ranks than asked for")
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:            # plain `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver's launcher would
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+                                      "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} was launched with WORLD_SIZE={world}: the launcher and the flag disagree")
+    dev_index = local % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MDCV_DIST_BACKEND", "nccl")      # "nccl" == RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -313,6 +421,7 @@ def main():
         net = net.to(device).train()
         opt = FusedAdam(net, lr=1e-3, pipeline=OPT_PIPELINE)      # update + re-pack run under the next forward's first layers
         red = GradAllReducer.attach(net, bucket_mb=32.0)       # RCCL all-reduce of finished buckets overlaps the rest of backward
+        red.timing = world > 1
         g = torch.Generator().manual_seed(1000 + rank)         # rank-seeded shard of the global batch
         B = a.yolo_batch
         x = torch.rand(B, 3, 416, 416, generator=g).to(device)
@@ -327,6 +436,8 @@ def main():
             return out
         dt = timed_region(yolo_step, a.steps, a.warmup, device, world)
         ips = B * world * a.steps / dt
+        comm = red.pop_comm_stats()                            # averaged over the warm-up and the timed steps
+        red.timing = False
         loss = float(yolo_step()[0])
         result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
         pcie = None
@@ -351,25 +462,52 @@ def main():
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             extra["yolo"]["replicas_in_sync"] = bool((hi - lo).abs().item() <= 1e-6 * max(1.0, abs(hi.item())))
+            extra["yolo"]["comm"] = dict(comm or {}, backend="rccl" if backend == "nccl" else backend, ranks=dist.get_world_size(),
+                                         gradient_bytes=int(net.flat_parameters()[1].numel() * 4), bucket_mb=32.0,
+                                         note="allreduce_busy_ms = time the comm stream spent inside all-reduce calls per step; exposed_comm_ms = how "
+                                              "long after the last compute kernel of backward the last bucket finished (rank 0, HIP events)")
         if not a.no_breakdown:        # every rank runs the instrumented step (it contains the collective); rank 0 reports
             plan = [p for p in net._plans.values() if p.has_bwd][0]
-            rec = kernel_breakdown(net, plan, yolo_step)
+            rec, krec = kernel_breakdown(net, plan, yolo_step)
             tot = sum(v[1] for v in rec.values())
-            conv = [a_ + b_ for a_, b_ in zip(rec.get("mdcv_conv2d", [0, 0.0, 0.0]), rec.get("mdcv_conv2d_dgrad_bnsums", [0, 0.0, 0.0]))]
             extra["yolo"]["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])}
             extra["yolo"]["kernel_launches_per_step"] = {k: v[0] for k, v in rec.items()}
             extra["yolo"]["sum_kernel_ms"] = round(tot, 3)
-            if conv[1] > 0:
-                ach = conv[2] / (conv[1] * 1e-3) / 1e12
-                traffic = None           # HBM bytes per mdcv_conv2d call from rocprofv3 PMC passes of this same command
-                tpath = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_yolo_v2.json")   # (scripts/pmc_traffic.sh; cannot be collected live)
-                if os.path.exists(tpath) and B == 32 and a.precision == "bf16":
-                    fam = json.load(open(tpath))["conv2d_family"]
-                    traffic = (fam["fetch_bytes_per_step"] + fam["write_bytes_per_step"]) / conv[0]
-                result["roofline"] = {"bound": "mfma", "kernel": "mdcv_conv2d family (mdcv_conv3x3_shift_kernel + conv_glds_kernel, bf16): every forward + data-gradient launch (data gradients carry the producer layer's BatchNorm-backward sums in their store loop; only conv FLOPs are counted)",
-                                      "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                                      "traffic": traffic, "launches": conv[0], "avg_launch_ms": conv[1] / conv[0],
-                                      "flops_per_launch_avg": conv[2] / conv[0]}
+            traffic, why = (load_traffic() if (B == 32 and a.precision == "bf16" and a.yolo_classes == 80) else (None, "non-default workload"))
+            top, rows = roofline_objects(krec, a.precision, traffic)
+            if top:
+                top["traffic_source"] = traffic["_file"] if traffic else None
+                if not traffic:
+                    top["traffic_reason"] = why
+                top["note"] = ("dominant kernel of the step by total time; achieved = algorithmic FLOPs of the launches dispatched to this symbol / their "
+                               "summed duration (HIP events around each kernel on its launch stream, one serial instrumented step)")
+                result["roofline"] = top
+                result["roofline_kernels"] = [{k: v for k, v in r.items() if k != "symbol"} for r in rows]
+        if world == 1 and a.precision == "bf16" and not a.no_fp32 and a.workload in ("both", "yolo"):
+            # the reference computes in fp32: the same step with the fp32 kernels (exact-f32 MFMA), reported beside the bf16 value
+            del opt
+            net._plans.clear()
+            torch.cuda.empty_cache()
+            cwd = os.getcwd()
+            os.chdir(tmp)
+            try:
+                torch.manual_seed(0)
+                net32 = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="fp32").to(device).train()
+            finally:
+                os.chdir(cwd)
+            opt32 = FusedAdam(net32, lr=1e-3)
+
+            def yolo_step32():
+                opt32.zero_grad()
+                out = net32(x, tg)
+                out[0].sum().backward()
+                opt32.step()
+            n32 = max(2, min(5, a.steps))
+            dt32 = timed_region(yolo_step32, n32, 2, device, 1)
+            extra["yolo"]["fp32_images_per_sec"] = B * n32 / dt32
+            extra["yolo"]["fp32_note"] = f"same step with precision='fp32' (fp32 storage, v_mfma_f32_16x16x4_f32), {n32} timed steps after 2 warm-up"
+            del net32, opt32
+            opt = None
         del net, opt
         torch.cuda.empty_cache()
 
@@ -401,10 +539,18 @@ def main():
                             "hbm_frac_step": ips * REKT_TRAIN_MB_PER_IMG / 1e3 / (PEAK_HBM_GBS * world)}
         if not a.no_breakdown:
             plan = [p for p in kp._plans.values() if p.has_bwd][0]
-            rec = kernel_breakdown(kp, plan, rekt_step)
+            rec, krec = kernel_breakdown(kp, plan, rekt_step)
             extra["rektnet"]["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])}
+            top, rows = roofline_objects(krec, a.precision, None)
+            extra["rektnet"]["roofline_kernels"] = [{k: v for k, v in r.items() if k != "symbol"} for r in rows]
+            if a.workload == "rektnet" and top:
+                top["traffic_source"] = None
+                result_roof = top
         if a.workload == "rektnet":
             result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
+            if not a.no_breakdown and top:
+                result["roofline"] = result_roof
+                result["roofline_kernels"] = extra["rektnet"]["roofline_kernels"]
 
     if a.workload in ("both", "postprocess"):
         # validate.py's per-image loop for one batch of eval outputs [B, 10647, 85] (416^2, 80 classes),
@@ -522,10 +668,9 @@ def main():
                        "parallelism": f"dp{world}", "hipgraph": bool(a.graph), "optimizer": "FusedAdam" + (" (pipelined under the next forward)" if OPT_PIPELINE else "")},
             "workloads": extra,
         }
-        if "roofline" in result:
-            line["roofline"] = result["roofline"]
-        else:
-            line["roofline"] = None
+        line["roofline"] = result.get("roofline")
+        line["roofline_kernels"] = result.get("roofline_kernels")
+        line["host_cores"] = os.cpu_count()
         if world == 1 and not a.no_cpu_baseline:
             cb = (cpu_baseline_yolo(cfg, tmp) if primary == "yolo" else cpu_baseline_rektnet() if primary == "rektnet"
                   else extra["postprocess"]["cpu_baseline"] if primary == "postprocess" else None)

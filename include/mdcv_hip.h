@@ -214,10 +214,28 @@ int mdcv_event_record(void* ev, void* stream);
 int mdcv_event_sync(void* ev);
 int mdcv_event_elapsed_ms(void* start, void* stop, float* ms);
 int mdcv_event_destroy(void* ev);
+/* In-library kernel profiler: between _begin and _stop EVERY kernel this library launches is bracketed by two HIP events recorded on
+ * the stream it is launched on.  _count = launches recorded so far (lets a host attribute them to its own calls); _stop ends recording,
+ * waits for the events and returns the record count; _read(i) -> duration in ms and the kernel symbol as rocprofv3 prints it.
+ * (bench.py's `roofline` / `roofline_kernels`; not meant for timed regions: each record costs two event records.) */
+int mdcv_profile_begin(void);
+int mdcv_profile_count(void);
+int mdcv_profile_stop(void);
+int mdcv_profile_read(int i, float* ms, char* name, int name_len);
 int mdcv_graph_begin(void* stream);
 int mdcv_graph_end(void* stream, void** graph_exec);
 int mdcv_graph_launch(void* graph_exec, void* stream);
 int mdcv_graph_destroy(void* graph_exec);
+
+/* ---- the one exchange step of the data-parallel path, for hosts that do not go through torch.distributed:
+ *      nn.DataParallel's gradient reduction (CVC-YOLOv3/train.py:193-195 with `losses[0].sum().backward()`, train.py:70) as an RCCL
+ *      all-reduce(SUM) of the flat fp32 gradient buffer over xGMI, one process per GPU.  librccl is bound at run time (dlopen by
+ *      soname, sharing the instance a host such as torch already loaded); -2 = librccl not found.  Return values > 0 are ncclResult_t.
+ *      id128: 128-byte ncclUniqueId made by rank 0 (mdcv_comm_unique_id) and handed to every rank by the host (file, socket, MPI...). */
+int mdcv_comm_unique_id(void* id128);
+int mdcv_comm_init(void** comm, int nranks, const void* id128, int rank);     /* on the calling thread's current HIP device */
+int mdcv_comm_allreduce_sum(void* comm, float* buf, long long n, void* stream);   /* in place, enqueue-only */
+int mdcv_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

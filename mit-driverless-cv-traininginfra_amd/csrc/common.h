@@ -12,6 +12,19 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #define MDCV_F32 0
 #define MDCV_BF16 1
 
+// Every kernel launch of the library goes through MDCV_LAUNCH: when the in-library
+// profiler is on (mdcv_profile_begin, runtime.hip) the launch is bracketed by two HIP events on its stream and remembered with the
+// kernel's host function, from which the symbol rocprofv3 prints is recovered.  Off: one predictable branch per launch.
+extern int mdcv_g_prof;
+void mdcv_prof_pre(hipStream_t st);
+void mdcv_prof_post(const void* fn, hipStream_t st);
+#define MDCV_LAUNCH(kern, grid, block, lds, st, ...)                                        \
+  do {                                                                                      \
+    if (mdcv_g_prof) mdcv_prof_pre(st);                                                     \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                            \
+    if (mdcv_g_prof) mdcv_prof_post(reinterpret_cast<const void*>(kern), st);               \
+  } while (0)
+
 #define MDCV_CHECK_LAUNCH()                                   \
   do {                                                        \
     hipError_t e__ = hipGetLastError();                       \

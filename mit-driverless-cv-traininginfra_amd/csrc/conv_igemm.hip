@@ -290,7 +290,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   a.tiles_n = cdiv(a.Nout, BN);
   a.tiles_total = cdiv(a.M, BM) * a.tiles_n;
   a.xcd_chunk = cdiv(a.tiles_total, 8);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(WM * WN * 64), LDS, st, a);
+  MDCV_LAUNCH(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(WM * WN * 64), LDS, st, a);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -763,7 +763,7 @@ int launch_conv_glds_f(const ConvArgs& a0, hipStream_t st, int B) {
   a.xcd_chunk = cdiv(a.tiles_total, 8);
   const unsigned in_bytes = (unsigned)((long long)B * a.Hin * a.Win * a.in_ldc * (long long)sizeof(T));
   const unsigned w_bytes = (unsigned)((long long)a.Nout * a.KH * a.KW * a.Cin * (long long)sizeof(T));
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(WM * WN * 64), LDS, st, a, in_bytes, w_bytes);
+  MDCV_LAUNCH(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(WM * WN * 64), LDS, st, a, in_bytes, w_bytes);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -1370,13 +1370,13 @@ static int launch_wgrad_reduce(const float* ws, float* dw_oihw, int splits, int 
                                int accumulate, hipStream_t st) {
   const int Ktot = KK * Cin_pad;
   if (Cout_real * cdiv(Cin_real, 64) < 128) {
-    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)cdiv(Ktot, 64), (unsigned)Cout_real), dim3(1024), 0, st, ws, dw_oihw, splits,
+    MDCV_LAUNCH(wgrad_reduce_flat_kernel, dim3((unsigned)cdiv(Ktot, 64), (unsigned)Cout_real), dim3(1024), 0, st, ws, dw_oihw, splits,
                        Cout_pad, Cin_real, Cin_pad, KK, Ktot, accumulate);
   } else {
     const dim3 rgrid((unsigned)Cout_real, (unsigned)cdiv(Cin_real, 64));
-    if (KK == 9) hipLaunchKernelGGL(wgrad_reduce_kk_kernel<9>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate);
-    else if (KK == 1) hipLaunchKernelGGL(wgrad_reduce_kk_kernel<1>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel, rgrid, dim3(256), KK * 65 * 4, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, KK, Ktot, accumulate);
+    if (KK == 9) MDCV_LAUNCH(wgrad_reduce_kk_kernel<9>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate);
+    else if (KK == 1) MDCV_LAUNCH(wgrad_reduce_kk_kernel<1>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate);
+    else MDCV_LAUNCH(wgrad_reduce_kernel, rgrid, dim3(256), KK * 65 * 4, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, KK, Ktot, accumulate);
   }
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -1590,7 +1590,7 @@ static int launch_wgrad_dma_t(const WgradArgs& a, unsigned grid, hipStream_t st,
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, a, dyb, xb);
+  MDCV_LAUNCH(kern, dim3(grid), dim3(256), LDS, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -1604,7 +1604,7 @@ static int launch_wgrad_narrow_t(const WgradArgs& a, unsigned grid, hipStream_t 
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, a, dyb, xb);
+  MDCV_LAUNCH(kern, dim3(grid), dim3(256), LDS, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -1970,8 +1970,8 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   if (use_dma) {
     const int rc = launch_wgrad_dma(a, grid, st, (unsigned)dyb, (unsigned)xb);
     if (rc) return rc;
-  } else if (dtype == MDCV_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(conv_wgrad_kernel<float>, dim3(grid), dim3(256), lds, st, a);
+  } else if (dtype == MDCV_BF16) MDCV_LAUNCH(conv_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(conv_wgrad_kernel<float>, dim3(grid), dim3(256), lds, st, a);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, KH * KW, accumulate, st);
@@ -1985,9 +1985,9 @@ int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad
   const unsigned grid = (unsigned)min(cdiv(n, 256), 8192);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MDCV_BF16)
-    hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w_oihw, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, Cout, Cin, KK, Cout_pad, Cin_pad);
+    MDCV_LAUNCH(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w_oihw, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, Cout, Cin, KK, Cout_pad, Cin_pad);
   else if (dtype == MDCV_F32)
-    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, st, w_oihw, (float*)w_fwd, (float*)w_dgrad, Cout, Cin, KK, Cout_pad, Cin_pad);
+    MDCV_LAUNCH(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, st, w_oihw, (float*)w_fwd, (float*)w_dgrad, Cout, Cin, KK, Cout_pad, Cin_pad);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -2008,8 +2008,8 @@ int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, int max
     if (e2 != hipSuccess) return (int)e2;
     lds_set = lds;
   }
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(64, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(64, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(pack_weights_batched_kernel<bf16_t>, dim3(64, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(pack_weights_batched_kernel<float>, dim3(64, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;

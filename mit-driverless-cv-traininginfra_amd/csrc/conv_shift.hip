@@ -426,7 +426,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
     if (e != hipSuccess) return (int)e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, in_bytes, w_bytes);
+  MDCV_LAUNCH(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, in_bytes, w_bytes);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -656,8 +656,8 @@ extern "C" {
 int mdcv_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int ldc, int Cpad, void* stream) {
   if (!src || !dst || (Cpad & 7) || (ldc & 7) || Cpad < C) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(ew_grid((long long)B * H * W * Cpad / 8)), dim3(256), 0, st, src, (bf16_t*)dst, B, C, H, W, ldc, Cpad);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_grid((long long)B * H * W * Cpad / 4)), dim3(256), 0, st, src, (float*)dst, B, C, H, W, ldc, Cpad);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(nchw_to_nhwc_kernel<bf16_t>, dim3(ew_grid((long long)B * H * W * Cpad / 8)), dim3(256), 0, st, src, (bf16_t*)dst, B, C, H, W, ldc, Cpad);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(nchw_to_nhwc_kernel<float>, dim3(ew_grid((long long)B * H * W * Cpad / 4)), dim3(256), 0, st, src, (float*)dst, B, C, H, W, ldc, Cpad);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -667,8 +667,8 @@ int mdcv_nhwc_to_nchw(int dtype, const void* src, int ldc, float* dst, int B, in
   if (!src || !dst) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
   const unsigned g = ew_grid((long long)B * C * H * W);
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)src, dst, B, C, H, W, ldc);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)src, dst, B, C, H, W, ldc);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(nhwc_to_nchw_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)src, dst, B, C, H, W, ldc);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(nhwc_to_nchw_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)src, dst, B, C, H, W, ldc);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -677,7 +677,7 @@ int mdcv_nhwc_to_nchw(int dtype, const void* src, int ldc, float* dst, int B, in
 int mdcv_partial_reduce(const float* partial, int rows, int nsums, int C, double* accum, void* stream) {
   if (!partial || !accum || rows < 1) return MDCV_EARG;
   const int cols = nsums * C;
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(cols, 64), (unsigned)cdiv(rows, 128)), dim3(256), 0, (hipStream_t)stream,
+  MDCV_LAUNCH(partial_reduce_kernel, dim3((unsigned)cdiv(cols, 64), (unsigned)cdiv(rows, 128)), dim3(256), 0, (hipStream_t)stream,
                      partial, rows, cols, accum);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -686,7 +686,7 @@ int mdcv_partial_reduce(const float* partial, int rows, int nsums, int C, double
 int mdcv_bn_finalize(double* accum, double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float momentum, float eps, float* scale, float* shift, float* mean, float* invstd, int C, void* stream) {
   if (!accum || !gamma || !beta || !scale || !shift || !mean || !invstd) return MDCV_EARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, accum, count, gamma, beta,
+  MDCV_LAUNCH(bn_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, accum, count, gamma, beta,
                      running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -705,14 +705,14 @@ int mdcv_bn_stats_finalize(const float* partial, int rows, double* accum, double
   ColFinArgs a = {};
   a.partial = partial; a.rows = rows; a.nsums = 2; a.C = C; a.count = count; a.gamma = gamma; a.beta = beta; a.rm = running_mean;
   a.rv = running_var; a.momentum = momentum; a.eps = eps; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
-  hipLaunchKernelGGL(bn_colfinal_kernel<0>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, a);
+  MDCV_LAUNCH(bn_colfinal_kernel<0>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, a);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
 
 int mdcv_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                         float* scale, float* shift, int C, void* stream) {
-  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean,
+  MDCV_LAUNCH(bn_eval_coeffs_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean,
                      running_var, eps, scale, shift, C);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -720,7 +720,7 @@ int mdcv_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 
 int mdcv_bn_eval_coeffs_bias(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                              const float* conv_bias, float* scale, float* shift, int C, void* stream) {
-  hipLaunchKernelGGL(bn_eval_coeffs_bias_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean,
+  MDCV_LAUNCH(bn_eval_coeffs_bias_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean,
                      running_var, eps, conv_bias, scale, shift, C);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -737,11 +737,11 @@ int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const f
   if (dtype == MDCV_BF16) {
     Strip s = make_strip<bf16_t>(M, C, 2048, 4); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
-    hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+    MDCV_LAUNCH(bn_act_fwd_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
     Strip s = make_strip<float>(M, C, 2048, 4); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
-    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+    MDCV_LAUNCH(bn_act_fwd_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -768,15 +768,15 @@ int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1,
   if (dtype == MDCV_BF16) {
     Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, a);
+    MDCV_LAUNCH(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
     Strip s = make_strip<float>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, a);
+    MDCV_LAUNCH(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, a);
   } else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   const int cols = nsums * C;
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)cdiv(cols, 64), (unsigned)cdiv(rows, 128)), dim3(256), 0, st, partial_ws, rows, cols, accum);
+  MDCV_LAUNCH(partial_reduce_kernel, dim3((unsigned)cdiv(cols, 64), (unsigned)cdiv(rows, 128)), dim3(256), 0, st, partial_ws, rows, cols, accum);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -784,7 +784,7 @@ int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1,
 int mdcv_bn_bwd_finalize(double* accum, int kx, int nsums, int zero_after, double count, const float* gamma, const float* mean,
                          const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cC, int C, void* stream) {
   if (!accum || !gamma || !dgamma || !dbeta || !cA || !cB || !cC) return MDCV_EARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, accum, kx, zero_after, count,
+  MDCV_LAUNCH(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, accum, kx, zero_after, count,
                      gamma, mean, invstd, dgamma, dbeta, cA, cB, cC, C, nsums);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -808,18 +808,18 @@ int mdcv_bn_act_bwd_reduce_finalize(int dtype, const void* dout, int ldd, const 
   if (dtype == MDCV_BF16) {
     Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, a);
+    MDCV_LAUNCH(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
     Strip s = make_strip<float>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, a);
+    MDCV_LAUNCH(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, a);
   } else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   ColFinArgs f = {};
   f.partial = partial_ws; f.rows = rows; f.nsums = nsums; f.C = C; f.count = count;
   f.g1 = gamma1; f.mean1 = mean1; f.is1 = invstd1; f.dg1 = dgamma1; f.db1 = dbeta1; f.cA1 = cA1; f.cB1 = cB1; f.cC1 = cC1;
   f.g2 = gamma2; f.mean2 = mean2; f.is2 = invstd2; f.dg2 = dgamma2; f.db2 = dbeta2; f.cA2 = cA2; f.cB2 = cB2; f.cC2 = cC2;
-  hipLaunchKernelGGL(bn_colfinal_kernel<1>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, f);
+  MDCV_LAUNCH(bn_colfinal_kernel<1>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, f);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -830,7 +830,7 @@ int mdcv_bn_bwd_finalize_rows(const float* partial, int rows, int C, double coun
   ColFinArgs f = {};
   f.partial = partial; f.rows = rows; f.nsums = 2; f.C = C; f.count = count;
   f.g1 = gamma; f.mean1 = mean; f.is1 = invstd; f.dg1 = dgamma; f.db1 = dbeta; f.cA1 = cA; f.cB1 = cB; f.cC1 = cC;
-  hipLaunchKernelGGL(bn_colfinal_kernel<3>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, f);
+  MDCV_LAUNCH(bn_colfinal_kernel<3>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, f);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -848,11 +848,11 @@ int mdcv_bn_act_bwd_apply(int dtype, const void* dout, int ldd, const void* y1, 
   if (dtype == MDCV_BF16) {
     Strip s = make_strip<bf16_t>(M, C, 2048, 4); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+    MDCV_LAUNCH(bn_act_bwd_apply_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
     Strip s = make_strip<float>(M, C, 2048, 4); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+    MDCV_LAUNCH(bn_act_bwd_apply_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -863,10 +863,10 @@ int mdcv_colsum(int dtype, const void* x, int ldc, int M, int C, double* accum, 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == MDCV_BF16) {
     Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, 1)); if (s.CV > 256) return MDCV_EARG;
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, (const bf16_t*)x, ldc, M, C, accum, s.PB, s.CV, s.PPI);
+    MDCV_LAUNCH(colsum_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, (const bf16_t*)x, ldc, M, C, accum, s.PB, s.CV, s.PPI);
   } else if (dtype == MDCV_F32) {
     Strip s = make_strip<float>(M, C, reduce_blocks(C, 1)); if (s.CV > 256) return MDCV_EARG;
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, (const float*)x, ldc, M, C, accum, s.PB, s.CV, s.PPI);
+    MDCV_LAUNCH(colsum_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, (const float*)x, ldc, M, C, accum, s.PB, s.CV, s.PPI);
   } else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -884,22 +884,22 @@ int mdcv_colsum_f32(int dtype, const void* x, int ldc, int M, int C, float* part
   if (dtype == MDCV_BF16) {
     Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, 1)); if (s.CV > 256) return MDCV_EARG;
     rows = cdiv(M, s.PB);
-    hipLaunchKernelGGL(colsum_rows_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)x, ldc, M, C, partial_ws, s.PB, s.CV, s.PPI);
+    MDCV_LAUNCH(colsum_rows_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16_t*)x, ldc, M, C, partial_ws, s.PB, s.CV, s.PPI);
   } else if (dtype == MDCV_F32) {
     Strip s = make_strip<float>(M, C, reduce_blocks(C, 1)); if (s.CV > 256) return MDCV_EARG;
     rows = cdiv(M, s.PB);
-    hipLaunchKernelGGL(colsum_rows_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)x, ldc, M, C, partial_ws, s.PB, s.CV, s.PPI);
+    MDCV_LAUNCH(colsum_rows_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)x, ldc, M, C, partial_ws, s.PB, s.CV, s.PPI);
   } else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   ColFinArgs f = {};
   f.partial = partial_ws; f.rows = rows; f.nsums = 1; f.C = C; f.count = 1.0; f.scale = out;
-  hipLaunchKernelGGL(bn_colfinal_kernel<2>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, f);
+  MDCV_LAUNCH(bn_colfinal_kernel<2>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, f);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
 
 int mdcv_accum_to_f32(double* accum, float* out, int n, int zero_after, void* stream) {
-  hipLaunchKernelGGL(accum_to_f32_kernel, dim3((unsigned)cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, accum, out, n, zero_after);
+  MDCV_LAUNCH(accum_to_f32_kernel, dim3((unsigned)cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, accum, out, n, zero_after);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -907,8 +907,8 @@ int mdcv_accum_to_f32(double* accum, float* out, int n, int zero_after, void* st
 int mdcv_upsample2x_fwd(int dtype, const void* in, int ldi, void* out, int ldo, int B, int H, int W, int C, void* stream) {
   if (!in || !out || (C & 7)) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(upsample2x_fwd_kernel<bf16_t>, dim3(ew_grid((long long)B * H * W * 4 * C / 8)), dim3(256), 0, st, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, B, H, W, C);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(ew_grid((long long)B * H * W * 4 * C / 4)), dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, B, H, W, C);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(upsample2x_fwd_kernel<bf16_t>, dim3(ew_grid((long long)B * H * W * 4 * C / 8)), dim3(256), 0, st, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, B, H, W, C);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(upsample2x_fwd_kernel<float>, dim3(ew_grid((long long)B * H * W * 4 * C / 4)), dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, B, H, W, C);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -917,8 +917,8 @@ int mdcv_upsample2x_fwd(int dtype, const void* in, int ldi, void* out, int ldo, 
 int mdcv_upsample2x_bwd(int dtype, const void* dout, int ldo, void* din, int ldi, int B, int H, int W, int C, void* stream) {
   if (!dout || !din || (C & 7)) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(ew_grid((long long)B * H * W * C / 8)), dim3(256), 0, st, (const bf16_t*)dout, ldo, (bf16_t*)din, ldi, B, H, W, C);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(ew_grid((long long)B * H * W * C / 4)), dim3(256), 0, st, (const float*)dout, ldo, (float*)din, ldi, B, H, W, C);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(upsample2x_bwd_kernel<bf16_t>, dim3(ew_grid((long long)B * H * W * C / 8)), dim3(256), 0, st, (const bf16_t*)dout, ldo, (bf16_t*)din, ldi, B, H, W, C);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(upsample2x_bwd_kernel<float>, dim3(ew_grid((long long)B * H * W * C / 4)), dim3(256), 0, st, (const float*)dout, ldo, (float*)din, ldi, B, H, W, C);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -929,8 +929,8 @@ int mdcv_maxpool2x2_fwd(int dtype, const void* in, int ldi, void* out, int ldo, 
   if (!in || !out || !idx || (C & 7) || (stride != 1 && stride != 2)) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * (stride == 2 ? H / 2 : H) * (stride == 2 ? W / 2 : W) * C;
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(maxpool2x2_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, idx, B, H, W, C, stride);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(maxpool2x2_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, idx, B, H, W, C, stride);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(maxpool2x2_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, idx, B, H, W, C, stride);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(maxpool2x2_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, idx, B, H, W, C, stride);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -941,8 +941,8 @@ int mdcv_maxpool2x2_bwd(int dtype, const void* dout, int ldo, const unsigned cha
   if (!dout || !din || !idx || (C & 7) || (stride != 1 && stride != 2)) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * H * W * C;
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(maxpool2x2_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)dout, ldo, idx, (bf16_t*)din, ldi, B, H, W, C, stride);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(maxpool2x2_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)dout, ldo, idx, (float*)din, ldi, B, H, W, C, stride);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(maxpool2x2_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)dout, ldo, idx, (bf16_t*)din, ldi, B, H, W, C, stride);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(maxpool2x2_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)dout, ldo, idx, (float*)din, ldi, B, H, W, C, stride);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;

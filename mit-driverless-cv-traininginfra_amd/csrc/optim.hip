@@ -56,7 +56,7 @@ int mdcv_adam_step(float* params, const float* grads, float* exp_avg, float* exp
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2 = 1.f - powf(beta2, (float)step);
   long long g = (n / 4 + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+  MDCV_LAUNCH(adam_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                      weight_decay, bc1, sqrtf(bc2), grad_scale);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -66,7 +66,7 @@ int mdcv_sgd_step(float* params, const float* grads, float* momentum_buf, long l
                   float grad_scale, void* stream) {
   if (!params || !grads || (momentum != 0.f && !momentum_buf) || step < 1) return MDCV_EARG;
   long long g = (n + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1;
-  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, n, lr, momentum, weight_decay,
+  MDCV_LAUNCH(sgd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, n, lr, momentum, weight_decay,
                      step == 1 ? 1 : 0, grad_scale);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;

@@ -75,7 +75,7 @@ int mdcv_crop_resize(const float* frames, int B, int C, int H, int W, const floa
       B > 65535)
     return MDCV_EARG;
   CropArgs a{frames, B, C, H, W, boxes, count, K, scale_x, scale_y, off_x, off_y, out_h, out_w, out, owner, total};
-  hipLaunchKernelGGL(crop_resize_kernel, dim3(K, B), dim3(256), 0, (hipStream_t)stream, a);
+  MDCV_LAUNCH(crop_resize_kernel, dim3(K, B), dim3(256), 0, (hipStream_t)stream, a);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -470,7 +470,7 @@ int mdcv_detect_post(const float* pred, int B, int N, int C, const float* target
   int* cnt = (int*)(keys + (size_t)B * N);
   hipError_t e = hipMemsetAsync(cnt, 0, (size_t)B * CNT_STRIDE * 4, st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(post_filter_kernel, dim3((N + FILTER_ROWS - 1) / FILTER_ROWS, B), dim3(256), 0, st, pred, B, N, 5 + C, conf_thres, keys, cnt);
+  MDCV_LAUNCH(post_filter_kernel, dim3((N + FILTER_ROWS - 1) / FILTER_ROWS, B), dim3(256), 0, st, pred, B, N, 5 + C, conf_thres, keys, cnt);
   MDCV_CHECK_LAUNCH();
   PostArgs a{};
   a.keys = keys; a.cnt = cnt; a.N = N; a.top_k = top_k; a.nms_thres = nms_thres;
@@ -478,7 +478,7 @@ int mdcv_detect_post(const float* pred, int B, int N, int C, const float* target
   a.targets = T > 0 ? targets : nullptr; a.T = T; a.iou_thres = iou_thres; a.width = width; a.height = height;
   a.out_boxes = out_boxes; a.out_prob = out_prob; a.out_cls = out_cls; a.out_index = out_index; a.out_correct = out_correct;
   a.out_count = out_count; a.out_stats = out_stats;
-  hipLaunchKernelGGL(post_image_kernel<true>, dim3(B), dim3(PB), 0, st, a);
+  MDCV_LAUNCH(post_image_kernel<true>, dim3(B), dim3(PB), 0, st, a);
   MDCV_CHECK_LAUNCH();
 #ifdef MDCV_POST_TS
   {
@@ -503,19 +503,19 @@ int mdcv_nms(const float* boxes, const float* scores, int n, float overlap, int 
   }
   unsigned long long* keys = (unsigned long long*)workspace;
   int* cnt = (int*)(keys + n);
-  hipLaunchKernelGGL(nms_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, scores, n, keys, cnt);
+  MDCV_LAUNCH(nms_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, scores, n, keys, cnt);
   MDCV_CHECK_LAUNCH();
   PostArgs a{};
   a.keys = keys; a.cnt = cnt; a.N = n; a.top_k = top_k; a.nms_thres = overlap; a.boxes = boxes;
   a.out_index = keep; a.out_count = count;
-  hipLaunchKernelGGL(post_image_kernel<false>, dim3(1), dim3(PB), 0, st, a);
+  MDCV_LAUNCH(post_image_kernel<false>, dim3(1), dim3(PB), 0, st, a);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
 
 int mdcv_average_precision(const unsigned char* tp, const float* conf, int m, int n_gt, float* out3, void* stream) {
   if (!tp || !conf || !out3 || m <= 0 || m > KMAX) return MDCV_EARG;
-  hipLaunchKernelGGL(average_precision_kernel, dim3(1), dim3(PB), 0, (hipStream_t)stream, tp, conf, m, n_gt, out3);
+  MDCV_LAUNCH(average_precision_kernel, dim3(1), dim3(PB), 0, (hipStream_t)stream, tp, conf, m, n_gt, out3);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -208,8 +208,8 @@ int mdcv_softargmax_fwd(int dtype, const void* logits, int ldc, int B, int K, in
   if (!logits || !hm || !pts || H * W * 4 > 64 * 1024) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
   const unsigned lds = (unsigned)(H * W * 4);
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(softargmax_fwd_kernel<bf16_t>, dim3((unsigned)(B * K)), dim3(256), lds, st, (const bf16_t*)logits, ldc, K, H, W, hm, pts);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(softargmax_fwd_kernel<float>, dim3((unsigned)(B * K)), dim3(256), lds, st, (const float*)logits, ldc, K, H, W, hm, pts);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(softargmax_fwd_kernel<bf16_t>, dim3((unsigned)(B * K)), dim3(256), lds, st, (const bf16_t*)logits, ldc, K, H, W, hm, pts);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(softargmax_fwd_kernel<float>, dim3((unsigned)(B * K)), dim3(256), lds, st, (const float*)logits, ldc, K, H, W, hm, pts);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -222,12 +222,12 @@ int mdcv_softargmax_bwd(int dtype, const float* hm, const float* pts, const floa
   hipStream_t st = (hipStream_t)stream;
   if (dhm) {
     if (!sdot_ws) return MDCV_EARG;
-    hipLaunchKernelGGL(softmax_dot_kernel, dim3((unsigned)(B * K)), dim3(256), 0, st, hm, dhm, H * W, sdot_ws);
+    MDCV_LAUNCH(softmax_dot_kernel, dim3((unsigned)(B * K)), dim3(256), 0, st, hm, dhm, H * W, sdot_ws);
     MDCV_CHECK_LAUNCH();
   }
   const unsigned grid = (unsigned)cdiv((long long)B * H * W, 256);
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL((softargmax_bwd_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, hm, pts, dpts, dhm, sdot_ws, B, K, H, W, (bf16_t*)dlogits, ldd);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL((softargmax_bwd_kernel<float, 8>), dim3(grid), dim3(256), 0, st, hm, pts, dpts, dhm, sdot_ws, B, K, H, W, (float*)dlogits, ldd);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH((softargmax_bwd_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, st, hm, pts, dpts, dhm, sdot_ws, B, K, H, W, (bf16_t*)dlogits, ldd);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH((softargmax_bwd_kernel<float, 8>), dim3(grid), dim3(256), 0, st, hm, pts, dpts, dhm, sdot_ws, B, K, H, W, (float*)dlogits, ldd);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -244,10 +244,10 @@ int mdcv_cross_ratio_loss(const float* hm, const float* pts, const float* thm, c
   if (loss_type == 1) {
     if (!hm || !thm) return MDCV_EARG;
     const long long n = (long long)B * 7 * H * W;
-    hipLaunchKernelGGL(hm_l2_kernel, dim3((unsigned)min(cdiv(n, 1024), 2048)), dim3(256), 0, st, hm, thm, n, 1.f / (float)B, gscale, dhm, acc_ws);
+    MDCV_LAUNCH(hm_l2_kernel, dim3((unsigned)min(cdiv(n, 1024), 2048)), dim3(256), 0, st, hm, thm, n, 1.f / (float)B, gscale, dhm, acc_ws);
     MDCV_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(cross_ratio_kernel, dim3(1), dim3(256), 0, st, pts, tpts, B, loss_type, include_geo, gamma_horz, gamma_vert, acc_ws, gscale, out3, dpts);
+  MDCV_LAUNCH(cross_ratio_kernel, dim3(1), dim3(256), 0, st, pts, tpts, B, loss_type, include_geo, gamma_horz, gamma_vert, acc_ws, gscale, out3, dpts);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -163,16 +163,16 @@ extern "C" {
 int mdcv_synth_cone_batch(unsigned seed, int step, int B, int T, int H, int W, int num_classes, float* images, float* targets, void* stream) {
   if (!images || !targets || B <= 0 || T <= 0 || H <= 0 || W <= 0 || num_classes <= 0 || B > 65535) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(synth_targets_kernel, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, st, seed, step, B, T, num_classes, targets);
+  MDCV_LAUNCH(synth_targets_kernel, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, st, seed, step, B, T, num_classes, targets);
   MDCV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(synth_images_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)B), dim3(256), 0, st, seed, step, B, T, H, W, targets, images);
+  MDCV_LAUNCH(synth_images_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)B), dim3(256), 0, st, seed, step, B, T, H, W, targets, images);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
 
 int mdcv_synth_crop_batch(unsigned seed, int step, int B, int size, float* images, float* heatmaps, float* points, void* stream) {
   if (!images || !heatmaps || !points || B <= 0 || size != 80) return MDCV_EARG;       // ConeDataset's target size (train_eval.py default)
-  hipLaunchKernelGGL(synth_crops_kernel<80>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, seed, step, B, images, heatmaps, points);
+  MDCV_LAUNCH(synth_crops_kernel<80>, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, seed, step, B, images, heatmaps, points);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -273,7 +273,7 @@ int mdcv_wgrad_shift(const void* dy, int dy_ldc, const void* x, int x_ldc, float
     attr_set = true;
   }
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
-  hipLaunchKernelGGL(wgrad3x3_shift_kernel, dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
+  MDCV_LAUNCH(wgrad3x3_shift_kernel, dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -479,7 +479,7 @@ int launch_stream(const WgradStreamArgs& a, int lds, unsigned dyb, unsigned xb, 
     if (e != hipSuccess) return (int)e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
+  MDCV_LAUNCH((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -608,7 +608,7 @@ int mdcv_wgrad_stem(const void* dy, int dy_ldc, const void* x, int x_ldc, float*
     attr_lds = lds;
   }
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
-  hipLaunchKernelGGL(wgrad7x7_stream_kernel, dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
+  MDCV_LAUNCH(wgrad7x7_stream_kernel, dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -258,20 +258,20 @@ int mdcv_yolo_head_train(int dtype, const void* logits, int ldc, void* dlogits, 
   double* acc = (double*)((int*)workspace + ints);
   hipError_t e = hipMemsetAsync(owner, 0xff, cells * 4, st); if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(ignore, 0, ((long long)Gh * Gw + 2) * 4 + (ints - (cells + (long long)Gh * Gw + 2)) * 4 + 64, st); if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(yolo_assign_kernel, dim3(grid_for((long long)B * T)), dim3(256), 0, st, targets, anchors_scaled, g, owner, ignore, (int*)nullptr, err);
+  MDCV_LAUNCH(yolo_assign_kernel, dim3(grid_for((long long)B * T)), dim3(256), 0, st, targets, anchors_scaled, g, owner, ignore, (int*)nullptr, err);
   MDCV_CHECK_LAUNCH();
   LossArgs la{logits, targets, anchors_scaled, owner, ignore, acc, g};
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(yolo_loss_kernel<bf16_t>, dim3(grid_for(cells)), dim3(256), 0, st, la);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(yolo_loss_kernel<float>, dim3(grid_for(cells)), dim3(256), 0, st, la);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(yolo_loss_kernel<bf16_t>, dim3(grid_for(cells)), dim3(256), 0, st, la);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(yolo_loss_kernel<float>, dim3(grid_for(cells)), dim3(256), 0, st, la);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(yolo_finalize_kernel, dim3(1), dim3(64), 0, st, acc, xy_loss, wh_loss, obj_loss, noobj_loss, out7);
+  MDCV_LAUNCH(yolo_finalize_kernel, dim3(1), dim3(64), 0, st, acc, xy_loss, wh_loss, obj_loss, noobj_loss, out7);
   MDCV_CHECK_LAUNCH();
   if (dlogits) {
     GradArgs ga{logits, dlogits, targets, anchors_scaled, owner, ignore, acc, gscale, g, ldd, Cpad, xy_loss, wh_loss, obj_loss, noobj_loss};
     const long long total = (long long)B * Gh * Gw * Cpad;
-    if (dtype == MDCV_BF16) hipLaunchKernelGGL(yolo_grad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, ga);
-    else hipLaunchKernelGGL(yolo_grad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, ga);
+    if (dtype == MDCV_BF16) MDCV_LAUNCH(yolo_grad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, ga);
+    else MDCV_LAUNCH(yolo_grad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, ga);
     MDCV_CHECK_LAUNCH();
   }
   return MDCV_OK;
@@ -291,8 +291,8 @@ int mdcv_yolo_head_grad(int dtype, const void* logits, int ldc, void* dlogits, i
   double* acc = (double*)((int*)workspace + ints);
   GradArgs ga{logits, dlogits, targets, anchors_scaled, owner, ignore, acc, gscale, g, ldd, Cpad, xy_loss, wh_loss, obj_loss, noobj_loss};
   const long long total = (long long)B * Gh * Gw * Cpad;
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(yolo_grad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, ga);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(yolo_grad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, ga);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(yolo_grad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, ga);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(yolo_grad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, ga);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -303,8 +303,8 @@ int mdcv_yolo_head_decode(int dtype, const void* logits, int ldc, const float* a
   if (!logits || !anchors_scaled || !out) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
   const long long total = (long long)B * A * Gh * Gw * (5 + C);
-  if (dtype == MDCV_BF16) hipLaunchKernelGGL(yolo_decode_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)logits, ldc, anchors_scaled, stride, B, A, C, Gh, Gw, out, rows_total, row_off);
-  else if (dtype == MDCV_F32) hipLaunchKernelGGL(yolo_decode_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)logits, ldc, anchors_scaled, stride, B, A, C, Gh, Gw, out, rows_total, row_off);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(yolo_decode_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)logits, ldc, anchors_scaled, stride, B, A, C, Gh, Gw, out, rows_total, row_off);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(yolo_decode_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)logits, ldc, anchors_scaled, stride, B, A, C, Gh, Gw, out, rows_total, row_off);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -326,11 +326,11 @@ int mdcv_build_targets(const float* targets, const float* anchors, int B, int T,
   hipError_t e = hipMemsetAsync(owner, 0xff, cells * 4, st); if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(ignore, 0, ((long long)Gh * Gw + 2) * 4, st); if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(tcls, 0, cells * C, st); if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(yolo_assign_kernel, dim3(grid_for((long long)B * T)), dim3(256), 0, st, targets, anchors, g, owner, ignore, rowinfo, err);
+  MDCV_LAUNCH(yolo_assign_kernel, dim3(grid_for((long long)B * T)), dim3(256), 0, st, targets, anchors, g, owner, ignore, rowinfo, err);
   MDCV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bt_dense_kernel, dim3(grid_for(cells)), dim3(256), 0, st, targets, anchors, g, owner, ignore, mask, conf_mask, tx, ty, tw, th, tconf);
+  MDCV_LAUNCH(bt_dense_kernel, dim3(grid_for(cells)), dim3(256), 0, st, targets, anchors, g, owner, ignore, mask, conf_mask, tx, ty, tw, th, tconf);
   MDCV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bt_tcls_kernel, dim3(grid_for((long long)B * T)), dim3(256), 0, st, targets, g, rowinfo, tcls);
+  MDCV_LAUNCH(bt_tcls_kernel, dim3(grid_for((long long)B * T)), dim3(256), 0, st, targets, g, rowinfo, tcls);
   MDCV_CHECK_LAUNCH();
   if (err_out) { e = hipMemcpyAsync(err_out, err, 4, hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return (int)e; }
   return MDCV_OK;

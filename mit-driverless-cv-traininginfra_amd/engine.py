@@ -475,7 +475,7 @@ class Plan:
             owner = plan.owner
             if plan._packed_ahead:                       # the optimizer packed every layer behind its update (optim.py, pipeline=True);
                 plan._packed_ahead = False               # the per-group waits further down this list order the forward behind it
-                if owner is None or owner._pflat._version == plan._packed_version:
+                if owner is None or getattr(owner, "_param_epoch", 0) == plan._packed_version:
                     return 0
             if owner is not None:
                 owner._param_sync()
@@ -558,8 +558,10 @@ class Plan:
         return ge
 
 
-def run_timed(plan, lst, stream=None):
-    """Run a launch list with a HIP event after every op (on the launch stream).  Returns [(name, ms, args)]."""
+def run_timed(plan, lst, stream=None, kernels=False):
+    """Run a launch list with a HIP event after every op (on the launch stream).  Returns [(name, ms, args)]; with
+    kernels=True each entry gets a fourth element, [(kernel symbol as rocprofv3 prints it, ms)] for every kernel the library
+    launched inside that op, each bracketed by its own pair of HIP events on the launch stream (mdcv_profile_*, csrc/runtime.hip)."""
     import ctypes
     L = plan.L
     if stream is None:
@@ -569,18 +571,36 @@ def run_timed(plan, lst, stream=None):
         e = ctypes.c_void_p()
         L.check(L.event_create(ctypes.byref(e)), "event_create")
         evs.append(e)
+    spans = []
+    if kernels:
+        L.check(L.profile_begin(), "profile_begin")
     L.check(L.event_record(evs[0], stream))
-    for i, (fn, args) in enumerate(lst):
-        rc = fn(*args, stream)
-        if rc:
-            raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
-        L.check(L.event_record(evs[i + 1], stream))
+    try:
+        for i, (fn, args) in enumerate(lst):
+            n0 = L.profile_count() if kernels else 0
+            rc = fn(*args, stream)
+            if rc:
+                raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
+            spans.append((n0, L.profile_count() if kernels else 0))
+            L.check(L.event_record(evs[i + 1], stream))
+    finally:
+        nrec = L.profile_stop() if kernels else 0
     L.check(L.event_sync(evs[-1]))
+    krec = []
+    if kernels:
+        if nrec < 0:
+            raise _lib.MdcvError(f"mdcv_profile_stop failed ({nrec})")
+        buf = ctypes.create_string_buffer(1024)
+        for i in range(nrec):
+            ms = ctypes.c_float()
+            L.check(L.profile_read(i, ctypes.byref(ms), buf, 1024), "profile_read")
+            krec.append((buf.value.decode(), ms.value))
     out = []
     for i, (fn, args) in enumerate(lst):
         ms = ctypes.c_float()
         L.check(L.event_elapsed_ms(evs[i], evs[i + 1], ctypes.byref(ms)))
-        out.append((getattr(fn, "__name__", str(fn)), ms.value, args if args else getattr(fn, "info", ())))
+        ent = (getattr(fn, "__name__", str(fn)), ms.value, args if args else getattr(fn, "info", ()))
+        out.append(ent + (krec[spans[i][0]:spans[i][1]],) if kernels else ent)
     for e in evs:
         L.event_destroy(e)
     return out

@@ -100,7 +100,8 @@ class FusedAdam(_FlatOptimizer):
             else:
                 plan._pending_updates[k] = fn                # the rest from the forward list, two groups ahead of their use
         plan._packed_ahead = True
-        plan._packed_version = pflat._version
+        model._params_changed()                                     # every other plan's packed operands are stale from here on
+        plan._packed_version = model._param_epoch                   # (load_weights / load_state_dict bump the epoch too: this pack is then redone)
         model._pipe_plan = plan
 
     @torch.no_grad()

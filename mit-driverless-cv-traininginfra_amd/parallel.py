@@ -36,6 +36,9 @@ class GradAllReducer:
         self._overlap = False
         self.extra_streams = []                   # compute-side streams besides the current one (the plans' wgrad stream)
         self.log = []
+        self.timing = False                       # record HIP events around every bucket (bench.py: all-reduce ms / exposed ms per step)
+        self._ev_steps = []                       # per step: ([(start, end) per bucket on the comm stream], backward-end event on the compute stream)
+        self._ev_cur = None
 
     # ---------------------------------------------------------------- plain use
     def buckets(self, flat):
@@ -85,6 +88,7 @@ class GradAllReducer:
         self._overlap = overlap and self._active()
         self._pending_hi = flat.numel()                 # buckets are cut from the END of the buffer (last layers finish first)
         self.log = []
+        self._ev_cur = [] if (self.timing and flat.is_cuda and self._active()) else None
         if self._active() and flat.is_cuda and self._stream is None:
             self._stream = torch.cuda.Stream(device=flat.device)
 
@@ -100,7 +104,14 @@ class GradAllReducer:
             for extra in self.extra_streams:
                 self._stream.wait_stream(extra)
             with torch.cuda.stream(self._stream):
-                self._reduce(seg)
+                if self._ev_cur is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self._stream)
+                    self._reduce(seg)
+                    e1.record(self._stream)
+                    self._ev_cur.append((e0, e1))
+                else:
+                    self._reduce(seg)
         else:
             self._reduce(seg)
         self._pending_hi = lo
@@ -115,6 +126,11 @@ class GradAllReducer:
         if not self._active():
             return
         self._fire(0)                                    # whatever is left (all of it when overlap is off)
+        if self._ev_cur:
+            done = torch.cuda.Event(enable_timing=True)      # every compute kernel of this backward is in front of this point
+            done.record(torch.cuda.current_stream())
+            self._ev_steps.append((self._ev_cur, done))
+            self._ev_cur = None
 
     def finish(self):
         """Order the compute stream behind the exchange (call before optimizer.step())."""
@@ -127,6 +143,24 @@ class GradAllReducer:
             torch.cuda.current_stream().wait_stream(self._stream)
         elif self.average:
             self._flat.div_(dist.get_world_size(self.group) if dist.is_initialized() else 1)
+
+
+    def pop_comm_stats(self):
+        """Averages over the steps recorded since the last call (timing=True): time the comm stream spent inside all-reduce
+        calls per step, the span first-bucket-start .. last-bucket-end, and the EXPOSED part — how long after the last compute
+        kernel of backward the last bucket finished, i.e. what `finish()` makes the optimizer step wait for."""
+        steps, self._ev_steps = self._ev_steps, []
+        if not steps:
+            return None
+        torch.cuda.synchronize()
+        busy = span = exposed = 0.0
+        for pairs, done in steps:
+            busy += sum(a.elapsed_time(b) for a, b in pairs)
+            span += pairs[0][0].elapsed_time(pairs[-1][1])
+            exposed += max(0.0, done.elapsed_time(pairs[-1][1]))
+        n = len(steps)
+        return {"steps": n, "buckets_per_step": len(steps[0][0]), "allreduce_busy_ms": busy / n, "allreduce_span_ms": span / n,
+                "exposed_comm_ms": exposed / n}
 
 
 def shard_batch(t, rank, world):

@@ -70,6 +70,10 @@ class CrossRatioLoss(nn.Module):
         if self.loss_type not in _TYPES:
             print("Did not recognize loss function selection!")
             raise NameError("name 'sys' is not defined")       # what the reference does here (cross_ratio_loss.py:31-32)
+        if tuple(points.shape[1:]) != (7, 2) or tuple(target_points.shape) != tuple(points.shape):
+            # the kernel's row stride is 14 floats and the geometric terms use key points 0..6 (cross_ratio_loss.py:36-57 hard-codes them too)
+            raise ValueError(f"CrossRatioLoss (HIP) takes points / target_points of shape [B, 7, 2]; got {tuple(points.shape)} and "
+                             f"{tuple(target_points.shape)}")
         _lib.require_gpu(points)
         out3 = _CrossRatioFn.apply(self, heatmap, points, target_hm, target_points)
         location_loss, total = out3[0], out3[2]

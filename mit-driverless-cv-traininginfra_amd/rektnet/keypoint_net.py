@@ -17,8 +17,8 @@ import torch.nn as nn
 
 from .. import _lib
 from ..engine import TNode, ConvSpec, BnSpec, parse_precision, ACT_RELU, BF16
-from ..yolo.models import _NetPlan, FlatParamsMixin, _bump_counters
-from .resnet import ResNet
+from ..yolo.models import _NetPlan, FlatParamsMixin, _bump_counters, _sync_before_state_dict
+from .resnet import ResNet, lower_conv_bn, lower_block, lower_block_bwd
 
 
 class _KeypointFn(torch.autograd.Function):
@@ -75,7 +75,16 @@ class KeypointNet(nn.Module, FlatParamsMixin):
         self.precision = parse_precision(precision if precision is not None else os.environ.get("MDCV_PRECISION", "bf16"))
         self.use_graph = os.environ.get("MDCV_GRAPH", "0") == "1"
         self._plans = {}
-        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._param_sync())   # a pipelined optimizer step may be in flight
+        self.register_state_dict_pre_hook(_sync_before_state_dict)   # a pipelined optimizer step may be in flight
+
+    def __getstate__(self):
+        return self._state_without_plans()
+
+    def load_state_dict(self, *args, **kw):
+        self._param_sync()
+        out = super().load_state_dict(*args, **kw)
+        self._params_changed()
+        return out
 
     def _initialize_weights(self):
         """kaiming-normal (fan_out, relu) conv weights, zero biases, BN weight 1 / bias 0 (reference :33-44)."""
@@ -100,10 +109,12 @@ class KeypointNet(nn.Module, FlatParamsMixin):
             raise ValueError(f"KeypointNet was built for image_size={self.image_size}, got {(H, W)}")
         infer = not self.training and not torch.is_grad_enabled() and not self.onnx_mode      # no backward can follow: one-launch conv+BN+ReLU
         key = (B, H, W, self.training, self.onnx_mode, self.precision, x.device.index, infer)
-        plan = self._plans.get(key)
+        plan = self._plan_lookup(key)
         if plan is None:
             plan = self._build_plan(x.device, B, H, W, self.training, self.onnx_mode, infer=infer)
-            self._plans[key] = plan
+            self._plan_store(key, plan)
+        if getattr(self, "_pipe_plan", None) is not None and plan is not self._pipe_plan:
+            self._param_sync()               # deferred group updates of a pipelined optimizer step are only released from ITS plan's forward list
         if self.onnx_mode:
             plan.run_forward(x)
             return plan.logits_nchw.clone()
@@ -116,6 +127,7 @@ class KeypointNet(nn.Module, FlatParamsMixin):
 
     def _build_plan(self, device, B, H, W, bn_train, logits_only, infer=False):
         plan = _KpPlan(device, self.precision, bn_train, grad_sink=self._grad_view)
+        plan.owner = self
         plan.grad_offset = lambda p: self._goff[id(p)][0]
         plan.use_graph = self.use_graph
         plan.graphs_bwd = {}
@@ -144,24 +156,7 @@ class KeypointNet(nn.Module, FlatParamsMixin):
         one_launch = infer and os.environ.get("MDCV_EVAL_FUSE", "1") == "1"
 
         def conv_bn(conv, bn, xnode, relu_into=None):
-            """relu_into: the activation buffer of a conv -> BN -> ReLU chain; in inference plans the three run as one launch."""
-            cs = ConvSpec(plan, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0], cin_pad=xnode.act.C)
-            plan.emit_pack(cs, need_dgrad=xnode.needs_grad)
-            bs = BnSpec(plan, bn)
-            if one_launch and relu_into is not None:
-                plan.emit_conv_bn_act_eval(cs, bs, xnode.act, relu_into, ACT_RELU, 0.0)
-                return cs, bs, None
-            y = plan.new_act(B, H, W, conv.out_channels)
-            if bn_train:
-                rows = plan.stats_rows(cs, xnode.act, y)
-                partial = plan.f32(rows * 2 * y.C, zero=False)
-                plan.emit_conv_fwd(cs, xnode.act, y, partial)
-                plan.emit_bn_stats(bs, y, partial, rows)
-                nbt.append(bn.num_batches_tracked)
-            else:
-                plan.emit_conv_fwd(cs, xnode.act, y)
-                plan.emit_bn_eval(bs)
-            return cs, bs, y
+            return lower_conv_bn(plan, conv, bn, xnode, B, H, W, bn_train, nbt, one_launch, relu_into=relu_into)
 
         a = TNode(plan.new_act(B, H, W, 16), name="stem")
         cs0, bs0, y0 = conv_bn(self.conv, self.bn, xin, relu_into=a.act)
@@ -169,17 +164,8 @@ class KeypointNet(nn.Module, FlatParamsMixin):
             plan.emit_bn_act_fwd(y0, bs0, a.act, ACT_RELU, 0.0)
         recs.append(("stem", cs0, bs0, xin, y0, a))
         for blk in (self.res1, self.res2, self.res3, self.res4):
-            x = a
-            mid = TNode(plan.new_act(B, H, W, blk.conv1.out_channels), name="mid")
-            cs1, bs1, y1 = conv_bn(blk.conv1, blk.bn1, x, relu_into=mid.act)
-            if y1 is not None:
-                plan.emit_bn_act_fwd(y1, bs1, mid.act, ACT_RELU, 0.0)
-            cs2, bs2, y2 = conv_bn(blk.conv2, blk.bn2, mid)
-            css, bss, ys = conv_bn(blk.shortcut_conv, blk.shortcut_bn, x)
-            out = TNode(plan.new_act(B, H, W, blk.conv2.out_channels), name="blk")
-            plan.emit_bn_act_fwd(y2, bs2, out.act, ACT_RELU, 0.0, y2=ys, bs2=bss)
-            recs.append(("block", x, cs1, bs1, y1, mid, cs2, bs2, y2, css, bss, ys, out))
-            a = out
+            rec, a = lower_block(plan, blk, a, B, H, W, bn_train, nbt, one_launch)
+            recs.append(rec)
         csh = ConvSpec(plan, self.out.weight, self.out.bias, 1, 0, 1, cin_pad=a.act.C)
         plan.emit_pack(csh, need_dgrad=True)
         lg = TNode(plan.new_act(B, H, W, K), name="logits")
@@ -215,14 +201,7 @@ class KeypointNet(nn.Module, FlatParamsMixin):
         for r in reversed(recs):
             plan.mark_ready()
             if r[0] == "block":
-                _, x, cs1, bs1, y1, mid, cs2, bs2, y2, css, bss, ys, out = r
-                dy2, dys = plan.emit_bn_act_bwd(out.grad, y2, bs2, ACT_RELU, 0.0, y2=ys, bs2=bss)
-                plan.emit_conv_bwd(cs2, mid, y2, dy2)
-                plan.emit_conv_bwd(css, x, ys, dys)
-                dy1 = plan.emit_bn_act_bwd(mid.grad, y1, bs1, ACT_RELU, 0.0)
-                plan.emit_conv_bwd(cs1, x, y1, dy1)
-                for cs in (cs1, cs2, css):
-                    plan.emit_bias_grad(cs, None, zero_only=True)
+                lower_block_bwd(plan, r)
             else:
                 _, cs0, bs0, xin_, y0, a0 = r
                 dy0 = plan.emit_bn_act_bwd(a0.grad, y0, bs0, ACT_RELU, 0.0)

@@ -125,6 +125,8 @@ class _YoloHeadFn(torch.autograd.Function):
                float(layer.object_loss), float(layer.no_object_loss))
         L.check(L.yolo_head_train(_lib.F32, lg.data_ptr(), cp, None, 0, cp, tg.data_ptr(), anchors.data_ptr(), *geo, ws.data_ptr(),
                                   out7.data_ptr(), None, st), "yolo_head_train")
+        if _CHECK_TARGETS and int(_head_err_view(ws, B, A, Gh, Gw).item()):
+            raise IndexError(_BAD_TARGET_MSG)
         ctx.saved = (lg, tg, anchors, ws, geo, cp, ch)
         return out7
 
@@ -203,15 +205,42 @@ class _DarknetTrainFn(torch.autograd.Function):
         return (None, None, None, None) + (None,) * len(model._plist)
 
 
+_CHECK_TARGETS = os.environ.get("MDCV_CHECK_TARGETS", "1") == "1"
+_BAD_TARGET_MSG = ("index out of range in build_targets: a target has cx >= 1.0 or cy >= 1.0 (grid cell == grid size), where the reference "
+                   "raises IndexError at utils/utils.py:262")
+
+
+def _head_err_view(ws, B, A, Gh, Gw):
+    """the int32 `err` word of a YOLO head workspace (csrc/yolo_head.hip: owner[B*A*Gh*Gw] | ignore[Gh*Gw] | err)"""
+    return ws.view(torch.int32)[B * A * Gh * Gw + Gh * Gw:B * A * Gh * Gw + Gh * Gw + 1]
+
+
 _EVAL_FUSE = os.environ.get("MDCV_EVAL_FUSE", "1") == "1"     # inference: conv + BatchNorm(running stats) + activation in one launch
 
 
 class _NetPlan(Plan):
     """engine.Plan + the per-network I/O buffers and the run_* entry points."""
 
+    err_views = ()        # int32 one-element views of the YOLO heads' `err` words (training plans)
+
+    def check_targets(self):
+        """Raises IndexError if the targets of the LAST forward through this plan held a centre coordinate >= 1.0 (the reference's
+        build_targets indexes its [B,A,G,G] tensors with gi == G there and raises, utils/utils.py:262; the fused head drops the
+        target and sets a flag).  The flags ride to a pinned host word with a non-blocking copy behind every forward; the
+        training loop looks at them at the start of the NEXT forward, so a bad label surfaces one step late but without a sync."""
+        ev = getattr(self, "_err_event", None)
+        if ev is None:
+            return
+        self._err_event = None
+        ev.synchronize()
+        if bool(self._err_host.any()):
+            raise IndexError(_BAD_TARGET_MSG)
+
     def run_forward(self, x, targets=None):
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
+        if targets is not None and self.err_views and _CHECK_TARGETS:
+            self.check_targets()
         self.in_holder["src"] = x
         if targets is not None:
             self.targets.copy_(targets.reshape(self.targets.shape), non_blocking=True)
@@ -221,6 +250,12 @@ class _NetPlan(Plan):
             self._graphed("fwd")
         else:
             self.run(self.fwd, st)
+        if targets is not None and self.err_views and _CHECK_TARGETS:
+            if getattr(self, "_err_host", None) is None:
+                self._err_host = torch.zeros(len(self.err_views), dtype=torch.int32).pin_memory()
+            self._err_host.copy_(torch.cat(self.err_views), non_blocking=True)
+            self._err_event = torch.cuda.Event()
+            self._err_event.record()
 
     def _graphed(self, which):
         """Replay (first call: warm run + capture) a launch list as a hipGraph.  Capture is illegal on the legacy default
@@ -294,6 +329,8 @@ class FlatParamsMixin:
     gradient all-reduce are single passes over contiguous HBM."""
 
     def _flatten(self):
+        if getattr(self, "_pipe_plan", None) is not None:
+            self._param_sync()                               # a pipelined optimizer step may still be updating the old buffers
         plist = [p for p in self.parameters()]
         dev = plist[0].device
         total = sum(p.numel() for p in plist)
@@ -311,6 +348,58 @@ class FlatParamsMixin:
         self._plist, self._pflat, self._gflat = plist, pflat, gflat
         self._flat_ptrs = [p.data_ptr() for p in plist]
         self._plans = {}
+        self._pipe_plan = None
+        self._params_changed()
+
+    # run-time caches that must not travel with a copy / pickle of the model: launch plans hold ctypes function pointers, raw device
+    # pointers and closures (copy.deepcopy(model) after a forward -- RektNet/train_eval.py:99 -- raised "ctypes objects containing
+    # pointers cannot be pickled"); the copy re-flattens its parameters and rebuilds its plans on first use.
+    _TRANSIENT = ("_plans", "_pipe_plan", "_last_train_plan", "_dp_reducer", "_pflat", "_gflat", "_flat_ptrs", "_goff", "_plist")
+
+    def _state_without_plans(self):
+        d = {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
+        d["_plans"] = {}
+        return d
+
+    # Launch plans are cached per (batch shape, mode) and own every buffer they touch (~10 GB for YOLOv3 at batch 32), so the cache
+    # is an LRU bounded by activation bytes (MDCV_PLAN_CACHE_GB, default 48) and by count (MDCV_MAX_PLANS, default 16): a ragged last
+    # batch (the reference's DataLoader has no drop_last) or validation at other resolutions costs extra plans only while they are
+    # in use, not one per shape ever seen.  The plan in use is never evicted.
+    max_plans = int(os.environ.get("MDCV_MAX_PLANS", "16"))
+    max_plan_bytes = int(float(os.environ.get("MDCV_PLAN_CACHE_GB", "48")) * (1 << 30))
+
+    def _plan_lookup(self, key):
+        plan = self._plans.get(key)
+        if plan is not None and next(reversed(self._plans)) != key:
+            self._plans[key] = self._plans.pop(key)          # most recently used last
+        return plan
+
+    def _plan_store(self, key, plan):
+        self._plans[key] = plan
+        while len(self._plans) > 1 and (len(self._plans) > max(1, self.max_plans) or
+                                        sum(getattr(p, "bytes", 0) for p in self._plans.values()) > self.max_plan_bytes):
+            victim = next(k for k in self._plans if k != key)
+            self._evict_plan(victim)
+
+    def _evict_plan(self, key):
+        plan = self._plans.pop(key)
+        if getattr(self, "_pipe_plan", None) is plan:
+            self._param_sync()                               # its deferred parameter-group updates must land first
+            self._pipe_plan = None
+        if getattr(self, "_last_train_plan", None) is plan:
+            self._last_train_plan = None
+        # the plan's buffers go back to the caching allocator when the last reference dies (an autograd graph that still needs the
+        # plan for its backward holds one); every stream that used them was joined into the current stream at the end of its step
+
+    def release_plans(self):
+        """Drop every cached launch plan (and its HBM buffers); the next forward rebuilds what it needs."""
+        for k in list(getattr(self, "_plans", {})):
+            self._evict_plan(k)
+
+    def _params_changed(self):
+        """Parameters were rewritten behind the optimizer's back (load_weights / load_state_dict): operands packed ahead of the next
+        forward by a pipelined optimizer step are stale."""
+        self._param_epoch = getattr(self, "_param_epoch", 0) + 1
 
     def _flat_ok(self):
         pl = getattr(self, "_plist", None)
@@ -399,7 +488,16 @@ class Darknet(nn.Module, FlatParamsMixin):
         self.precision = parse_precision(precision if precision is not None else os.environ.get("MDCV_PRECISION", "bf16"))
         self.use_graph = os.environ.get("MDCV_GRAPH", "0") == "1"
         self._plans = {}
-        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._param_sync())   # a pipelined optimizer step may be in flight
+        self.register_state_dict_pre_hook(_sync_before_state_dict)   # a pipelined optimizer step may be in flight
+
+    def __getstate__(self):
+        return self._state_without_plans()
+
+    def load_state_dict(self, *args, **kw):
+        self._param_sync()
+        out = super().load_state_dict(*args, **kw)
+        self._params_changed()
+        return out
 
     # ---- getters consumed by train.py / validate.py / detect.py (reference models.py:279-310)
     def get_start_weight_dim(self): return self.start_weights_dim
@@ -422,10 +520,12 @@ class Darknet(nn.Module, FlatParamsMixin):
         B, _, H, W = x.shape
         T = targets.shape[1] if targets is not None else 0
         key = (B, H, W, T, targets is not None, self.training, self.precision, x.device.index)
-        plan = self._plans.get(key)
+        plan = self._plan_lookup(key)
         if plan is None:
             plan = self._build_plan(x.device, B, H, W, T, targets is not None, self.training)
-            self._plans[key] = plan
+            self._plan_store(key, plan)
+        if getattr(self, "_pipe_plan", None) is not None and plan is not self._pipe_plan:
+            self._param_sync()               # deferred group updates of a pipelined optimizer step are only released from ITS plan's forward list
         if targets is None:
             plan.run_forward(x)
             return plan.eval_out.clone()
@@ -442,6 +542,7 @@ class Darknet(nn.Module, FlatParamsMixin):
         defs, mods = self.module_defs, self.module_list
         n = len(defs)
         plan = _NetPlan(device, self.precision, bn_train, grad_sink=self._grad_view)
+        plan.owner = self
         plan.grad_offset = lambda p: self._goff[id(p)][0]
         plan.use_graph = self.use_graph
         plan.pre = []
@@ -506,6 +607,12 @@ class Darknet(nn.Module, FlatParamsMixin):
                     par = plan.new_act(B, shp[i][1], shp[i][2], ctot)
                     parents[i] = par
                     off = 0
+                    for s in src[:-1]:
+                        if shp[s][0] % 8:
+                            # the concat buffer places every source at a multiple-of-8 channel offset (16-byte vectors); the consumer's
+                            # packed weights index input channels contiguously, so a pad hole in the middle would misalign them
+                            raise NotImplementedError(f"[route] at section {i}: source {s} has {shp[s][0]} channels; every concat source but the "
+                                                      f"last must have a multiple of 8 channels")
                     for s in src:
                         if s not in dest and defs[s]["type"] in ("convolutional", "upsample", "shortcut", "maxpool"):
                             dest[s] = (par, off)
@@ -649,6 +756,7 @@ class Darknet(nn.Module, FlatParamsMixin):
                            float(yl.no_object_loss))
                     plan.call(plan.fwd, L.yolo_head_train, dt, lg.act.ptr, lg.act.ldc, None, 0, lg.act.C, plan.targets.data_ptr(),
                               anchors.data_ptr(), *geo, ws.data_ptr(), plan.out7.data_ptr(), None)
+                    plan.err_views = tuple(plan.err_views) + (_head_err_view(ws, B, A, Gh, Gw),)
                     recs.append(("yolo", lg, anchors, ws, geo))
                 else:
                     plan.call(plan.fwd, L.yolo_head_decode, dt, lg.act.ptr, lg.act.ldc, anchors.data_ptr(), float(yl.stride_for(Gh)), B, A, C,
@@ -735,6 +843,8 @@ class Darknet(nn.Module, FlatParamsMixin):
         self.header_info = header
         self.seen = header[3]
         pos, head = 0, 0
+        self._param_sync()
+        self._params_changed()
 
         def take(dst, count=None):
             nonlocal pos
@@ -777,6 +887,10 @@ class Darknet(nn.Module, FlatParamsMixin):
                 else:
                     conv.bias.data.cpu().numpy().tofile(fp)
                 conv.weight.data.cpu().numpy().tofile(fp)
+
+
+def _sync_before_state_dict(module, prefix, keep_vars):
+    module._param_sync()
 
 
 def _zero_tensor(t, stream):

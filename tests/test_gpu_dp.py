@@ -1,0 +1,193 @@
+"""-m gpu: data-parallel parity of the HIP path (BASELINE.json configs[3]).
+
+N ranks (2 and 4) share this one GPU over the gloo backend (RCCL refuses two ranks on one device; the RCCL exchange itself is
+covered by test_gpu_models.py::test_rccl_allreduce_path_single_rank and csrc's mdcv_comm_* test below).  Rank r runs the HIP
+drop-in (fp32 kernels) on shard r of the fixture batch with the overlapped bucketed all-reduce attached, exactly as bench.py /
+a training loop would, and checks the reference's nn.DataParallel semantics (CVC-YOLOv3/train.py:193-195 with
+`losses[0].sum().backward()`, train.py:70) against vectors produced by the reference itself (tests/golden/make_golden.py):
+  * rank r's losses == the reference on shard r alone        (per-shard BatchNorm statistics, per-shard build_targets)
+  * the reduced gradient == the SUM over shards of the reference's gradients (conv-0 / last-layer tensors and every tensor's norm)
+  * every rank holds the same reduced gradient bit for bit.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, which, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        q.put((rank, (_yolo if which == "yolo" else _rektnet)(rank, world)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                                  # surface failures instead of letting the parent wait for its timeout
+        import traceback
+        q.put((rank, {"error": repr(e) + traceback.format_exc()}))
+
+
+def _yolo(rank, world):
+    from mdcv.yolo.models import Darknet
+    from mdcv.parallel import GradAllReducer, shard_batch
+    z = np.load(os.path.join(G, "mini_darknet_dp.npz"))
+    os.chdir(os.path.join(G, "mini"))
+    net = Darknet("mini.cfg", 2.0, 1.6, 25.0, 0.1, False, precision="fp32")
+    net.load_weights("mini.weights", net.get_start_weight_dim())
+    net = net.cuda().train()
+    red = GradAllReducer.attach(net, bucket_mb=0.05)        # several buckets on this tiny net, reduced while backward still runs
+    x = shard_batch(torch.from_numpy(z["x"]), rank, world).cuda()
+    tg = shard_batch(torch.from_numpy(z["targets"]), rank, world).cuda()
+    out = net(x, tg)
+    out[0].sum().backward()
+    red.finish()
+    torch.cuda.synchronize()
+    params = list(net.parameters())
+    return {"losses": torch.stack([o.detach() for o in out]).cpu().numpy(), "g0": params[0].grad.cpu().numpy(),
+            "glast": params[-2].grad.cpu().numpy(), "gnorm": [float(p.grad.double().norm()) for p in params],
+            "buckets": len(red.log), "flat": net.flat_parameters()[1].cpu().numpy()}
+
+
+def _rektnet(rank, world):
+    from mdcv.rektnet.keypoint_net import KeypointNet
+    from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+    from mdcv.parallel import GradAllReducer, shard_batch
+    z = np.load(os.path.join(G, "rektnet_dp.npz"))
+    zs = np.load(os.path.join(G, "rektnet_net.npz"))
+    net = KeypointNet(7, (80, 80), precision="fp32")
+    net.load_state_dict({k[4:]: torch.from_numpy(zs[k]) for k in zs.files if k.startswith("sd::")})
+    net = net.cuda().train()
+    red = GradAllReducer.attach(net, bucket_mb=0.25)
+    x = shard_batch(torch.from_numpy(z["x"]), rank, world).cuda()
+    tp = shard_batch(torch.from_numpy(z["tpts"]), rank, world).cuda()
+    hm, pts = net(x)
+    loc, geo, tot = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)(hm, pts, None, tp)
+    tot.backward()
+    red.finish()
+    torch.cuda.synchronize()
+    params = list(net.parameters())
+    return {"losses": np.array([float(loc), float(geo), float(tot)], np.float32), "g0": params[0].grad.cpu().numpy(),
+            "gnorm": [float(p.grad.double().norm()) for p in params], "names": [n for n, _ in net.named_parameters()],
+            "buckets": len(red.log), "flat": net.flat_parameters()[1].cpu().numpy()}
+
+
+def _run(world, which):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, which, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    for r in range(world):
+        assert "error" not in res[r], res[r]["error"]
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_hip_mini_darknet_data_parallel_vs_reference(world):
+    z = np.load(os.path.join(G, "mini_darknet_dp.npz"))
+    res = _run(world, "yolo")
+    for r in range(world):
+        np.testing.assert_allclose(res[r]["losses"], z[f"losses_{world}"][r], rtol=1e-4, err_msg=f"rank {r}: per-shard losses")
+        scale = float(np.abs(z[f"g0_{world}"]).max())
+        assert float(np.abs(res[r]["g0"] - z[f"g0_{world}"]).max()) <= 1e-3 * scale, f"rank {r}: reduced conv-0 gradient"
+        scale = float(np.abs(z[f"glast_{world}"]).max())
+        assert float(np.abs(res[r]["glast"] - z[f"glast_{world}"]).max()) <= 1e-3 * scale, f"rank {r}: reduced head gradient"
+        np.testing.assert_allclose(res[r]["gnorm"], z[f"gnorm_{world}"], rtol=2e-3, atol=1e-6)
+        assert res[r]["buckets"] > 3                         # the exchange really ran bucket by bucket
+        assert np.array_equal(res[r]["flat"], res[0]["flat"]), f"rank {r} holds a different reduced gradient than rank 0"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_hip_keypointnet_data_parallel_vs_reference(world):
+    z = np.load(os.path.join(G, "rektnet_dp.npz"))
+    res = _run(world, "rektnet")
+    for r in range(world):
+        np.testing.assert_allclose(res[r]["losses"], z[f"losses_{world}"][r], rtol=1e-4, atol=1e-6, err_msg=f"rank {r}: per-shard losses")
+        scale = float(np.abs(z[f"g0_{world}"]).max())
+        assert float(np.abs(res[r]["g0"] - z[f"g0_{world}"]).max()) <= 5e-3 * scale, f"rank {r}: reduced stem gradient"
+        for n, mine, ref in zip(res[r]["names"], res[r]["gnorm"], z[f"gnorm_{world}"]):
+            if n.endswith(".bias") and "bn" not in n:        # mathematically zero (bias in front of a BatchNorm / under a softmax)
+                assert mine < 2e-3, (n, mine)
+            else:
+                assert abs(mine - ref) <= 5e-3 * max(ref, 1e-4), (n, mine, ref)
+        assert np.array_equal(res[r]["flat"], res[0]["flat"])
+
+
+def test_bench_gpus_flag_is_honoured():
+    """`python bench.py --gpus 2` on a box with fewer GPUs must fail loudly (never run fewer ranks than asked for); under a launcher
+    whose WORLD_SIZE disagrees with the flag it must fail too; with the gloo test backend it spawns the two ranks itself."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MDCV_DIST_BACKEND")}
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, cwd=ROOT, capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode != 0 and "refusing" in (out.stderr + out.stdout)
+    out = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "1", "--warmup", "0"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "disagree" in (out.stderr + out.stdout)
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--workload", "yolo", "--yolo-batch", "4", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-breakdown"], env=dict(env, MDCV_DIST_BACKEND="gloo"), cwd=ROOT, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8
+    y = line["workloads"]["yolo"]
+    assert y["replicas_in_sync"] is True and y["comm"]["ranks"] == 2 and y["comm"]["buckets_per_step"] >= 4
+    assert y["comm"]["allreduce_busy_ms"] > 0 and y["comm"]["exposed_comm_ms"] >= 0
+
+
+def test_comm_c_abi_single_rank_rccl():
+    """mdcv_comm_* (the RCCL entry points of the C ABI, for hosts that do not go through torch.distributed) with a world of one rank on
+    this GPU: all-reduce(SUM) over one rank is the identity; run in a subprocess so a broken RCCL cannot take the test session down."""
+    import subprocess
+    code = r"""
+import ctypes, sys, torch
+sys.path.insert(0, %r)
+from mdcv import _lib
+L = _lib.lib()
+torch.cuda.set_device(0)
+uid = ctypes.create_string_buffer(128)
+L.check(L.comm_unique_id(uid), "comm_unique_id")
+comm = ctypes.c_void_p()
+L.check(L.comm_init(ctypes.byref(comm), 1, uid, 0), "comm_init")
+g = torch.Generator().manual_seed(5)
+x = torch.randn(3 * 1000 * 1000 + 17, generator=g).cuda()
+ref = x.clone()
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    L.check(L.comm_allreduce_sum(comm, x.data_ptr(), x.numel(), st), "comm_allreduce_sum")
+torch.cuda.synchronize()
+assert torch.equal(x, ref)
+L.check(L.comm_destroy(comm), "comm_destroy")
+print("COMM_OK")
+""" % ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "COMM_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])

@@ -129,3 +129,60 @@ def test_cross_ratio_prints_and_unknown_type():
     crit = CrossRatioLoss("bogus", True, 0.1, 0.2)
     with pytest.raises(NameError):
         crit(None, torch.zeros(1, 7, 2), None, torch.zeros(1, 7, 2))
+
+
+def test_models_with_cached_plans_deepcopy_and_pickle():
+    """RektNet/train_eval.py:99 keeps `best_model = copy.deepcopy(model)` after a forward; the launch plans a forward leaves behind
+    hold ctypes function pointers and closures, which must not travel with the copy (it rebuilds them lazily)."""
+    import copy
+    import pickle
+    from mdcv.rektnet.keypoint_net import KeypointNet
+    from mdcv.yolo.models import Darknet
+
+    class FakePlan:                        # what a cached plan looks like to pickle: ctypes pointers + closures
+        def __init__(self):
+            self.fn = ctypes.CFUNCTYPE(ctypes.c_int)(lambda: 0)
+            self.closure = lambda s: 0
+
+    cwd = os.getcwd()
+    os.chdir(os.path.join(G, "mini"))
+    try:
+        yolo = Darknet("mini.cfg", 2.0, 1.6, 25.0, 0.1, False)
+    finally:
+        os.chdir(cwd)
+    for net in (KeypointNet(), yolo):
+        net._flatten()                     # parameters become views of one flat buffer, as after the first forward
+        net._plans[("k",)] = FakePlan()
+        net._last_train_plan = FakePlan()
+        before = {k: v.clone() for k, v in net.state_dict().items()}
+        for dup in (copy.deepcopy(net), pickle.loads(pickle.dumps(net))):
+            assert dup._plans == {} and not hasattr(dup, "_last_train_plan") and not dup._flat_ok()
+            for k, v in dup.state_dict().items():
+                assert torch.equal(v, before[k]), k
+            p0 = next(dup.parameters())
+            with torch.no_grad():
+                p0.add_(1.0)                # the copy owns its storage
+            assert torch.equal(net.state_dict()[next(iter(before))], before[next(iter(before))])
+        assert ("k",) in net._plans        # the original keeps its plans
+
+
+def test_cross_ratio_rejects_other_keypoint_counts():
+    from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+    crit = CrossRatioLoss("l1_softargmax", True, 0.1, 0.2)
+    with pytest.raises(ValueError):
+        crit(None, torch.zeros(2, 5, 2), None, torch.zeros(2, 5, 2))
+
+
+def test_bench_cli_contract_without_gpu():
+    """bench.py refuses to run without a GPU (no CPU fallback) -- and says so instead of crashing."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
+
+
+def test_kernel_fingerprint_tracks_sources(tmp_path):
+    from mdcv import _fingerprint as F
+    a = F.kernel_fingerprint()
+    assert a == F.kernel_fingerprint() and len(a) == 16
+    assert any(f.endswith("conv_igemm.hip") for f in F.fingerprint_files()) and any(f.endswith("engine.py") for f in F.fingerprint_files())
