@@ -193,25 +193,47 @@ def kernel_breakdown(model, plan, step_fn):
         torch.cuda.synchronize()
     finally:
         plan.run = orig_run
+    # second instrumented step in the step's REAL schedule (weight gradients on the side stream beside the main stream's kernels, as in the
+    # timed region and in a rocprofv3 trace of this command): only the in-library event pair around every kernel, on its own stream
+    import ctypes
+    L = plan.L
+    try:
+        L.check(L.profile_begin(), "profile_begin")
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        n = L.profile_stop()
         plan.use_graph = g
+    buf, ms = ctypes.create_string_buffer(1024), ctypes.c_float()
+    for i in range(max(n, 0)):
+        L.check(L.profile_read(i, ctypes.byref(ms), buf, 1024), "profile_read")
+        e = krec.setdefault(buf.value.decode(), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        e["launches_overlapped"] = e.get("launches_overlapped", 0) + 1
+        e["ms_overlapped"] = e.get("ms_overlapped", 0.0) + ms.value
     return rec, krec
 
 
 def roofline_objects(krec, precision, traffic):
     """`roofline` = the ONE kernel symbol with the largest share of the step's kernel time among the kernels whose algorithmic work
     is modelled; `roofline_kernels` = every modelled kernel symbol (MFMA-bound convolutions / weight gradients in TFLOP/s, HBM-bound
-    BatchNorm passes in GB/s), largest total time first.  Durations are the in-library HIP-event brackets of the instrumented step."""
+    BatchNorm passes in GB/s), largest total time first.  Durations are the in-library HIP-event pairs around each kernel on its launch
+    stream: `avg_us` / `achieved` / `frac` in the step's real schedule (side-stream weight gradients sharing the CUs with the main
+    stream, which is what a rocprofv3 kernel trace of this command sees), `*_serial` with every kernel alone on the GPU."""
     peak_f = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
     rows = []
     for sym, e in krec.items():
         if e["launches"] == 0 or e["ms"] <= 0 or (e["flops"] == 0 and e["bytes"] == 0):
             continue
         mf = e["flops"] > 0
-        ach = (e["flops"] / (e["ms"] * 1e-3) / 1e12) if mf else (e["bytes"] / (e["ms"] * 1e-3) / 1e9)
+        work, div = (e["flops"], 1e12) if mf else (e["bytes"], 1e9)
+        ser = work / (e["ms"] * 1e-3) / div
+        mso = e.get("ms_overlapped", e["ms"]) if e.get("launches_overlapped", e["launches"]) == e["launches"] else e["ms"]
+        ach = work / (mso * 1e-3) / div
         peak = peak_f if mf else PEAK_HBM_GBS
         row = {"kernel": short_symbol(sym), "symbol": sym, "bound": "mfma" if mf else "hbm", "launches": e["launches"],
-               "avg_us": 1e3 * e["ms"] / e["launches"], "total_ms": e["ms"], "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mf else "GB/s",
-               "frac": ach / peak, ("flops_per_launch" if mf else "bytes_per_launch"): (e["flops"] if mf else e["bytes"]) / e["launches"]}
+               "avg_us": 1e3 * mso / e["launches"], "total_ms": mso, "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mf else "GB/s",
+               "frac": ach / peak, ("flops_per_launch" if mf else "bytes_per_launch"): work / e["launches"],
+               "avg_us_serial": 1e3 * e["ms"] / e["launches"], "achieved_serial": ser, "frac_serial": ser / peak}
         t = (traffic or {}).get("kernels", {}).get(short_symbol(sym)) if traffic else None
         row["traffic"] = (t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) if t else None
         rows.append(row)
@@ -480,7 +502,8 @@ def main():
                 if not traffic:
                     top["traffic_reason"] = why
                 top["note"] = ("dominant kernel of the step by total time; achieved = algorithmic FLOPs of the launches dispatched to this symbol / their "
-                               "summed duration (HIP events around each kernel on its launch stream, one serial instrumented step)")
+                               "summed duration, HIP events around each kernel on its launch stream in one instrumented step with the real two-stream "
+                               "schedule (*_serial: the same kernels alone on the GPU)")
                 result["roofline"] = top
                 result["roofline_kernels"] = [{k: v for k, v in r.items() if k != "symbol"} for r in rows]
         if world == 1 and a.precision == "bf16" and not a.no_fp32 and a.workload in ("both", "yolo"):
@@ -595,7 +618,8 @@ def main():
         kp = KeypointNet(7, (80, 80), precision=a.precision).to(device).eval()
         B = a.joint_batch
         g = torch.Generator().manual_seed(4000 + rank)
-        x = torch.rand(B, 3, 608, 608, generator=g).to(device)
+        x8 = torch.randint(0, 256, (B, 3, 608, 608), generator=g, dtype=torch.uint8).to(device)    # the decoded camera frames (cv2.imread gives uint8)
+        x = x8.float() / 255.0                                                                    # what the detector is fed
         rng = np.random.default_rng(4000 + rank)
         rows, vals = [], []
         for b in range(B):
@@ -640,12 +664,14 @@ def main():
             stage("detector_eval_608", lambda: det_net(x))
             det = detect_postprocess(out0, None, thr, 0.25, 0.5, 608, 608)
             stage("postprocess", lambda: detect_postprocess(out0, None, thr, 0.25, 0.5, 608, 608))
-            crops, _, M = crop_resize(x, det.boxes[:, :16], det.count, (80, 80), pad_rows_to=64)
-            stage("crop_resize", lambda: crop_resize(x, det.boxes[:, :16], det.count, (80, 80), pad_rows_to=64))
+            # crops are cut from the uint8 frames with the reference's rule: 8-bit fixed-point cv2.resize, then / 255 (RektNet/dataset.py:35-38,52)
+            crops, _, M = crop_resize(x8, det.boxes[:, :16], det.count, (80, 80), pad_rows_to=64)
+            stage("crop_resize", lambda: crop_resize(x8, det.boxes[:, :16], det.count, (80, 80), pad_rows_to=64))
             stage("keypoint_eval", lambda: kp(crops))
-            dt = timed_region(lambda: pipe(x), a.steps, a.warmup, device, world)
+            dt = timed_region(lambda: pipe(x, frames=x8), a.steps, a.warmup, device, world)
         ips = B * world * a.steps / dt
         extra["joint"] = {"images_per_sec": ips, "ms_per_batch": 1e3 * dt / a.steps, "frames_per_gpu": B, "crops_per_batch": M,
+                          "crop_rule": "uint8 frame -> cv2 8-bit fixed-point INTER_LINEAR -> /255 (mdcv_crop_resize_u8)",
                           "conf_thres": thr, "kept_per_frame_mean": float(det.count.float().mean()), "stage_ms": {k: round(v, 4) for k, v in stages.items()},
                           "stage_images_per_sec": {k: round(B * world / (v * 1e-3), 1) for k, v in stages.items()}}
         result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}

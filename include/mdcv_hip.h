@@ -194,6 +194,12 @@ int mdcv_average_precision(const unsigned char* tp, const float* conf, int m, in
 int mdcv_crop_resize(const float* frames, int B, int C, int H, int W, const float* boxes, const int* count, int K, float scale_x,
                      float scale_y, float off_x, float off_y, int out_h, int out_w, float* out, int* owner, int* total, void* stream);
 
+/* The same cut with the rule the reference's loaders actually apply (RektNet/dataset.py:35-38,52, RektNet/detect.py:29-35): the frame
+ * is a uint8 image [B,C,H,W], cv2.resize runs its 8-bit fixed-point INTER_LINEAR (11-bit coefficients, result rounded to 8 bits), and
+ * only then is the crop divided by 255: out = (float)(u8 / 255.0). */
+int mdcv_crop_resize_u8(const unsigned char* frames, int B, int C, int H, int W, const float* boxes, const int* count, int K, float scale_x,
+                        float scale_y, float off_x, float off_y, int out_h, int out_w, float* out, int* owner, int* total, void* stream);
+
 /* ---- on-device synthetic cone data with the output contracts of the reference's datasets; every value is a pure
  *      function of (seed, step, index), reproduced bit for bit by oracle/synth_oracle.py.
  *      detector batch (CVC-YOLOv3/utils/datasets.py:124-315): images [B,3,H,W] in [0,1], targets [B,T,5] (cls,cx,cy,w,h), zero rows last.

@@ -12,8 +12,22 @@ from . import _lib
 from .yolo.postprocess import detect_postprocess
 
 
-def crop_resize(frames, boxes, count, out_size=(80, 80), scale=(1.0, 1.0), offset=(0.0, 0.0), pad_rows_to=1):
-    """frames [B,C,H,W] fp32, boxes [B,K,4] corner boxes in detector coordinates, count [B] (int32) -> (crops, owner, M).
+def to_u8(frames):
+    """[0,1] float frames -> the uint8 image they were decoded from (round(x * 255)); uint8 input passes through."""
+    if frames.dtype == torch.uint8:
+        return frames.contiguous()
+    return (frames.detach().to(torch.float32) * 255.0).round_().clamp_(0, 255).to(torch.uint8).contiguous()
+
+
+def crop_resize(frames, boxes, count, out_size=(80, 80), scale=(1.0, 1.0), offset=(0.0, 0.0), pad_rows_to=1, u8=None):
+    """frames [B,C,H,W] fp32 (or uint8), boxes [B,K,4] corner boxes in detector coordinates, count [B] (int32) -> (crops, owner, M).
+
+    Two resampling rules (both cv2.resize's default INTER_LINEAR, RektNet/utils.py:73-76):
+      * u8=True (default for uint8 frames): what the reference's loaders do — the frame is an 8-bit image, cv2 resizes it in 11-bit
+        fixed point and rounds to 8 bits, THEN the crop is divided by 255 (dataset.py:35-38,52; detect.py:29-35).  Float frames in
+        [0,1] are first put back on the 8-bit grid (`to_u8`).
+      * u8=False (default for float frames): OpenCV's float32 formulation applied to the float frame, no 8-bit rounding — for
+        frames that never were 8-bit (synthetic streams, already-normalised tensors).
 
     crops is [Mpad, C, out_h, out_w] with the M real crops first (image-major, box order kept) and zero rows up to the next
     multiple of `pad_rows_to`; owner [Mpad] is the frame index of each real crop.  Box coordinates are mapped to frame pixels
@@ -27,7 +41,9 @@ def crop_resize(frames, boxes, count, out_size=(80, 80), scale=(1.0, 1.0), offse
     if not (0 < oh <= 256 and 0 < ow <= 256):
         raise ValueError("crop_resize: output side must be in 1..256")
     dev = frames.device
-    fr = frames.detach().to(torch.float32).contiguous()
+    if u8 is None:
+        u8 = frames.dtype == torch.uint8
+    fr = to_u8(frames) if u8 else frames.detach().to(torch.float32).contiguous()
     bx = boxes.detach().to(torch.float32).contiguous()
     B, C, H, W = (int(v) for v in fr.shape)
     K = int(bx.shape[1])
@@ -41,7 +57,7 @@ def crop_resize(frames, boxes, count, out_size=(80, 80), scale=(1.0, 1.0), offse
     owner = torch.zeros(Mpad, dtype=torch.int32, device=dev)
     total = torch.zeros(1, dtype=torch.int32, device=dev)
     if K > 0:
-        L.check(L.crop_resize(fr.data_ptr(), B, C, H, W, bx.data_ptr(), cnt.data_ptr(), K, float(scale[0]), float(scale[1]),
+        L.check((L.crop_resize_u8 if u8 else L.crop_resize)(fr.data_ptr(), B, C, H, W, bx.data_ptr(), cnt.data_ptr(), K, float(scale[0]), float(scale[1]),
                               float(offset[0]), float(offset[1]), oh, ow, out.data_ptr(), owner.data_ptr(), total.data_ptr(),
                               torch.cuda.current_stream().cuda_stream), "crop_resize")
     return out, owner, M
@@ -50,10 +66,12 @@ def crop_resize(frames, boxes, count, out_size=(80, 80), scale=(1.0, 1.0), offse
 class JointPipeline:
     """detector: eval-mode `Darknet`; keypoint_net: eval-mode `KeypointNet`.  `__call__(imgs, frames=None)`:
     imgs [B,3,H,W] is the detector input; crops are cut from `frames` (defaults to imgs) after mapping the boxes with
-    `scale` / `offset`.  Returns a dict: det (Detections), crops, owner, num (M), keypoints [M,K,2] (normalised x,y in the
+    `scale` / `offset`.  `frames` as uint8 [B,3,H,W] (the decoded camera image, as the reference's cv2.imread delivers it) takes the
+    reference's 8-bit resize rule; float frames take the float rule unless `u8=True` (see crop_resize).  Returns a dict: det (Detections), crops, owner, num (M), keypoints [M,K,2] (normalised x,y in the
     crop) and keypoints_frame [M,K,2] (frame pixels)."""
 
-    def __init__(self, detector, keypoint_net, conf_thres=None, nms_thres=None, top_k=200, max_cones=64, bucket=64):
+    def __init__(self, detector, keypoint_net, conf_thres=None, nms_thres=None, top_k=200, max_cones=64, bucket=64, u8=None):
+        self.u8 = u8
         self.detector, self.keypoint_net = detector, keypoint_net
         c, n, _ = detector.get_threshs() if hasattr(detector, "get_threshs") else (0.8, 0.25, 0.5)
         self.conf_thres = float(c if conf_thres is None else conf_thres)
@@ -70,7 +88,7 @@ class JointPipeline:
         kcap = min(self.max_cones, self.top_k)
         src = imgs if frames is None else frames
         size = tuple(self.keypoint_net.image_size)
-        crops, owner, M = crop_resize(src, det.boxes[:, :kcap], det.count, size, scale, offset, pad_rows_to=self.bucket)
+        crops, owner, M = crop_resize(src, det.boxes[:, :kcap], det.count, size, scale, offset, pad_rows_to=self.bucket, u8=self.u8)
         res = dict(det=det, crops=crops[:M], owner=owner[:M], num=M, keypoints=None, keypoints_frame=None)
         if M == 0:
             return res

@@ -57,15 +57,65 @@ def resize_bilinear(img, out_h, out_w):
     return (rows0 * b0[None, :, None] + rows1 * b1[None, :, None]).astype(F)
 
 
-def crop_resize(frames, boxes, count, out_h=80, out_w=80, scale=(1.0, 1.0), offset=(0.0, 0.0)):
-    """frames [B,C,H,W], boxes [B,K,4] corner, count [B] -> ([M,C,out_h,out_w], image index [M]); image-major order."""
-    frames = np.asarray(frames, F)
+def _taps_u8(dst, src, clamp_weights):
+    """OpenCV's 8-bit INTER_LINEAR tap table for one axis (resize.cpp, `resize()` coefficient loop with fixpt = true):
+    fx = (float)((d + 0.5) * scale - 0.5) with scale = 1. / ((double)dst / src); sx = cvFloor(fx); fx -= sx.
+    x axis (clamp_weights): sx < 0 -> sx = 0, fx = 0 ; sx >= src - 1 -> sx = src - 1, fx = 0.
+    y axis: the weights stay, the two ROW indices are clamped instead (`clip(sy + k, 0, ssize.height)`).
+    Coefficients are `saturate_cast<short>(c * INTER_RESIZE_COEF_SCALE)` = round-half-even(c * 2048)."""
+    sc = 1.0 / (float(dst) / float(src))
+    d = np.arange(dst, dtype=np.float64)
+    fx = ((d + 0.5) * sc - 0.5).astype(F)
+    sx = np.floor(fx).astype(np.int64)
+    fx = (fx - sx.astype(F)).astype(F)
+    if clamp_weights:
+        lo = sx < 0
+        sx[lo] = 0; fx[lo] = 0
+        hi = sx >= src - 1
+        sx[hi] = src - 1; fx[hi] = 0
+    c0 = np.rint((F(1) - fx).astype(F) * F(2048)).astype(np.int64)
+    c1 = np.rint(fx * F(2048)).astype(np.int64)
+    return np.clip(sx, 0, src - 1), np.clip(sx + 1, 0, src - 1), c0, c1
+
+
+def resize_bilinear_u8(img, out_h, out_w):
+    """img [C,h,w] uint8 -> [C,out_h,out_w] uint8; cv2.resize(img, (out_w, out_h)) on an 8-bit image (what RektNet/utils.py:73-76
+    does to the cv2.imread output in dataset.py:35-38 and detect.py:29-32): HResizeLinear in 11-bit fixed point, then
+    VResizeLinear's `uchar((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2)`.  PARITY UNPINNED like resize_bilinear
+    (cv2 is not in the image); cross-checked against the float formulation to +-1 grey level in tests/test_oracle_golden.py."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8
+    s = img.astype(np.int64)
+    x0, x1, a0, a1 = _taps_u8(out_w, img.shape[2], True)
+    y0, y1, b0, b1 = _taps_u8(out_h, img.shape[1], False)
+    d0 = s[:, y0][:, :, x0] * a0 + s[:, y0][:, :, x1] * a1
+    d1 = s[:, y1][:, :, x0] * a0 + s[:, y1][:, :, x1] * a1
+    v = (((b0[None, :, None] * (d0 >> 4)) >> 16) + ((b1[None, :, None] * (d1 >> 4)) >> 16) + 2) >> 2
+    return (v & 0xFF).astype(np.uint8)
+
+
+def to_u8(frames):
+    """[0,1] float frames -> the 8-bit image (round-half-even(x * 255), clamped); uint8 passes through."""
+    frames = np.asarray(frames)
+    if frames.dtype == np.uint8:
+        return frames
+    return np.clip(np.rint(frames.astype(F) * F(255)), 0, 255).astype(np.uint8)
+
+
+def crop_resize(frames, boxes, count, out_h=80, out_w=80, scale=(1.0, 1.0), offset=(0.0, 0.0), u8=False):
+    """frames [B,C,H,W], boxes [B,K,4] corner, count [B] -> ([M,C,out_h,out_w], image index [M]); image-major order.
+    u8: the reference's order of operations — resize the 8-bit image, then `image.transpose((2, 0, 1)) / 255.0` in float64 and one
+    rounding to float32 (dataset.py:52, detect.py:33-34)."""
+    frames = to_u8(frames) if u8 else np.asarray(frames, F)
     B, C, H, W = frames.shape
     out, owner = [], []
     for b in range(B):
         for k in range(int(count[b])):
             x1, y1, x2, y2 = crop_bounds(boxes[b, k], H, W, scale, offset)
-            out.append(resize_bilinear(frames[b, :, y1:y2, x1:x2], out_h, out_w))
+            if u8:
+                out.append((resize_bilinear_u8(frames[b, :, y1:y2, x1:x2], out_h, out_w).astype(np.float64) / 255.0).astype(F))
+            else:
+                out.append(resize_bilinear(frames[b, :, y1:y2, x1:x2], out_h, out_w))
             owner.append(b)
     if not out:
         return np.zeros((0, C, out_h, out_w), F), np.zeros((0,), np.int64)

@@ -285,6 +285,40 @@ def test_crop_bounds_and_order():
     np.testing.assert_array_equal(crops[2], PL.resize_bilinear(frames[1, :, 5:25, 5:25], 16, 8))
 
 
+@pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (17, 9), (80, 80), (160, 121), (300, 40), (40, 80), (79, 81)])
+def test_resize_bilinear_u8_fixed_point_rule(h, w):
+    """The 8-bit rule of cv2.resize (what the reference's loaders run on the cv2.imread image): identity at scale 1, never more than
+    one grey level from the exact bilinear value (11-bit coefficients + two truncating shifts + one rounding), exact on constant
+    and on horizontally / vertically linear images' interiors up to that level, and monotone (no wrap-around at 0 / 255)."""
+    rng = np.random.default_rng(h * 1000 + w)
+    img = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
+    got = PL.resize_bilinear_u8(img, 80, 80)
+    assert got.dtype == np.uint8 and got.shape == (3, 80, 80)
+    exact = torch.nn.functional.interpolate(T(img.astype(np.float64))[None], size=(80, 80), mode="bilinear", align_corners=False)[0].numpy()
+    assert np.abs(got.astype(np.float64) - exact).max() <= 1.0 + 1e-9
+    if (h, w) == (80, 80):
+        np.testing.assert_array_equal(got, img)
+    for v in (0, 1, 127, 254, 255):
+        np.testing.assert_array_equal(PL.resize_bilinear_u8(np.full((1, h, w), v, np.uint8), 80, 80), np.full((1, 80, 80), v, np.uint8))
+    # the divide by 255 happens AFTER the 8-bit rounding, in float64, rounded once to float32 (dataset.py:52)
+    f = rng.random((1, 3, h, w), dtype=np.float32)
+    crops, _ = PL.crop_resize(f, np.array([[[0, 0, w, h]]], np.float32), [1], 80, 80, u8=True)
+    np.testing.assert_array_equal(crops[0], (PL.resize_bilinear_u8(PL.to_u8(f[0]), 80, 80).astype(np.float64) / 255.0).astype(np.float32))
+    assert set(np.unique(np.rint(crops * 255) / 255 - crops).tolist()) <= {0.0} or np.abs(np.rint(crops * 255) / 255 - crops).max() < 1e-7
+
+
+def test_resize_bilinear_u8_hand_computed():
+    """2x upscale of a 1x2 image by hand: dst x = 0..3 -> fx = (x + .5) * .5 - .5 = -.25, .25, .75, 1.25 -> taps (0,0|w=0), (0,1|.25),
+    (0,1|.75), (1,1|0); coefficients 2048/0, 1536/512, 512/1536, 2048/0; one source row, so both vertical taps read the same D."""
+    img = np.array([[[10, 200]]], np.uint8)
+    got = PL.resize_bilinear_u8(img, 1, 4)[0, 0].tolist()
+    want = []
+    for a0, a1 in ((2048, 0), (1536, 512), (512, 1536), (0, 2048)):       # (0, 2048) == the clamped tap (1, 1 | 2048, 0) on this image
+        d = 10 * a0 + 200 * a1
+        want.append((((2048 * (d >> 4)) >> 16) + ((0 * (d >> 4)) >> 16) + 2) >> 2)     # fy = (0 + .5) * 1 - .5 = 0 -> b = (2048, 0)
+    assert got == want == [10, 58, 153, 200], (got, want)     # exact bilinear: 10, 57.5, 152.5, 200
+
+
 # ---------------------------------------------------------------------------
 # synthetic cone data (SURVEY.md §8f-4) — oracle/synth_oracle.py: contracts and the cv2 heat-map restatement
 from oracle import synth_oracle as SO
