@@ -818,6 +818,8 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
       if (g_conv_deep_small && nk >= g_conv_deep_small && (v == 6 || v == 7)) v += 3;   // 3-stage ring for the mid / sparse grids too
       if (g_conv_deep4 && nk >= g_conv_deep4 && t128 <= 512 && (v == 9 || v == 10)) v = v == 9 ? 12 : 14;   // sparse grids: 4 stages
     }
+    if (!BF && small) v = v == 8 ? 6 : (v == 11 ? 9 : (v == 13 ? 12 : v));   // the 8-wave 256-row tiles exist in bf16 only: fp32 takes the 128x128 LDS-DMA tiles
+                                                                           // (the register-staged fallback has no inference epilogue and is slower)
     if (v >= 6 && !small) v = (v == 8 || v == 11 || v == 13) ? 2 : ((v == 7 || v == 10) ? 4 : 0);
     if (v == 6) return launch_conv_glds<T, MODE, 128, 128, 2, 2>(a, st, B);
     if (v == 7) return launch_conv_glds<T, MODE, 128, 64, 2, 2>(a, st, B);
