@@ -193,32 +193,18 @@ def kernel_breakdown(model, plan, step_fn):
         torch.cuda.synchronize()
     finally:
         plan.run = orig_run
-    # second instrumented step in the step's REAL schedule (weight gradients on the side stream beside the main stream's kernels, as in the
-    # timed region and in a rocprofv3 trace of this command): only the in-library event pair around every kernel, on its own stream
-    import ctypes
-    L = plan.L
-    try:
-        L.check(L.profile_begin(), "profile_begin")
-        step_fn()
-        torch.cuda.synchronize()
-    finally:
-        n = L.profile_stop()
         plan.use_graph = g
-    buf, ms = ctypes.create_string_buffer(1024), ctypes.c_float()
-    for i in range(max(n, 0)):
-        L.check(L.profile_read(i, ctypes.byref(ms), buf, 1024), "profile_read")
-        e = krec.setdefault(buf.value.decode(), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-        e["launches_overlapped"] = e.get("launches_overlapped", 0) + 1
-        e["ms_overlapped"] = e.get("ms_overlapped", 0.0) + ms.value
     return rec, krec
 
 
-def roofline_objects(krec, precision, traffic):
+def roofline_objects(krec, precision, traffic, in_step=None):
     """`roofline` = the ONE kernel symbol with the largest share of the step's kernel time among the kernels whose algorithmic work
     is modelled; `roofline_kernels` = every modelled kernel symbol (MFMA-bound convolutions / weight gradients in TFLOP/s, HBM-bound
-    BatchNorm passes in GB/s), largest total time first.  Durations are the in-library HIP-event pairs around each kernel on its launch
-    stream: `avg_us` / `achieved` / `frac` in the step's real schedule (side-stream weight gradients sharing the CUs with the main
-    stream, which is what a rocprofv3 kernel trace of this command sees), `*_serial` with every kernel alone on the GPU."""
+    BatchNorm passes in GB/s), largest total time first.  `avg_us` / `achieved` / `frac`: the in-library start / stop HIP event pair of
+    each dispatch on its launch stream (hipExtLaunchKernel) in one instrumented step that runs every kernel ALONE on the GPU -- the
+    kernel's own quality.  In the timed steps the weight gradients run on a side stream beside the main stream's kernels and both
+    stretch; `avg_us_in_step` / `achieved_in_step` quote that from the rocprofv3 kernel trace of this same command committed under
+    profiles/ (only when it was taken with this tree's kernels)."""
     peak_f = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
     rows = []
     for sym, e in krec.items():
@@ -226,20 +212,38 @@ def roofline_objects(krec, precision, traffic):
             continue
         mf = e["flops"] > 0
         work, div = (e["flops"], 1e12) if mf else (e["bytes"], 1e9)
-        ser = work / (e["ms"] * 1e-3) / div
-        mso = e.get("ms_overlapped", e["ms"]) if e.get("launches_overlapped", e["launches"]) == e["launches"] else e["ms"]
-        ach = work / (mso * 1e-3) / div
+        ach = work / (e["ms"] * 1e-3) / div
         peak = peak_f if mf else PEAK_HBM_GBS
         row = {"kernel": short_symbol(sym), "symbol": sym, "bound": "mfma" if mf else "hbm", "launches": e["launches"],
-               "avg_us": 1e3 * mso / e["launches"], "total_ms": mso, "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mf else "GB/s",
-               "frac": ach / peak, ("flops_per_launch" if mf else "bytes_per_launch"): work / e["launches"],
-               "avg_us_serial": 1e3 * e["ms"] / e["launches"], "achieved_serial": ser, "frac_serial": ser / peak}
+               "avg_us": 1e3 * e["ms"] / e["launches"], "total_ms": e["ms"], "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mf else "GB/s",
+               "frac": ach / peak, ("flops_per_launch" if mf else "bytes_per_launch"): work / e["launches"]}
+        ns = (in_step or {}).get(short_symbol(sym))
+        if ns:
+            row["avg_us_in_step"] = ns / 1e3
+            row["achieved_in_step"] = work / e["launches"] / (ns * 1e-9) / div
         t = (traffic or {}).get("kernels", {}).get(short_symbol(sym)) if traffic else None
         row["traffic"] = (t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) if t else None
         rows.append(row)
     rows.sort(key=lambda r: -r["total_ms"])
     top = dict(rows[0]) if rows else None
     return top, rows
+
+
+def load_in_step_stats(workload):
+    """{kernel: average ns} from the newest profiles/rNN_<workload>_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this very
+    command, scripts/profile_round.sh) whose companion JSON line carries this tree's kernel fingerprint; else (None, reason)."""
+    import csv
+    import glob
+    from mdcv._fingerprint import kernel_fingerprint
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{workload}_bench_under_rocprof.json")), reverse=True):
+        try:
+            line = json.loads([ln for ln in open(f).read().splitlines() if ln.startswith("{")][-1])
+        except Exception:
+            continue
+        c = f.replace("_bench_under_rocprof.json", "_bench_kernel_stats.csv")
+        if line.get("fingerprint") == kernel_fingerprint() and os.path.exists(c):
+            return {short_symbol(r["Name"]): float(r["AverageNs"]) for r in csv.DictReader(open(c))}, os.path.basename(c)
+    return None, "no rocprofv3 kernel stats under profiles/ taken with this tree's kernels"
 
 
 def load_traffic():
@@ -496,14 +500,16 @@ def main():
             extra["yolo"]["kernel_launches_per_step"] = {k: v[0] for k, v in rec.items()}
             extra["yolo"]["sum_kernel_ms"] = round(tot, 3)
             traffic, why = (load_traffic() if (B == 32 and a.precision == "bf16" and a.yolo_classes == 80) else (None, "non-default workload"))
-            top, rows = roofline_objects(krec, a.precision, traffic)
+            in_step, src = load_in_step_stats("yolo") if (B == 32 and a.precision == "bf16" and a.yolo_classes == 80) else (None, "non-default workload")
+            top, rows = roofline_objects(krec, a.precision, traffic, in_step)
             if top:
                 top["traffic_source"] = traffic["_file"] if traffic else None
                 if not traffic:
                     top["traffic_reason"] = why
+                top["in_step_source"] = src
                 top["note"] = ("dominant kernel of the step by total time; achieved = algorithmic FLOPs of the launches dispatched to this symbol / their "
-                               "summed duration, HIP events around each kernel on its launch stream in one instrumented step with the real two-stream "
-                               "schedule (*_serial: the same kernels alone on the GPU)")
+                               "summed duration (start / stop HIP events of each dispatch on its launch stream, one instrumented step, kernels alone on "
+                               "the GPU); *_in_step: the same from the rocprofv3 trace of this command, where side-stream and main-stream kernels share the CUs")
                 result["roofline"] = top
                 result["roofline_kernels"] = [{k: v for k, v in r.items() if k != "symbol"} for r in rows]
         if world == 1 and a.precision == "bf16" and not a.no_fp32 and a.workload in ("both", "yolo"):
@@ -697,6 +703,8 @@ def main():
         line["roofline"] = result.get("roofline")
         line["roofline_kernels"] = result.get("roofline_kernels")
         line["host_cores"] = os.cpu_count()
+        from mdcv._fingerprint import kernel_fingerprint
+        line["fingerprint"] = kernel_fingerprint()
         if world == 1 and not a.no_cpu_baseline:
             cb = (cpu_baseline_yolo(cfg, tmp) if primary == "yolo" else cpu_baseline_rektnet() if primary == "rektnet"
                   else extra["postprocess"]["cpu_baseline"] if primary == "postprocess" else None)

@@ -220,8 +220,8 @@ int mdcv_event_record(void* ev, void* stream);
 int mdcv_event_sync(void* ev);
 int mdcv_event_elapsed_ms(void* start, void* stop, float* ms);
 int mdcv_event_destroy(void* ev);
-/* In-library kernel profiler: between _begin and _stop EVERY kernel this library launches is bracketed by two HIP events recorded on
- * the stream it is launched on.  _count = launches recorded so far (lets a host attribute them to its own calls); _stop ends recording,
+/* In-library kernel profiler: between _begin and _stop EVERY kernel this library launches carries a start / stop HIP event pair bound
+ * to its own dispatch on the stream it is launched on (hipExtLaunchKernel: no extra packets, the durations are the kernel's own).  _count = launches recorded so far (lets a host attribute them to its own calls); _stop ends recording,
  * waits for the events and returns the record count; _read(i) -> duration in ms and the kernel symbol as rocprofv3 prints it.
  * (bench.py's `roofline` / `roofline_kernels`; not meant for timed regions: each record costs two event records.) */
 int mdcv_profile_begin(void);

@@ -1,6 +1,7 @@
 // Shared device helpers for the MDCV gfx950 kernels.  CDNA4 only: wave = 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef unsigned short bf16_t;   // raw bf16 bits; all arithmetic is done in fp32
@@ -12,17 +13,21 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #define MDCV_F32 0
 #define MDCV_BF16 1
 
-// Every kernel launch of the library goes through MDCV_LAUNCH: when the in-library
-// profiler is on (mdcv_profile_begin, runtime.hip) the launch is bracketed by two HIP events on its stream and remembered with the
-// kernel's host function, from which the symbol rocprofv3 prints is recovered.  Off: one predictable branch per launch.
+// Every kernel launch of the library goes through MDCV_LAUNCH.  When the in-library profiler is on (mdcv_profile_begin, runtime.hip) the
+// kernel is launched with hipExtLaunchKernelGGL and a start / stop event pair: the pair carries the dispatch's OWN begin / end
+// timestamps (what a rocprofv3 kernel trace reports), adds no packets to the stream, and is remembered with the kernel's host function,
+// from which the symbol rocprofv3 prints is recovered.  Off: one predictable branch per launch.
 extern int mdcv_g_prof;
-void mdcv_prof_pre(hipStream_t st);
-void mdcv_prof_post(const void* fn, hipStream_t st);
-#define MDCV_LAUNCH(kern, grid, block, lds, st, ...)                                        \
-  do {                                                                                      \
-    if (mdcv_g_prof) mdcv_prof_pre(st);                                                     \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                            \
-    if (mdcv_g_prof) mdcv_prof_post(reinterpret_cast<const void*>(kern), st);               \
+void mdcv_prof_new(const void* fn, hipEvent_t* e0, hipEvent_t* e1);
+#define MDCV_LAUNCH(kern, grid, block, lds, st, ...)                                                      \
+  do {                                                                                                    \
+    if (mdcv_g_prof) {                                                                                    \
+      hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                          \
+      mdcv_prof_new(reinterpret_cast<const void*>(kern), &e0__, &e1__);                                   \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0__, e1__, 0, __VA_ARGS__);                      \
+    } else {                                                                                              \
+      hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                        \
+    }                                                                                                     \
   } while (0)
 
 #define MDCV_CHECK_LAUNCH()                                   \

@@ -1,6 +1,7 @@
 // Runtime plumbing of libmdcv_hip.so that is not a kernel:
-//   * the in-library kernel profiler behind MDCV_LAUNCH (common.h): a HIP event on the launch stream in front of and behind
-//     EVERY kernel this library launches, with the kernel's symbol as rocprofv3 prints it (bench.py's `roofline` /
+//   * the in-library kernel profiler behind MDCV_LAUNCH (common.h): a start / stop HIP event pair bound to the dispatch of
+//     EVERY kernel this library launches (hipExtLaunchKernel: the kernel's own begin / end timestamps on the stream it runs on),
+//     with the kernel's symbol as rocprofv3 prints it (bench.py's `roofline` /
 //     `roofline_kernels` are built from these; the rocprofv3 kernel trace of the same command under profiles/ must agree);
 //   * the gradient exchange over RCCL for hosts that do not go through torch.distributed (SURVEY.md §8b `comm_init`,
 //     `allreduce_sum`): the one collective of the data-parallel path (CVC-YOLOv3/train.py:193-195 nn.DataParallel's
@@ -45,21 +46,12 @@ const std::string& kernel_name(const void* fn) {
 }
 }  // namespace
 
-void mdcv_prof_pre(hipStream_t st) {
-  Rec r{nullptr, nullptr, nullptr};
-  if (hipEventCreate(&r.e0) != hipSuccess) return;
-  (void)hipEventRecord(r.e0, st);
+void mdcv_prof_new(const void* fn, hipEvent_t* e0, hipEvent_t* e1) {
+  Rec r{fn, nullptr, nullptr};
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { *e0 = *e1 = nullptr; return; }
+  *e0 = r.e0; *e1 = r.e1;
   std::lock_guard<std::mutex> g(g_mu);
   g_recs.push_back(r);
-}
-
-void mdcv_prof_post(const void* fn, hipStream_t st) {
-  hipEvent_t e;
-  if (hipEventCreate(&e) != hipSuccess) return;
-  (void)hipEventRecord(e, st);
-  std::lock_guard<std::mutex> g(g_mu);
-  if (!g_recs.empty() && g_recs.back().e1 == nullptr) { g_recs.back().fn = fn; g_recs.back().e1 = e; }
-  else (void)hipEventDestroy(e);
 }
 
 // ---------------------------------------------------------------------------------------------- RCCL, bound at run time
