@@ -67,8 +67,9 @@ class _Lib:
         for v in os.environ.get("MDCV_CONV_VARIANT", "").split(","):      # tuning hook for in-network A/B runs (see conv2d_set_variant)
             if v.strip():
                 self.cdll.mdcv_conv2d_set_variant(int(v))
-        if os.environ.get("MDCV_WGRAD_VARIANT", "").strip():
-            self.cdll.mdcv_conv2d_wgrad_set_variant(int(os.environ["MDCV_WGRAD_VARIANT"]))
+        for v in os.environ.get("MDCV_WGRAD_VARIANT", "").split(","):
+            if v.strip():
+                self.cdll.mdcv_conv2d_wgrad_set_variant(int(v))
 
     def check(self, rc, what=""):
         if rc != 0:

@@ -1296,14 +1296,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // input channel c (KK independent loads per split, several splits unrolled), so a block has ~4*KK*unroll loads in flight per
 // thread group instead of four dependent chains; the four partial sums meet in LDS.  (The chained version was latency-bound:
 // 25 us per layer, 1.9 ms per YOLOv3 step.)
+// `table` (layer batch, mdcv_conv2d_wgrad_batched): blockIdx.z is the layer; its slabs follow each other in ws, its gradient is table[z].dw.
 template <int KK>
 __global__ __launch_bounds__(256) void wgrad_reduce_kk_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int Cout_pad,
-                                                              int Cin_real, int Cin_pad, int Ktot, int accumulate) {
+                                                              int Cin_real, int Cin_pad, int Ktot, int accumulate, const WgradBatchRec* __restrict__ table) {
   __shared__ float tile[4][KK][65];
   const int co = blockIdx.x, ci0 = blockIdx.y * 64;
   const int nci = min(64, Cin_real - ci0);
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
   const size_t slab = (size_t)Cout_pad * Ktot;
+  if (table) { ws += (size_t)blockIdx.z * splits * slab; dw = table[blockIdx.z].dw; }
   float acc[KK];
 #pragma unroll
   for (int t = 0; t < KK; ++t) acc[t] = 0.f;
@@ -1369,15 +1371,23 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_flat_kernel(const float* __
 
 // sums the fp32 slabs ws[splits][Cout_pad][KK*Cin_pad] into the OIHW gradient
 static int launch_wgrad_reduce(const float* ws, float* dw_oihw, int splits, int Cout_pad, int Cout_real, int Cin_pad, int Cin_real, int KK,
-                               int accumulate, hipStream_t st) {
+                               int accumulate, hipStream_t st, const WgradBatchRec* table = nullptr, int nlayers = 1) {
   const int Ktot = KK * Cin_pad;
+  if (table) {                                       // layer batch: only the wide-layer kernel carries the table
+    if (KK != 9 && KK != 1) return MDCV_EARG;
+    const dim3 rgrid((unsigned)Cout_real, (unsigned)cdiv(Cin_real, 64), (unsigned)nlayers);
+    if (KK == 9) MDCV_LAUNCH(wgrad_reduce_kk_kernel<9>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate, table);
+    else MDCV_LAUNCH(wgrad_reduce_kk_kernel<1>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate, table);
+    MDCV_CHECK_LAUNCH();
+    return MDCV_OK;
+  }
   if (Cout_real * cdiv(Cin_real, 64) < 128) {
     MDCV_LAUNCH(wgrad_reduce_flat_kernel, dim3((unsigned)cdiv(Ktot, 64), (unsigned)Cout_real), dim3(1024), 0, st, ws, dw_oihw, splits,
                        Cout_pad, Cin_real, Cin_pad, KK, Ktot, accumulate);
   } else {
     const dim3 rgrid((unsigned)Cout_real, (unsigned)cdiv(Cin_real, 64));
-    if (KK == 9) MDCV_LAUNCH(wgrad_reduce_kk_kernel<9>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate);
-    else if (KK == 1) MDCV_LAUNCH(wgrad_reduce_kk_kernel<1>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate);
+    if (KK == 9) MDCV_LAUNCH(wgrad_reduce_kk_kernel<9>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate, (const WgradBatchRec*)nullptr);
+    else if (KK == 1) MDCV_LAUNCH(wgrad_reduce_kk_kernel<1>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate, (const WgradBatchRec*)nullptr);
     else MDCV_LAUNCH(wgrad_reduce_kernel, rgrid, dim3(256), KK * 65 * 4, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, KK, Ktot, accumulate);
   }
   MDCV_CHECK_LAUNCH();
@@ -1579,6 +1589,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
   }
 }
 
+int g_wgrad_slots = 512;   // target block count of the generic weight-gradient kernel (tuning hook 20000 + n)
 int g_wgrad_variant = 0;    // 0: 64-pixel steps x 2 stages ; 1: 32 x 3 ; 2: 32 x 4 ; 3: 64 x 3 (one block per CU)
 
 template <int BP, int STAGES, bool SAME>
@@ -1843,6 +1854,8 @@ int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, i
 
 // tuning hook: force the tile configuration of wide (Nout > 64) layers; -1 restores the heuristic
 int mdcv_conv2d_wgrad_set_variant(int v) {   /* tuning hook; 1000 + 100*d + blocks/64: stream-kernel prefetch depth / target blocks */
+  if (v >= 20000 && v < 30000) { g_wgrad_slots = v - 20000; return MDCV_OK; }   /* 20000 + target block count of the generic kernel */
+  if (v >= 30000 && v < 40000) { mdcv_wgrad_stream_tiled_blocks(v - 30000); return MDCV_OK; }   /* 30000 + target block count of the tiled LDS-ring kernel */
   if (v >= 1000) { mdcv_wgrad_stream_tune((v - 1000) / 100, ((v - 1000) % 100) * 64); v = 0; }
   else if (v == 0) mdcv_wgrad_stream_tune(0, 0);
   g_wgrad_variant = v;
@@ -1871,7 +1884,7 @@ int mdcv_conv2d_set_variant(int v) {
 int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot) {
   const int bp = dtype == MDCV_BF16 ? 128 : 64;
   const int tiles = cdiv(Cout, 128) * cdiv(Ktot, 128);
-  const int slots = 512;   // resident blocks: 2 per CU (wide tile 66 KiB; narrow tile 4 x 20 KiB ring)
+  const int slots = g_wgrad_slots;   // resident blocks: 2 per CU (wide tile 66 KiB; narrow tile 4 x 20 KiB ring)
   int s = slots / tiles;                  // never spill into a second, nearly empty round
   const int max_s = cdiv(M, bp * 4);
   if (s > max_s) s = max_s;
@@ -1977,6 +1990,28 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, KH * KW, accumulate, st);
+}
+
+// Weight gradients of `nlayers` convolutions of identical geometry in ONE launch pair (see include/mdcv_hip.h).
+int mdcv_conv2d_wgrad_batched_splits(int dtype, int nlayers, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW,
+                                     int stride, int pad, int dil, int dy_ldc, int x_ldc) {
+  if (nlayers < 1 || g_wgrad_variant == 9 || g_wgrad_variant == 10 || Hin != Hout || Win != Wout) return 0;
+  if (!mdcv_wgrad_stream_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc)) return 0;
+  return mdcv_wgrad_stream_batch_splits(nlayers, B, Hout, Wout, Cin, Cout, dil);
+}
+
+int mdcv_conv2d_wgrad_batched(int dtype, const void* table, int nlayers, int dy_ldc, int x_ldc, float* ws, int splits, int accumulate,
+                              int B, int Hin, int Win, int Cin, int Cin_real, int Hout, int Wout, int Cout, int Cout_real,
+                              int KH, int KW, int stride, int pad, int dil, void* stream) {
+  if (!table || !ws || nlayers < 1 || splits < 1) return MDCV_EARG;
+  if ((Cin & 7) || (Cout & 7) || (dy_ldc & 7) || (x_ldc & 7)) return MDCV_EARG;
+  if (mdcv_conv2d_wgrad_batched_splits(dtype, nlayers, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc) <= 0 ||
+      !mdcv_wgrad_stream_splits_ok(splits, B, Hout, Wout, Cin, Cout, dil))
+    return MDCV_EARG;
+  const int rc = mdcv_wgrad_stream(nullptr, dy_ldc, nullptr, x_ldc, ws, splits, B, Hout, Wout, Cin, Cout, dil, (hipStream_t)stream, table, nlayers);
+  if (rc) return rc;
+  return launch_wgrad_reduce(ws, nullptr, splits, Cout, Cout_real, Cin, Cin_real, 9, accumulate, (hipStream_t)stream,
+                             reinterpret_cast<const WgradBatchRec*>(table), nlayers);
 }
 
 int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,

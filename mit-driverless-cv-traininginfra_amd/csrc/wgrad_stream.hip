@@ -62,7 +62,10 @@ template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[4], bf1
 
 // NCI / NCO: 16-channel blocks of Cin / Cout.  A: co blocks per wave.  PG: position groups.  BP: positions per step (8 KiB of
 // activations).  D: steps in flight behind the one being multiplied.  TGRP: taps staged together in the epilogue (9, 3 or 1).
-template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP>
+// TILED: the block owns a 16*NCO x 9 x 16*NCI slice of a LARGER dW (Cout = tiles_co * 16*NCO, Cin = tiles_ci * 16*NCI): the 128..1024-channel
+// layers of YOLOv3 at 52x52 / 26x26 / 13x13.  Same ring, same fragments; the DMA columns and the slab rows / columns carry the tile offset.
+// 128 co x 64 ci x 9 taps per block fills 24 KiB per 64 positions = 393 FLOP per filled byte (generic 128 x 128 im2col tile: 64).
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false>
 __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a, unsigned dy_bytes, unsigned x_bytes) {
   constexpr int RBX = NCI * 32, RBY = NCO * 32;            // row bytes
   constexpr int LPRX = 2 * NCI, LPRY = 2 * NCO;            // 16-byte slots (= DMA lanes) per row
@@ -81,14 +84,33 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const ring = smem;                          // the activation ring sits at LDS offset 0, the dY stages behind it
   const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
-  if (logical >= a.splits) return;
-  const int split = logical;
+  int split = logical, tile_co = 0, tile_ci = 0;
+  if constexpr (TILED) {
+    static_assert(TGRP == 1, "tiled slabs are written one tap at a time");
+    if (logical >= a.nlayers * a.splits * a.tiles) return;
+    split = logical / a.tiles;                               // = layer * splits + split: the tiles of one split are neighbours on an XCD
+    const int tl = logical - split * a.tiles;                //   (they read the same pixel rows)
+    tile_co = tl / a.tiles_ci; tile_ci = tl - tile_co * a.tiles_ci;
+  } else {
+    if (logical >= a.splits) return;
+  }
+  const int slab_index = split;                              // [layer][split] slab of the workspace
+  const void* dyp = a.dy;
+  const void* xp = a.x;
+  if constexpr (TILED) {
+    const int layer = split / a.splits;
+    split -= layer * a.splits;
+    if (a.table) {                                           // batch of same-geometry layers: this block's operands
+      const WgradBatchRec* rec = reinterpret_cast<const WgradBatchRec*>(a.table) + layer;
+      dyp = rec->dy; xp = rec->x;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pg = wave % PG, tg = wave / PG;
   const int cog = tg / NCI, cit = tg - cog * NCI;          // this wave's co blocks cog*A .. +A-1 and ci block
-  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, dy_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dyp), 0, dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xp), 0, x_bytes, 0x00020000);
 
   const int RS = a.RS, rmask = a.RS - 1;                    // ring rows: a power of two
   unsigned char* const stages = smem + RS * RBX;
@@ -102,10 +124,10 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
   // DMA roles.  activations: lane -> row rrx of the chunk, slot sx; it fetches the logical 16-byte column sx ^ 2*g(row).
   const int rrx = lane / LPRX, sx = lane % LPRX;
   const int gxw = ((rrx & 7) / RX) & (NCI - 1);             // chunks start at ring rows that are multiples of 8
-  const unsigned lane_x = (unsigned)((sx ^ (gxw << 1)) * 16);
+  const unsigned lane_x = (unsigned)((sx ^ (gxw << 1)) * 16) + (unsigned)(tile_ci * (NCI * 32));
   const int rry = lane / LPRY, sy = lane % LPRY;
   const int gyw = ((((wave * RPIY) + rry) & 7) / RY) & (NCO - 1);   // chunk c = wave + 8j starts at row c*RPIY; 8j*RPIY is a multiple of 8
-  const unsigned lane_y = (unsigned)((sy ^ (gyw << 1)) * 16);
+  const unsigned lane_y = (unsigned)((sy ^ (gyw << 1)) * 16) + (unsigned)(tile_co * (NCO * 32));
 
   auto pix_off = [&](int p, unsigned ld2, bool ok) -> unsigned {   // stream position -> byte offset of its pixel row, or OOB (zero fill)
     ok = ok && p >= 0 && p < a.Mq;
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
   // epilogue: the PG partial sums meet in LDS (fixed order), TGRP taps at a time, then coalesced rows of the split's slab
   constexpr int OR = TGRP * CIN + 4;                         // floats per staged row
   float* so = reinterpret_cast<float*>(smem);
-  float* __restrict__ ws = a.ws + (size_t)split * COUT * a.Ktot;
+  float* __restrict__ ws = a.ws + ((size_t)slab_index * a.Cout + (size_t)tile_co * COUT) * a.Ktot + tile_ci * CIN;
 #pragma unroll
   for (int g0 = 0; g0 < 9 / TGRP; ++g0) {
 #pragma unroll
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
     constexpr int V4 = TGRP * CIN / 4;                       // float4 per staged row
     for (int v = tid; v < COUT * V4; v += 512) {
       const int row = v / V4, c4 = (v - row * V4) * 4;
-      *reinterpret_cast<float4*>(ws + (size_t)row * a.Ktot + g0 * TGRP * CIN + c4) = *reinterpret_cast<const float4*>(so + row * OR + c4);
+      *reinterpret_cast<float4*>(ws + (size_t)row * a.Ktot + g0 * TGRP * a.Cin + c4) = *reinterpret_cast<const float4*>(so + row * OR + c4);
     }
     __syncthreads();
   }
@@ -430,10 +452,15 @@ __global__ __launch_bounds__(512) void wgrad7x7_stream_kernel(WgradStreamArgs a,
   }
 }
 
-struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; };
+struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; bool tiled = false; };
 int g_stream_d = 0;        // tuning hook: force the prefetch depth (1..3); 0 = per-configuration default
 int g_stream_blocks = 0;   // tuning hook: force the target block count; 0 = default
 int g_stream_alt = 0;      // tuning hook: alternative wave grids (A = 2, two blocks per CU) for 32->64 and 64->64
+int g_stream_tiled = 1;    // 128 co x 64 ci tiles for the wide layers (Cin % 64 == 0, Cout % 128 == 0); tuning hook: 0 = off
+int g_stream_tiled_blocks = 128;   // target block count of the tiled instantiation.  A block fills its CU (8 waves x 224 VGPRs, 112 KiB LDS), and the
+                           // weight gradients run on a side stream BESIDE the main stream's kernels: with one block on every CU the main stream's
+                           // workgroups wait for whole weight-gradient blocks to retire; 128 blocks leave half the CUs to the main stream
+                           // (YOLOv3 step, same-box A/B: 256 blocks 2033, 192: 2080, 128: 2103, 64: 2033 img/s)
 
 // (Cin, Cout) -> instantiation; false if unsupported
 inline bool stream_cfg(int Cin, int Cout, StreamCfg& c) {
@@ -442,7 +469,8 @@ inline bool stream_cfg(int Cin, int Cout, StreamCfg& c) {
   else if (Cin == 32 && Cout == 32)  c = {2, 2, 2, 4, 128, 2, 9};
   else if (Cin == 32 && Cout == 64)  c = {2, 4, 4, 4, 128, 2, 3};
   else if (Cin == 64 && Cout == 64)  c = {4, 4, 4, 2, 64, 2, 3};
-  else if (Cin == 64 && Cout == 128) c = {4, 8, 4, 1, 64, 2, 1};
+  else if (Cin == 64 && Cout == 128 && !g_stream_tiled) c = {4, 8, 4, 1, 64, 2, 1};
+  else if (g_stream_tiled && Cin % 64 == 0 && Cout % 128 == 0 && Cin <= 4096 && Cout <= 4096) { c = {4, 8, 4, 1, 64, 2, 1}; c.tiled = true; }
   else return false;
   if (g_stream_alt && Cin == 32 && Cout == 64) c = {2, 4, 2, 2, 128, 2, 3};
   if (g_stream_alt && Cin == 64 && Cout == 64) c = {4, 4, 2, 1, 64, 2, 3};
@@ -470,16 +498,16 @@ inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c) {
   return stream_lds(c, W, dil) <= 160 * 1024;
 }
 
-template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP>
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false>
 int launch_stream(const WgradStreamArgs& a, int lds, unsigned dyb, unsigned xb, hipStream_t st) {
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_lds = lds;
   }
-  MDCV_LAUNCH((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
+  MDCV_LAUNCH((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -505,6 +533,7 @@ int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil) {
   if (!stream_cfg(Cin, Cout, c)) return 1;
   const int Mq = B * (H + dil) * (W + dil);
   int s = g_stream_blocks > 0 ? g_stream_blocks : (c.a <= 2 ? 512 : 256);
+  if (c.tiled) s = ((g_stream_blocks > 0 ? g_stream_blocks : g_stream_tiled_blocks) + (Cout / 128) * (Cin / 64) - 1) / ((Cout / 128) * (Cin / 64));   // blocks = splits x channel tiles
   const int max_s = (Mq + c.bp * 4 - 1) / (c.bp * 4);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -520,10 +549,26 @@ bool mdcv_wgrad_stream_splits_ok(int splits, int B, int H, int W, int Cin, int C
   return (Mq + pps - 1) / pps == splits;
 }
 
+// splits per layer for a batch of `nlayers` same-geometry layers through the channel-tiled kernel: blocks = nlayers x splits x tiles ~ one per CU,
+// never less than 4 steps per split; 0 when the geometry does not take the tiled instantiation
+int mdcv_wgrad_stream_batch_splits(int nlayers, int B, int H, int W, int Cin, int Cout, int dil) {
+  StreamCfg c;
+  if (nlayers < 1 || !stream_cfg_geom(Cin, Cout, W, dil, c) || !c.tiled) return 0;
+  const int Mq = B * (H + dil) * (W + dil);
+  const int tiles = (Cout / 128) * (Cin / 64) * nlayers;
+  int s = ((g_stream_blocks > 0 ? g_stream_blocks : g_stream_tiled_blocks) + tiles - 1) / tiles;
+  const int max_s = (Mq + c.bp * 4 - 1) / (c.bp * 4);
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  const int pps = ((Mq + s - 1) / s + c.bp - 1) / c.bp * c.bp;
+  return (Mq + pps - 1) / pps;
+}
+
 int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, int Cin, int Cout,
-                      int dil, hipStream_t st) {
+                      int dil, hipStream_t st, const void* table, int nlayers) {
   StreamCfg c;
   if (!stream_cfg_geom(Cin, Cout, W, dil, c)) return MDCV_EARG;
+  if ((table || nlayers != 1) && !c.tiled) return MDCV_EARG;
   WgradStreamArgs a;
   a.dy = dy; a.x = x; a.ws = ws; a.dy_ldc = dy_ldc; a.x_ldc = x_ldc;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Ktot = 9 * Cin; a.dil = dil;
@@ -533,9 +578,17 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   a.pos_per_split = ((a.Mq + splits - 1) / splits + c.bp - 1) / c.bp * c.bp;
   if ((a.Mq + a.pos_per_split - 1) / a.pos_per_split != splits) return MDCV_EARG;
   a.splits = splits;
-  a.xcd_chunk = (splits + 7) / 8;
+  a.tiles_ci = c.tiled ? Cin / 64 : 1;
+  a.tiles = c.tiled ? (Cout / 128) * a.tiles_ci : 1;
+  a.table = table; a.nlayers = nlayers;
+  a.xcd_chunk = (nlayers * splits * a.tiles + 7) / 8;
   const int lds = stream_lds(c, W, dil);
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
+  if (c.tiled) {
+    if (c.d == 1) return launch_stream<4, 8, 4, 1, 64, 1, 1, true>(a, lds, dyb, xb, st);
+    if (c.d == 2) return launch_stream<4, 8, 4, 1, 64, 2, 1, true>(a, lds, dyb, xb, st);
+    return launch_stream<4, 8, 4, 1, 64, 3, 1, true>(a, lds, dyb, xb, st);
+  }
 #define STREAM_CASE(CI, CO, NCI, NCO, A, PG, BP, TGRP)                                            \
   if (Cin == CI && Cout == CO) {                                                                  \
     if (c.d == 1) return launch_stream<NCI, NCO, A, PG, BP, 1, TGRP>(a, lds, dyb, xb, st);        \
@@ -556,7 +609,8 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   return MDCV_EARG;
 }
 
-void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_alt = d >= 4; g_stream_d = d & 3; g_stream_blocks = blocks; }
+void mdcv_wgrad_stream_tiled_blocks(int blocks) { g_stream_tiled_blocks = blocks > 0 ? blocks : 128; }
+void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_tiled = !(d & 8); g_stream_alt = (d & 4) != 0; g_stream_d = d & 3; g_stream_blocks = blocks; }
 
 // ---- 7x7 stem (see wgrad7x7_stream_kernel)
 static int stem_hpad(int W) { return (3 * (W + 3 + 1) + 31) / 32 * 32; }
@@ -599,6 +653,7 @@ int mdcv_wgrad_stem(const void* dy, int dy_ldc, const void* x, int x_ldc, float*
   a.pos_per_split = ((a.Mq + splits - 1) / splits + 255) / 256 * 256;
   if ((a.Mq + a.pos_per_split - 1) / a.pos_per_split != splits) return MDCV_EARG;
   a.splits = splits;
+  a.tiles = a.tiles_ci = 1; a.table = nullptr; a.nlayers = 1;
   a.xcd_chunk = (splits + 7) / 8;
   const int lds = stem_lds(W);
   static int attr_lds = 0;

@@ -207,5 +207,6 @@ class KeypointNet(nn.Module, FlatParamsMixin):
                 dy0 = plan.emit_bn_act_bwd(a0.grad, y0, bs0, ACT_RELU, 0.0)
                 plan.emit_conv_bwd(cs0, xin_, y0, dy0, x_wgrad=plan.x16)
                 plan.emit_bias_grad(cs0, None, zero_only=True)
+        plan.flush_wgrad_batches()
         plan.mark_ready()
         return plan

@@ -159,6 +159,7 @@ class ResNet(nn.Module, FlatParamsMixin):
         dout_in.__name__ = "nchw_to_nhwc"
         plan.bwd.append((dout_in, ()))
         lower_block_bwd(plan, rec)
+        plan.flush_wgrad_batches()
         plan.mark_ready()
         if need_dx:
             plan.dx_nchw = torch.empty(B, self.in_channels, H, W, dtype=torch.float32, device=device)

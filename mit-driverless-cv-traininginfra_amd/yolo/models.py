@@ -205,6 +205,7 @@ class _DarknetTrainFn(torch.autograd.Function):
         return (None, None, None, None) + (None,) * len(model._plist)
 
 
+_ABLATE = frozenset(v for v in os.environ.get("MDCV_ABLATE", "").split(",") if v)     # timing experiments: results are wrong by construction
 _CHECK_TARGETS = os.environ.get("MDCV_CHECK_TARGETS", "1") == "1"
 _BAD_TARGET_MSG = ("index out of range in build_targets: a target has cx >= 1.0 or cy >= 1.0 (grid cell == grid size), where the reference "
                    "raises IndexError at utils/utils.py:262")
@@ -297,6 +298,10 @@ class _NetPlan(Plan):
 
     def run_bwd_list(self):
         """The backward launch list on the current stream, weight gradients on the side stream (see above)."""
+        if _ABLATE and not getattr(self, "_ablated", False):          # timing experiments only (scripts/ablate.sh): drop launches by name
+            self._ablated = True
+            self.fwd = [(f, a) for f, a in self.fwd if getattr(f, "__name__", "") not in _ABLATE]
+            self.bwd = [(f, a) for f, a in self.bwd if getattr(f, "__name__", "") not in _ABLATE]
         cur = torch.cuda.current_stream()
         if not self.overlap_wgrad or "run" in self.__dict__:                   # (bench.py's per-kernel timing swaps `run`)
             self.run(self.bwd, cur.cuda_stream)
@@ -828,6 +833,7 @@ class Darknet(nn.Module, FlatParamsMixin):
                         continue
                     for sn, off in parts:
                         plan.grad_identity(sn, z.grad.slice(off, sn.act.C))
+            plan.flush_wgrad_batches()
             plan.mark_ready()
         plan.outs = outs
         return plan

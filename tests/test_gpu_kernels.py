@@ -589,7 +589,10 @@ def test_wgrad_shift_kernel(case):
 
 
 WGRAD_STREAM_CASES = [(2, 16, 16, 12, 9, 1), (3, 16, 16, 80, 80, 2), (2, 16, 32, 30, 17, 2), (4, 32, 32, 80, 80, 1), (2, 32, 64, 40, 33, 2),
-                      (3, 64, 64, 26, 20, 1), (2, 64, 128, 80, 80, 2), (1, 64, 128, 104, 104, 1), (1, 32, 64, 208, 208, 1), (5, 64, 64, 5, 4, 1)]
+                      (3, 64, 64, 26, 20, 1), (2, 64, 128, 80, 80, 2), (1, 64, 128, 104, 104, 1), (1, 32, 64, 208, 208, 1), (5, 64, 64, 5, 4, 1),
+                      # channel-tiled instantiation (128 co x 64 ci tiles): the wide layers of YOLOv3 / RektNet's 128 -> 128
+                      (2, 128, 256, 26, 26, 1), (3, 256, 128, 13, 13, 1), (1, 128, 128, 80, 80, 1), (2, 192, 384, 9, 11, 1), (2, 128, 128, 20, 17, 2),
+                      (4, 512, 1024, 13, 13, 1)]
 
 
 @pytest.mark.parametrize("case", WGRAD_STREAM_CASES, ids=[str(c) for c in WGRAD_STREAM_CASES])
@@ -660,6 +663,53 @@ def test_wgrad_stream_kernel_channel_slices(case):
     scale = max(1.0, float(np.abs(ref).max()))
     np.testing.assert_allclose(outs[0], ref, rtol=2e-2, atol=2e-2 * scale)
     np.testing.assert_allclose(outs[0], outs[9], rtol=1e-3, atol=1e-3 * scale)
+
+
+@pytest.mark.parametrize("case", [(3, 2, 128, 256, 13, 13), (4, 4, 256, 128, 26, 26), (5, 1, 64, 128, 20, 9), (2, 8, 128, 128, 8, 8)], ids=str)
+def test_wgrad_batched_layers(case):
+    """mdcv_conv2d_wgrad_batched: the weight gradients of n same-geometry layers in one launch pair (each block works on ONE layer, chosen
+    from a device table; a batched slab reduce writes every layer's OIHW gradient) == torch per layer == the single-layer call."""
+    import struct
+    L = _lib.lib()
+    dt = BF16
+    n, B, Ci, Co, H, W = case
+    g = torch.Generator().manual_seed(n * 100 + Ci + H)
+    xs = [torch.randn(B, Ci, H, W, generator=g) for _ in range(n)]
+    dys = [torch.randn(B, Co, H, W, generator=g) for _ in range(n)]
+    refs = []
+    for x, dy in zip(xs, dys):
+        w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+        F.conv2d(rnd(dt, x), w, None, stride=1, padding=1).backward(rnd(dt, dy))
+        refs.append(w.grad.numpy())
+    xb, dyb = [to_nhwc(x, dt) for x in xs], [to_nhwc(dy, dt) for dy in dys]
+    splits = L.conv2d_wgrad_batched_splits(dt, n, B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, Co, Ci)
+    assert splits >= 1
+    assert L.conv2d_wgrad_batched_splits(dt, n, B, H, W, Ci, H // 2, W // 2, Co, 3, 3, 2, 1, 1, Co, Ci) == 0      # stride 2: no batched kernel
+    assert L.conv2d_wgrad_batched_splits(dt, n, B, H, W, 24, H, W, Co, 3, 3, 1, 1, 1, Co, 24) == 0                 # narrow layer: none either
+    dws = [torch.full((Co, Ci, 3, 3), 7.0, dtype=torch.float32, device="cuda") for _ in range(n)]
+    table = torch.frombuffer(bytearray(b"".join(struct.pack("<QQQ", d.data_ptr(), x.data_ptr(), w.data_ptr()) for d, x, w in zip(dyb, xb, dws))),
+                             dtype=torch.uint8).cuda()
+    ws = torch.full((n * splits * Co * 9 * Ci,), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(L.conv2d_wgrad_batched(dt, table.data_ptr(), n, Co, Ci, ws.data_ptr(), splits, 0, B, H, W, Ci, Ci, H, W, Co, Co, 3, 3, 1, 1, 1, st()),
+            "wgrad batched")
+    torch.cuda.synchronize()
+    for i in range(n):
+        got = dws[i].cpu().numpy()
+        scale = max(1.0, float(np.abs(refs[i]).max()))
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, refs[i], rtol=2e-2, atol=2e-2 * scale, err_msg=f"layer {i}")
+        s1 = L.conv2d_wgrad_splits_geom(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, Co, Ci)
+        ws1 = torch.empty(s1 * Co * 9 * Ci, dtype=torch.float32, device="cuda")
+        dw1 = torch.empty(Co, Ci, 3, 3, dtype=torch.float32, device="cuda")
+        L.check(L.conv2d_wgrad(dt, dyb[i].data_ptr(), Co, xb[i].data_ptr(), Ci, ws1.data_ptr(), s1, dw1.data_ptr(), 0, B, H, W, Ci, Ci, H, W, Co, Co,
+                               3, 3, 1, 1, 1, st()), "wgrad")
+        np.testing.assert_allclose(got, dw1.cpu().numpy(), rtol=1e-3, atol=1e-3 * scale)
+    # accumulate = 1 adds to what is there; wrong arguments are refused
+    L.check(L.conv2d_wgrad_batched(dt, table.data_ptr(), n, Co, Ci, ws.data_ptr(), splits, 1, B, H, W, Ci, Ci, H, W, Co, Co, 3, 3, 1, 1, 1, st()), "acc")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dws[0].cpu().numpy(), 2 * refs[0], rtol=2e-2, atol=4e-2 * max(1.0, float(np.abs(refs[0]).max())))
+    assert L.conv2d_wgrad_batched(dt, None, n, Co, Ci, ws.data_ptr(), splits, 0, B, H, W, Ci, Ci, H, W, Co, Co, 3, 3, 1, 1, 1, st()) == -1
+    assert L.conv2d_wgrad_batched(dt, table.data_ptr(), n, Co, Ci, ws.data_ptr(), splits, 0, B, H, W, Ci, Ci, H, W, Co, Co, 5, 5, 1, 2, 1, st()) == -1
 
 
 def test_wgrad_stream_accumulate_and_determinism():
