@@ -108,7 +108,8 @@ int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const f
                     const float* b2, const void* resid, int ldr, void* out, int ldo, int M, int C, int act, float slope, void* stream);
 int mdcv_bn_act_bwd_reduce_ws_floats(int dtype, int M, int C, int nsums);
 /* partial rows -> statistics -> scale/shift (+ running stats) in ONE launch while rows <= 4096 (a workgroup owns 16 channels and
- * sums their rows itself; larger buffers fall back to mdcv_partial_reduce + mdcv_bn_finalize through `accum`). */
+ * sums their rows itself); larger buffers are first folded to 64 rows IN PLACE by one more launch (no atomics; `partial` is the
+ * caller's scratch and is consumed).  `accum` is unused (kept for the two-stage entry points mdcv_partial_reduce / mdcv_bn_finalize). */
 int mdcv_bn_stats_finalize(const float* partial, int rows, double* accum, double count, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
                            float* invstd, int C, void* stream);
@@ -118,7 +119,8 @@ int mdcv_bn_act_bwd_reduce_finalize(int dtype, const void* dout, int ldd, const 
                                     const float* mean2, const float* invstd2, float* partial_ws, int M, int C, int act, float slope,
                                     double count, const float* gamma1, float* dgamma1, float* dbeta1, float* cA1, float* cB1, float* cC1,
                                     const float* gamma2, float* dgamma2, float* dbeta2, float* cA2, float* cB2, float* cC2, void* stream);
-/* finalize for the fused data-gradient sums: rows x [2][C] partials (sum g, sum g*(y-mean)) -> dgamma, dbeta, cA, cB, cC */
+/* finalize for the fused data-gradient sums: rows x [2][C] partials (sum g, sum g*(y-mean)) -> dgamma, dbeta, cA, cB, cC
+ * (more than 4096 rows are folded in place first, as above: `partial` is consumed) */
 int mdcv_bn_bwd_finalize_rows(const float* partial, int rows, int C, double count, const float* gamma, const float* mean,
                               const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cC, void* stream);
 int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1, int ld1, const float* s1, const float* b1,

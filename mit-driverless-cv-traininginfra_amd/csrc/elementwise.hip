@@ -351,6 +351,44 @@ __device__ __forceinline__ void bwd_coeffs(double sg, double sgx, double count, 
   cC[c] = (float)(-g * is * mg + g * is * is * mu * mgx);
 }
 
+// More than COLFIN_MAX_ROWS partial rows (RektNet's 80x80 x 256-image tensors: 12 800 rows per layer; YOLOv3's 208^2 / 416^2 layers): fold them
+// to COLFIN_FOLD_ROWS rows first, IN PLACE and without atomics: block (column group, j) sums the rows j, j + R, j + 2R, ... of its 16 columns
+// and writes row j -- it is the only block that reads the rows it writes.  Fixed order -> deterministic.  (The earlier path, 128-row blocks +
+// one fp64 atomic per column per block + a finalize launch, took 37 us per RektNet layer.)
+constexpr int COLFIN_FOLD_ROWS = 64;
+__global__ __launch_bounds__(1024) void rows_fold_kernel(float* __restrict__ partial, int rows, int cols) {
+  __shared__ double red[64][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx, j = blockIdx.y;
+  double s = 0.0;
+  if (c < cols) {
+#pragma unroll 4
+    for (int r = j + COLFIN_FOLD_ROWS * ry; r < rows; r += COLFIN_FOLD_ROWS * 64) s += (double)partial[(size_t)r * cols + c];
+  }
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry < 16) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t += red[ry * 4 + k][cx];
+    red[ry * 4][cx] = t;
+  }
+  __syncthreads();
+  if (ry == 0 && c < cols) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k * 4][cx];
+    partial[(size_t)j * cols + c] = (float)t;
+  }
+}
+
+// rows -> at most COLFIN_MAX_ROWS rows (returns the new row count); `partial` is scratch of the caller and is consumed
+static int fold_rows(float* partial, int rows, int cols, hipStream_t st) {
+  if (rows <= COLFIN_MAX_ROWS) return rows;
+  MDCV_LAUNCH(rows_fold_kernel, dim3((unsigned)cdiv(cols, 16), (unsigned)COLFIN_FOLD_ROWS), dim3(1024), 0, st, partial, rows, cols);
+  return COLFIN_FOLD_ROWS;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(1024) void bn_colfinal_kernel(ColFinArgs a) {
   __shared__ double red[3][64][16];
@@ -697,11 +735,8 @@ int mdcv_bn_stats_finalize(const float* partial, int rows, double* accum, double
                            float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
                            float* invstd, int C, void* stream) {
   if (!partial || !accum || rows < 1 || !gamma || !beta || !scale || !shift || !mean || !invstd) return MDCV_EARG;
-  if (rows > COLFIN_MAX_ROWS) {
-    const int rc = mdcv_partial_reduce(partial, rows, 2, C, accum, stream);
-    if (rc) return rc;
-    return mdcv_bn_finalize(accum, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C, stream);
-  }
+  rows = fold_rows(const_cast<float*>(partial), rows, 2 * C, (hipStream_t)stream);      // (large buffers: folded in place first)
+  MDCV_CHECK_LAUNCH();
   ColFinArgs a = {};
   a.partial = partial; a.rows = rows; a.nsums = 2; a.C = C; a.count = count; a.gamma = gamma; a.beta = beta; a.rm = running_mean;
   a.rv = running_var; a.momentum = momentum; a.eps = eps; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
@@ -827,6 +862,8 @@ int mdcv_bn_act_bwd_reduce_finalize(int dtype, const void* dout, int ldd, const 
 int mdcv_bn_bwd_finalize_rows(const float* partial, int rows, int C, double count, const float* gamma, const float* mean,
                               const float* invstd, float* dgamma, float* dbeta, float* cA, float* cB, float* cC, void* stream) {
   if (!partial || rows < 1 || !gamma || !mean || !invstd || !dgamma || !dbeta || !cA || !cB || !cC) return MDCV_EARG;
+  rows = fold_rows(const_cast<float*>(partial), rows, 2 * C, (hipStream_t)stream);
+  MDCV_CHECK_LAUNCH();
   ColFinArgs f = {};
   f.partial = partial; f.rows = rows; f.nsums = 2; f.C = C; f.count = count;
   f.g1 = gamma; f.mean1 = mean; f.is1 = invstd; f.dg1 = dgamma; f.db1 = dbeta; f.cA1 = cA; f.cB1 = cB; f.cC1 = cC;

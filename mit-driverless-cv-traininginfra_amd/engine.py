@@ -470,7 +470,11 @@ class Plan:
     fuse_bn = os.environ.get("MDCV_BN_FUSE", "1") == "1"
 
     fuse_skip = int(os.environ.get("MDCV_BN_FUSE_SKIP", "13"))
-    fuse_max_rows = int(os.environ.get("MDCV_BN_FUSE_MAXROWS", "4096"))   # partial rows the column-owner finalize is asked to sum
+    # Data gradients whose fused sums would take more than this many partial rows (RektNet's 80^2 x 256 tensors: 12 800; YOLOv3's 208^2 / 416^2
+    # layers) keep the stand-alone reduce pass.  The finalize can take them since round 2 (rows beyond 4096 are folded in place first,
+    # csrc/elementwise.hip), but the fused store loops still lose on these HBM-bound layers: RektNet 31.99k -> 31.34k img/s, YOLOv3 2136 -> 2118
+    # with the limit lifted (same-box A/B).
+    fuse_max_rows = int(os.environ.get("MDCV_BN_FUSE_MAXROWS", "4096"))
 
     def _fuse_pays(self, geom):
         """Per-geometry choice between the fused sums and the stand-alone reduce pass (MDCV_BN_FUSE_SKIP = bit mask of the classes
