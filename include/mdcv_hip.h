@@ -150,6 +150,16 @@ int mdcv_maxpool2x2_fwd(int dtype, const void* in, int ldi, void* out, int ldo, 
 int mdcv_maxpool2x2_bwd(int dtype, const void* dout, int ldo, const unsigned char* idx, void* din, int ldi, int B, int H, int W, int C, int stride,
                         void* stream);
 
+/* generic forms of the two (models.py:74-88 builds nn.MaxPool2d(size, stride, (size - 1) // 2) and nn.Upsample(scale_factor = stride) for any
+ * size / stride): window k <= 15, -inf padding (pad < k), Ho = (H + 2*pad - k) / stride + 1; idx = kh*k + kw of the first maximum;
+ * backward gathers over the windows that contain an input pixel (no atomics).  H, W = input dims. */
+int mdcv_maxpool_fwd(int dtype, const void* in, int ldi, void* out, int ldo, unsigned char* idx, int B, int H, int W, int C, int k, int stride,
+                     int pad, void* stream);
+int mdcv_maxpool_bwd(int dtype, const void* dout, int ldo, const unsigned char* idx, void* din, int ldi, int B, int H, int W, int C, int k, int stride,
+                     int pad, void* stream);
+int mdcv_upsample_fwd(int dtype, const void* in, int ldi, void* out, int ldo, int B, int H, int W, int C, int scale, void* stream);
+int mdcv_upsample_bwd(int dtype, const void* dout, int ldo, void* din, int ldi, int B, int H, int W, int C, int scale, void* stream);
+
 /* ---- YOLOLayer.forward (models.py:140-220) + build_targets / bbox_iou (utils/utils.py:163-275)
  * logits NHWC, channel = a*(5+C)+attr.  anchors_scaled = anchors/stride, fp32 [A][2].  targets fp32 [B][T][5].
  * train: out7[0] += loss, out7[1..6] += (x,y,w,h,obj,noobj) parts; dlogits = d loss / d logits (* *gscale if given). */

@@ -680,6 +680,116 @@ __global__ void maxpool2x2_bwd_kernel(const T* __restrict__ dout, int ldo, const
   }
 }
 
+// ---------------------------------------------------------------- generic max-pool and nearest upsample (reference models.py:74-88 builds
+// nn.MaxPool2d(size, stride, (size - 1) // 2) and nn.Upsample(scale_factor = stride) for ANY size / stride; the bundled cfgs only use the
+// 2x2 pools and the x2 upsample above).  Padding never wins (-inf); the first maximum in (kh, kw) scan order wins like torch;
+// idx = kh*k + kw (k <= 15), so backward is a gather over the windows that contain the input pixel: no atomics, deterministic.
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ in, int ldi, T* __restrict__ out, int ldo, unsigned char* __restrict__ idx,
+                                   int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = C / VEC;
+  const long long total = (long long)B * Ho * Wo * CV;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const long long op = i / CV;
+    const int ow = (int)(op % Wo);
+    const long long t = op / Wo;
+    const int oh = (int)(t % Ho), b = (int)(t / Ho);
+    float best[VEC]; unsigned char bi[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    for (int kh = 0; kh < k; ++kh) {
+      const int h = oh * stride - pad + kh;
+      if (h < 0 || h >= H) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        const int w = ow * stride - pad + kw;
+        if (w < 0 || w >= W) continue;
+        float v[VEC];
+        ET<T>::unpack(*reinterpret_cast<const uint4*>(in + (((long long)b * H + h) * W + w) * ldi + cv * VEC), v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (v[e] > best[e]) { best[e] = v[e]; bi[e] = (unsigned char)(kh * k + kw); }
+      }
+    }
+    *reinterpret_cast<uint4*>(out + op * ldo + cv * VEC) = ET<T>::pack(best);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) idx[op * C + cv * VEC + e] = bi[e];
+  }
+}
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dout, int ldo, const unsigned char* __restrict__ idx, T* __restrict__ din, int ldi,
+                                   int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = C / VEC;
+  const long long total = (long long)B * H * W * CV;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const long long ip = i / CV;
+    const int w = (int)(ip % W);
+    const long long t = ip / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    float g[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+    // windows that contain (h, w): oh*stride - pad <= h <= oh*stride - pad + k - 1
+    int oh0 = h + pad - k + 1; oh0 = oh0 > 0 ? (oh0 + stride - 1) / stride : 0;
+    int ow0 = w + pad - k + 1; ow0 = ow0 > 0 ? (ow0 + stride - 1) / stride : 0;
+    const int oh1 = min(Ho - 1, (h + pad) / stride), ow1 = min(Wo - 1, (w + pad) / stride);
+    for (int oh = oh0; oh <= oh1; ++oh)
+      for (int ow = ow0; ow <= ow1; ++ow) {
+        const int pos = (h + pad - oh * stride) * k + (w + pad - ow * stride);
+        const long long op = ((long long)b * Ho + oh) * Wo + ow;
+        float d[VEC];
+        ET<T>::unpack(*reinterpret_cast<const uint4*>(dout + op * ldo + cv * VEC), d);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) if (idx[op * C + cv * VEC + e] == pos) g[e] += d[e];
+      }
+    *reinterpret_cast<uint4*>(din + ip * ldi + cv * VEC) = ET<T>::pack(g);
+  }
+}
+template <typename T>
+__global__ void upsample_fwd_kernel(const T* __restrict__ in, int ldi, T* __restrict__ out, int ldo, int B, int H, int W, int C, int sc) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = C / VEC;
+  const int Ws = W * sc, Hs = H * sc;
+  const long long total = (long long)B * Hs * Ws * CV;         // one thread per OUTPUT vector
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const long long op = i / CV;
+    const int ow = (int)(op % Ws);
+    const long long t = op / Ws;
+    const int oh = (int)(t % Hs), b = (int)(t / Hs);
+    const long long ip = ((long long)b * H + oh / sc) * W + ow / sc;
+    *reinterpret_cast<uint4*>(out + op * ldo + cv * VEC) = *reinterpret_cast<const uint4*>(in + ip * ldi + cv * VEC);
+  }
+}
+template <typename T>
+__global__ void upsample_bwd_kernel(const T* __restrict__ dout, int ldo, T* __restrict__ din, int ldi, int B, int H, int W, int C, int sc) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = C / VEC;
+  const long long total = (long long)B * H * W * CV;           // one thread per INPUT vector: sum of its sc x sc outputs (fixed order)
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const long long ip = i / CV;
+    const int w = (int)(ip % W);
+    const long long t = ip / W;
+    const int h = (int)(t % H), b = (int)(t / H);
+    float s[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[e] = 0.f;
+    for (int dy = 0; dy < sc; ++dy)
+      for (int dx = 0; dx < sc; ++dx) {
+        const long long op = ((long long)b * sc * H + sc * h + dy) * sc * W + sc * w + dx;
+        float v[VEC];
+        ET<T>::unpack(*reinterpret_cast<const uint4*>(dout + op * ldo + cv * VEC), v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] += v[e];
+      }
+    *reinterpret_cast<uint4*>(din + ip * ldi + cv * VEC) = ET<T>::pack(s);
+  }
+}
+
 static unsigned ew_grid(long long total) {
   long long g = (total + 255) / 256;
   if (g > 8192) g = 8192;
@@ -980,6 +1090,55 @@ int mdcv_maxpool2x2_bwd(int dtype, const void* dout, int ldo, const unsigned cha
   const long long n = (long long)B * H * W * C;
   if (dtype == MDCV_BF16) MDCV_LAUNCH(maxpool2x2_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)dout, ldo, idx, (bf16_t*)din, ldi, B, H, W, C, stride);
   else if (dtype == MDCV_F32) MDCV_LAUNCH(maxpool2x2_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)dout, ldo, idx, (float*)din, ldi, B, H, W, C, stride);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+// generic forms (any window <= 15 / stride / scale); Ho = (H + 2*pad - k) / stride + 1
+int mdcv_maxpool_fwd(int dtype, const void* in, int ldi, void* out, int ldo, unsigned char* idx, int B, int H, int W, int C, int k, int stride,
+                     int pad, void* stream) {
+  if (!in || !out || !idx || (C & 7) || k < 1 || k > 15 || stride < 1 || pad < 0 || 2 * pad >= k + (k == 1) || H + 2 * pad < k || W + 2 * pad < k) return MDCV_EARG;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * Ho * Wo * C;
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(maxpool_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, idx, B, H, W, C, k, stride, pad, Ho, Wo);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(maxpool_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, idx, B, H, W, C, k, stride, pad, Ho, Wo);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_maxpool_bwd(int dtype, const void* dout, int ldo, const unsigned char* idx, void* din, int ldi, int B, int H, int W, int C, int k, int stride,
+                     int pad, void* stream) {
+  if (!dout || !din || !idx || (C & 7) || k < 1 || k > 15 || stride < 1 || pad < 0 || 2 * pad >= k + (k == 1) || H + 2 * pad < k || W + 2 * pad < k) return MDCV_EARG;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * H * W * C;
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(maxpool_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)dout, ldo, idx, (bf16_t*)din, ldi, B, H, W, C, k, stride, pad, Ho, Wo);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(maxpool_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)dout, ldo, idx, (float*)din, ldi, B, H, W, C, k, stride, pad, Ho, Wo);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_upsample_fwd(int dtype, const void* in, int ldi, void* out, int ldo, int B, int H, int W, int C, int scale, void* stream) {
+  if (!in || !out || (C & 7) || scale < 1 || scale > 64) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * H * W * scale * scale * C;
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(upsample_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)in, ldi, (bf16_t*)out, ldo, B, H, W, C, scale);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(upsample_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, B, H, W, C, scale);
+  else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_upsample_bwd(int dtype, const void* dout, int ldo, void* din, int ldi, int B, int H, int W, int C, int scale, void* stream) {
+  if (!dout || !din || (C & 7) || scale < 1 || scale > 64) return MDCV_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * H * W * C;
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(upsample_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)dout, ldo, (bf16_t*)din, ldi, B, H, W, C, scale);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(upsample_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)dout, ldo, (float*)din, ldi, B, H, W, C, scale);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;

@@ -590,10 +590,13 @@ class Darknet(nn.Module, FlatParamsMixin):
                 h, w = h * int(d["stride"]), w * int(d["stride"])
             elif k == "maxpool":
                 ks, st_ = int(d["size"]), int(d["stride"])
-                if ks != 2 or st_ not in (1, 2):
-                    raise NotImplementedError("only the 2x2 max-pools of yolo_baseline_tiny.cfg (stride 2, or stride 1 + zero pad) are lowered")
-                if st_ == 2:
-                    h, w = h // 2, w // 2
+                if ks == 2 and st_ == 1:
+                    pass                                 # ZeroPad2d((0,1,0,1)) + MaxPool2d(2, 1): same size (models.py:77-79)
+                else:                                    # MaxPool2d(size, stride, (size - 1) // 2)
+                    if ks > 15:
+                        raise NotImplementedError("max-pool windows up to 15x15 are lowered")
+                    pp = (ks - 1) // 2
+                    h, w = (h + 2 * pp - ks) // st_ + 1, (w + 2 * pp - ks) // st_ + 1
             elif k == "route":
                 src = [res(i, int(t)) for t in d["layers"].split(",")]
                 c = sum(shp[s][0] for s in src)
@@ -713,17 +716,24 @@ class Darknet(nn.Module, FlatParamsMixin):
                 a = cur.act
                 idx = torch.empty(z.act.M * z.act.C, dtype=torch.uint8, device=device)
                 plan.keep.append(idx)
-                plan.call(plan.fwd, L.maxpool2x2_fwd, dt, a.ptr, a.ldc, z.act.ptr, z.act.ldc, idx.data_ptr(), B, a.H, a.W, a.C, st_)
-                recs.append(("maxpool", cur, z, idx, st_))
+                ks = int(d["size"])
+                if ks == 2 and st_ in (1, 2):            # the pools of yolo_baseline_tiny.cfg
+                    plan.call(plan.fwd, L.maxpool2x2_fwd, dt, a.ptr, a.ldc, z.act.ptr, z.act.ldc, idx.data_ptr(), B, a.H, a.W, a.C, st_)
+                    recs.append(("maxpool", cur, z, idx, st_, 0))
+                else:
+                    plan.call(plan.fwd, L.maxpool_fwd, dt, a.ptr, a.ldc, z.act.ptr, z.act.ldc, idx.data_ptr(), B, a.H, a.W, a.C, ks, st_, (ks - 1) // 2)
+                    recs.append(("maxpool", cur, z, idx, st_, ks))
                 outs[i] = z
                 cur = z
             elif k == "upsample":
-                if int(d["stride"]) != 2:
-                    raise NotImplementedError("only x2 nearest upsample is lowered")
+                sc = int(d["stride"])
                 z = TNode(out_act(i), name="up%d" % i)
                 a = cur.act
-                plan.call(plan.fwd, L.upsample2x_fwd, dt, a.ptr, a.ldc, z.act.ptr, z.act.ldc, B, a.H, a.W, a.C)
-                recs.append(("upsample", cur, z))
+                if sc == 2:
+                    plan.call(plan.fwd, L.upsample2x_fwd, dt, a.ptr, a.ldc, z.act.ptr, z.act.ldc, B, a.H, a.W, a.C)
+                else:
+                    plan.call(plan.fwd, L.upsample_fwd, dt, a.ptr, a.ldc, z.act.ptr, z.act.ldc, B, a.H, a.W, a.C, sc)
+                recs.append(("upsample", cur, z, sc))
                 outs[i] = z
                 cur = z
             elif k == "route":
@@ -805,25 +815,30 @@ class Darknet(nn.Module, FlatParamsMixin):
                     plan.grad_identity(a, z.grad)
                     plan.grad_identity(b, z.grad)
                 elif kind == "upsample":
-                    _, xn, z = r
+                    _, xn, z, sc = r
                     if z.gstate == "none":
                         continue
                     out, add = plan.grad_target(xn)
+                    up_bwd = (L.upsample2x_bwd, ()) if sc == 2 else (L.upsample_bwd, (sc,))
                     if add is None:
-                        plan.call(plan.bwd, L.upsample2x_bwd, dt, z.grad.ptr, z.grad.ldc, out.ptr, out.ldc, B, xn.act.H, xn.act.W, xn.act.C)
+                        plan.call(plan.bwd, up_bwd[0], dt, z.grad.ptr, z.grad.ldc, out.ptr, out.ldc, B, xn.act.H, xn.act.W, xn.act.C, *up_bwd[1])
                     else:
                         tmp = plan.new_act(B, xn.act.H, xn.act.W, xn.act.C)
-                        plan.call(plan.bwd, L.upsample2x_bwd, dt, z.grad.ptr, z.grad.ldc, tmp.ptr, tmp.ldc, B, xn.act.H, xn.act.W, xn.act.C)
+                        plan.call(plan.bwd, up_bwd[0], dt, z.grad.ptr, z.grad.ldc, tmp.ptr, tmp.ldc, B, xn.act.H, xn.act.W, xn.act.C, *up_bwd[1])
                         plan.call(plan.bwd, L.bn_act_fwd, dt, tmp.ptr, tmp.ldc, None, None, None, 0, None, None, add.ptr, add.ldc,
                                   out.ptr, out.ldc, out.M, out.C, ACT_NONE, 0.0)
                 elif kind == "maxpool":
-                    _, xn, z, idx, st_ = r
+                    _, xn, z, idx, st_, ks = r
                     if z.gstate == "none":
                         continue
                     out, add = plan.grad_target(xn)
                     tgt = out if add is None else plan.new_act(B, xn.act.H, xn.act.W, xn.act.C)
-                    plan.call(plan.bwd, L.maxpool2x2_bwd, dt, z.grad.ptr, z.grad.ldc, idx.data_ptr(), tgt.ptr, tgt.ldc, B, xn.act.H, xn.act.W,
-                              xn.act.C, st_)
+                    if ks == 0:
+                        plan.call(plan.bwd, L.maxpool2x2_bwd, dt, z.grad.ptr, z.grad.ldc, idx.data_ptr(), tgt.ptr, tgt.ldc, B, xn.act.H, xn.act.W,
+                                  xn.act.C, st_)
+                    else:
+                        plan.call(plan.bwd, L.maxpool_bwd, dt, z.grad.ptr, z.grad.ldc, idx.data_ptr(), tgt.ptr, tgt.ldc, B, xn.act.H, xn.act.W,
+                                  xn.act.C, ks, st_, (ks - 1) // 2)
                     if add is not None:
                         plan.call(plan.bwd, L.bn_act_fwd, dt, tgt.ptr, tgt.ldc, None, None, None, 0, None, None, add.ptr, add.ldc,
                                   out.ptr, out.ldc, out.M, out.C, ACT_NONE, 0.0)

@@ -902,3 +902,53 @@ def test_shift_conv_dilation2(case):
     torch.testing.assert_close(outs[-20][0], outs[-21][0], rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(outs[-20][2], outs[-21][2], rtol=1e-2, atol=2e-2)
     torch.testing.assert_close(outs[-20][1], outs[-21][1], rtol=2e-3, atol=0.5)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("k,s,H,W", [(3, 1, 13, 17), (3, 2, 16, 20), (5, 1, 9, 9), (2, 2, 12, 8), (13, 1, 19, 19), (1, 1, 5, 7), (3, 3, 14, 11)])
+def test_maxpool_generic(dt, k, s, H, W):
+    """nn.MaxPool2d(k, s, (k - 1) // 2) for any window / stride (reference models.py:74-84 builds it from the cfg): forward values, the
+    argmax-routed backward (ties: first maximum in scan order, like torch) against torch on the CPU."""
+    L = _lib.lib()
+    B, C = 2, 16
+    p = (k - 1) // 2
+    g = torch.Generator().manual_seed(k * 100 + s * 10 + H)
+    x = rnd(dt, torch.randn(B, C, H, W, generator=g))
+    x[0, :, 2:5, 2:5] = 0.5                                      # a plateau: ties inside windows
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, k, s, p)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    dy = rnd(dt, torch.randn(B, C, Ho, Wo, generator=g))
+    ref.backward(dy)
+    xb, dyb = to_nhwc(x, dt), to_nhwc(dy, dt)
+    out = torch.empty(B, Ho, Wo, C, dtype=TD[dt], device="cuda")
+    idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device="cuda")
+    dx = torch.full((B, H, W, C), 7.0, dtype=TD[dt], device="cuda")
+    L.check(L.maxpool_fwd(dt, xb.data_ptr(), C, out.data_ptr(), C, idx.data_ptr(), B, H, W, C, k, s, p, st()), "maxpool_fwd")
+    L.check(L.maxpool_bwd(dt, dyb.data_ptr(), C, idx.data_ptr(), dx.data_ptr(), C, B, H, W, C, k, s, p, st()), "maxpool_bwd")
+    np.testing.assert_array_equal(to_nchw(out, dt, C).numpy(), ref.detach().numpy())
+    tol = 0 if dt == F32 else 2e-2                                # bf16: sums of several routed gradients round once more
+    np.testing.assert_allclose(to_nchw(dx, dt, C).numpy(), xr.grad.numpy(), rtol=tol, atol=tol)
+    assert L.maxpool_fwd(dt, xb.data_ptr(), C, out.data_ptr(), C, idx.data_ptr(), B, H, W, C, 17, s, 8, st()) == -1
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("sc,H,W", [(3, 5, 7), (4, 8, 8), (1, 4, 4), (2, 6, 10)])
+def test_upsample_generic(dt, sc, H, W):
+    """nn.Upsample(scale_factor = stride, nearest) for any integer stride (models.py:86-88) and its backward (sum over the sc x sc copies)."""
+    L = _lib.lib()
+    B, C = 2, 24
+    g = torch.Generator().manual_seed(sc * 10 + H)
+    x = rnd(dt, torch.randn(B, C, H, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr, scale_factor=sc, mode="nearest")
+    dy = rnd(dt, torch.randn(B, C, H * sc, W * sc, generator=g))
+    ref.backward(dy)
+    xb, dyb = to_nhwc(x, dt), to_nhwc(dy, dt)
+    out = torch.empty(B, H * sc, W * sc, C, dtype=TD[dt], device="cuda")
+    dx = torch.empty(B, H, W, C, dtype=TD[dt], device="cuda")
+    L.check(L.upsample_fwd(dt, xb.data_ptr(), C, out.data_ptr(), C, B, H, W, C, sc, st()), "upsample_fwd")
+    L.check(L.upsample_bwd(dt, dyb.data_ptr(), C, dx.data_ptr(), C, B, H, W, C, sc, st()), "upsample_bwd")
+    np.testing.assert_array_equal(to_nchw(out, dt, C).numpy(), ref.detach().numpy())
+    tol = 1e-5 if dt == F32 else 3e-2
+    np.testing.assert_allclose(to_nchw(dx, dt, C).numpy(), xr.grad.numpy(), rtol=tol, atol=tol)

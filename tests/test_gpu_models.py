@@ -536,6 +536,66 @@ def test_tiny_cfg_structure_and_train_step_vs_oracle(tmp_path):
         assert relerr(p.grad.cpu(), r) < 2e-3, (n, relerr(p.grad.cpu(), r))
 
 
+def test_cfg_with_other_pool_and_upsample_sizes_vs_oracle(tmp_path):
+    """The reference builds nn.MaxPool2d(size, stride, (size - 1) // 2) and nn.Upsample(scale_factor = stride) for whatever the cfg says
+    (models.py:74-88).  A cfg with 3x3 / stride-2 and 5x5 / stride-1 pools and a x4 upsample: one fp32 train step (losses, every parameter
+    gradient) and the eval rows against the CPU oracle."""
+    from mdcv.yolo.models import Darknet
+    from oracle import yolo_oracle as yo
+    head = ("[net]\nwidth=64\nheight=64\nonnx_height=64\nclasses=1\nchannels=3\n"
+            "yolo_masks=3,4,5|0,1,2\nyolo_scales=8,2\nvalidate_uri=dataset/validate.csv\ntrain_uri=dataset/train.csv\n"
+            "weights_uri=none\nstart_weights_dim=18,18\nnum_train_images=-1\nnum_validate_images=-1\nleaky_slope=0.1\n"
+            "conv_activation=leaky\nbuild_targets_ignore_thresh=0.5\nconf_thresh=0.8\nnms_thresh=0.25\niou_thresh=0.5\n\n")
+
+    def conv(f, k):
+        return f"[convolutional]\nfilters={f}\nsize={k}\nstride=1\n\n"
+    mp = "[maxpool]\nsize=3\nstride=2\n\n"
+    body = (conv(16, 3) + mp + conv(32, 3) + mp + conv(64, 3) + mp + "[maxpool]\nsize=5\nstride=1\n\n" + conv(32, 1) + conv("preyolo", 1) +
+            "[yolo]\n\n[route]\nlayers = -3\n\n" + conv(16, 1) + "[upsample]\nstride=4\n\n[route]\nlayers = -1, 2\n\n" + conv(32, 3) +
+            conv("preyolo", 1) + "[yolo]\n")
+    os.makedirs(tmp_path / "dataset")
+    (tmp_path / "dataset" / "train.csv").write_text('"4,6|6,10|10,8|12,20|20,16|24,36"\n')
+    (tmp_path / "pools.cfg").write_text(head + body)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        torch.manual_seed(7)
+        net = Darknet("pools.cfg", 2.0, 1.6, 25.0, 0.1, False, precision="fp32")
+        net.save_weights("p.weights")
+        orc = yo.DarknetOracle("pools.cfg", anchors=yo.read_anchor_row("dataset/train.csv"))
+        orc.load_weights("p.weights", [18, 18])
+    finally:
+        os.chdir(cwd)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(3, 3, 64, 64, generator=g)
+    tg = torch.zeros(3, 4, 5)
+    for b in range(3):
+        tg[b, :b + 1, 1:3] = torch.rand(b + 1, 2, generator=g) * 0.9 + 0.05
+        tg[b, :b + 1, 3:5] = torch.rand(b + 1, 2, generator=g) * 0.28 + 0.05
+    for k in orc.trainable():
+        orc.params[k].requires_grad_(True)
+    ref = orc.forward(x, tg)
+    ref[0].sum().backward()
+    net = net.cuda().train()
+    out = net(x.cuda(), tg.cuda())
+    out[0].backward()
+    close(torch.stack([o.detach() for o in out]).cpu(), torch.stack([r.detach() for r in ref]), rtol=2e-4)
+    refs = {}
+    for n, p in net.named_parameters():
+        _, i, mod, leaf = n.split(".")
+        refs[n] = orc.params[("conv" if mod.startswith("conv") else "bn") + f"{i}.{leaf}"].grad
+    gmax = max(float(r.abs().max()) for r in refs.values())
+    for n, p in net.named_parameters():          # (a gradient that is round-off in the reference itself -- 1e-7 of the rest -- is held to an absolute bound)
+        err = float((p.grad.cpu() - refs[n]).abs().max())
+        assert err <= 2e-3 * max(float(refs[n].abs().max()), 1e-4 * gmax), (n, err, float(refs[n].abs().max()), gmax)
+    net.eval()
+    with torch.no_grad():
+        ev = net(x.cuda()).cpu()
+        rows = orc.forward(x, None, bn_train=False)
+    assert tuple(ev.shape) == tuple(rows.shape) == (3, 3 * (8 * 8 + 32 * 32), 6)
+    close(ev, rows, rtol=1e-3, atol=1e-3)
+
+
 def test_hipgraph_replay_matches_eager():
     """MDCV_GRAPH=1: forward/backward launch lists captured into hipGraphs reproduce the eager step bit for bit."""
     z = load("mini_darknet.npz")
