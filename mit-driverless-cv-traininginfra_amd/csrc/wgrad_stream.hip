@@ -27,6 +27,11 @@
 namespace {
 
 constexpr unsigned OOB = 0x80000000u;
+#ifdef MDCV_WST_NOPIPE
+constexpr bool g_pipe_enabled = false;
+#else
+constexpr bool g_pipe_enabled = true;
+#endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -247,6 +252,15 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
 #else
   const bool late = NSUB == 1 && wave >= 4;                  // (two sub-steps per step: the skewed schedule spills)
 #endif
+  // channel-tiled instantiation: the reads run a few fragments ahead of the multiplies (wgrad_stream_pipe.inc, scripts/gen_wgrad_pipeline.py)
+  constexpr bool kPipe = TILED && NSUB == 2 && PG == 1 && A == 4 && g_pipe_enabled;
+  bf16x8_t fa2[2][4];
+  if constexpr (kPipe) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa2[n][i] = bf16x8_t{};
+  }
   auto step = [&](int t, int rho0, bool more, int t_new, int rho_new) {
 #ifdef MDCV_WST_NOCOMPUTE
     if (more) issue(t_new, rho_new);
@@ -258,11 +272,17 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
 #ifndef MDCV_WST_NODMA
     if (more) issue(t_new, rho_new);
 #endif
+    if constexpr (kPipe) {
+      const unsigned ystage = (unsigned)((t % (D + 1)) * YSTAGE);
+      const unsigned xs0 = (unsigned)(rho0 * RBX);
+#include "wgrad_stream_pipe.inc"
+    } else {
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-      if (late && s > 0) mfmas();
-      reads(t, rho0, s);
-      if (!late) mfmas();
+      for (int s = 0; s < NSUB; ++s) {
+        if (late && s > 0) mfmas();
+        reads(t, rho0, s);
+        if (!late) mfmas();
+      }
     }
   };
 
