@@ -810,9 +810,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
                      (long long)a.Nout * a.Ktot * (long long)sizeof(T) < (1LL << 31);
   if (a.Nout > 64) {
     int v = g_conv_variant;
-    if (v < 0) {   // measured on MI355X (scripts/bench_conv.py): tall tiles once the grid is >= 4 waves of CUs, half-width tiles
+    if (v < 0) {   // measured on MI355X (scripts/conv_ab.py): tall tiles once the grid is >= 4 waves of CUs, half-width tiles
       const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);   // when 128x128 would leave CUs idle
-      const int nk = a.Ktot / (4 * ET<T>::VEC);      // long K loops profit from the 3-stage DMA ring (scripts/bench_conv.py)
+      const int nk = a.Ktot / (4 * ET<T>::VEC);      // long K loops profit from the 3-stage DMA ring (scripts/conv_ab.py)
       v = t128 >= (g_conv_midgrid ? g_conv_midgrid : 1024) ? 11 : (nk >= 100 ? 9 : (t128 >= 300 ? 6 : 7));
       if (g_conv_fuse_small && MODE != 0 && a.fuse.y && nk <= 8 && v == 11) v = 6;
       if (g_conv_deep_small && nk >= g_conv_deep_small && (v == 6 || v == 7)) v += 3;   // 3-stage ring for the mid / sparse grids too

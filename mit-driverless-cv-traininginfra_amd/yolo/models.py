@@ -205,6 +205,7 @@ class _DarknetTrainFn(torch.autograd.Function):
         return (None, None, None, None) + (None,) * len(model._plist)
 
 
+_TAIL_PROBE = os.environ.get("MDCV_TAIL_PROBE", "0") == "1"
 _ABLATE = frozenset(v for v in os.environ.get("MDCV_ABLATE", "").split(",") if v)     # timing experiments: results are wrong by construction
 _CHECK_TARGETS = os.environ.get("MDCV_CHECK_TARGETS", "1") == "1"
 _BAD_TARGET_MSG = ("index out of range in build_targets: a target has cx >= 1.0 or cy >= 1.0 (grid cell == grid size), where the reference "
@@ -319,6 +320,10 @@ class _NetPlan(Plan):
             if rc:
                 raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
         if used:
+            if _TAIL_PROBE:                                  # how long the side stream runs on after the main stream's last backward kernel
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur); e1.record(side)
+                self.__dict__.setdefault("tail_events", []).append((e0, e1))
             cur.wait_stream(side)
 
     def run_backward(self, gout):

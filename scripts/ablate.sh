@@ -1,9 +1,10 @@
 #!/bin/bash
-# Which launches is the YOLOv3 step time sensitive to?  Re-times the step with one family of launches dropped from the lists
+# Which launches is a training step's time sensitive to?  Re-times the step with one family of launches dropped from the lists
 # (MDCV_ABLATE, results are wrong by construction: timing only).  The difference to the full step is what removing / hiding that
-# family could buy at most.
+# family could buy at most.   usage: ablate.sh [yolo|rektnet]
 R=${GRAFT_REPO_ROOT:-/root/repo}
-run() { MDCV_ABLATE="$1" python $R/bench.py --workload yolo --no-cpu-baseline --no-breakdown --no-fp32 --steps 20 --warmup 6 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-60s %8.1f img/s %7.3f ms' % ('$1' or 'full', l['value'], l['ms_per_step']))"; }
+WL=${1:-yolo}
+run() { MDCV_ABLATE="$1" python $R/bench.py --workload $WL --no-cpu-baseline --no-breakdown --no-fp32 --steps 20 --warmup 6 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-60s %8.1f img/s %7.3f ms' % ('$1' or 'full', l['value'], l['ms_per_step']))"; }
 run ""
 run "conv2d_wgrad"
 run "mdcv_bn_act_fwd"
