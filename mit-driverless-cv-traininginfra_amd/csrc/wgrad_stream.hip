@@ -61,6 +61,9 @@ template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[1], bf1
 template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[2], bf16x8_t& f) {
   asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(f) : "n"(N) : "memory");
 }
+template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[8], bf16x8_t& f) {
+  asm volatile("s_waitcnt lgkmcnt(%9)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]), "+v"(f) : "n"(N) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[4], bf16x8_t& f) {
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(f) : "n"(N) : "memory");
 }
@@ -70,19 +73,22 @@ template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[4], bf1
 // TILED: the block owns a 16*NCO x 9 x 16*NCI slice of a LARGER dW (Cout = tiles_co * 16*NCO, Cin = tiles_ci * 16*NCI): the 128..1024-channel
 // layers of YOLOv3 at 52x52 / 26x26 / 13x13.  Same ring, same fragments; the DMA columns and the slab rows / columns carry the tile offset.
 // 128 co x 64 ci x 9 taps per block fills 24 KiB per 64 positions = 393 FLOP per filled byte (generic 128 x 128 im2col tile: 64).
-template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false>
-__global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a, unsigned dy_bytes, unsigned x_bytes) {
+// NW: waves per block (8, or 4 for the one-wave-per-SIMD instantiation whose waves own all 128 output channels: A = 8, 288 accumulator
+// registers, 17 fragment reads per 72 MFMAs instead of 13 per 36).
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void wgrad3x3_stream_kernel(WgradStreamArgs a, unsigned dy_bytes, unsigned x_bytes) {
   constexpr int RBX = NCI * 32, RBY = NCO * 32;            // row bytes
   constexpr int LPRX = 2 * NCI, LPRY = 2 * NCO;            // 16-byte slots (= DMA lanes) per row
   constexpr int RPIX = 64 / LPRX, RPIY = 64 / LPRY;        // rows per 1 KiB DMA instruction
   constexpr int RX = 8 / NCI, RY = 8 / NCO;                // rows per 256-byte bank period
-  constexpr int DYI = BP / RPIY / 8;                       // dY DMA instructions per wave per step
-  constexpr int NI = 1 + DYI;                              // DMA instructions per wave per step
+  constexpr int DYI = BP / RPIY / NW;                      // dY DMA instructions per wave per step
+  constexpr int XI = BP / RPIX / NW;                       // activation DMA instructions per wave per step
+  constexpr int NI = XI + DYI;                             // DMA instructions per wave per step
   constexpr int NSUB = BP / 32 / PG;                       // 32-position sub-steps per wave per step
-  constexpr int TG = 8 / PG;
+  constexpr int TG = NW / PG;
   constexpr int YSTAGE = BP * RBY;
   constexpr int CIN = NCI * 16, COUT = NCO * 16;
-  static_assert(BP / RPIX == 8, "one activation DMA per wave per step");
+  static_assert(BP / RPIX == NW * XI && XI >= 1 && (NW * RPIY) % 8 == 0, "whole activation DMAs per wave per step");
   static_assert(TG == (NCO / A) * NCI && NSUB >= 1 && DYI >= 1, "wave grid");
   static_assert(9 % TGRP == 0, "tap groups");
 
@@ -151,14 +157,15 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
   // step t: the BP new activation rows (p_begin + t*BP + hpad ..) and the BP dY rows of the step
   auto issue = [&](int t, int rho_new) {
     const int p0 = p_begin + t * BP;
-    {
-      const int rho = (rho_new + wave * RPIX) & rmask;
-      issue_x(p0 + a.hpad + wave * RPIX, rho);
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const int chunk = wave + NW * j;
+      issue_x(p0 + a.hpad + chunk * RPIX, (rho_new + chunk * RPIX) & rmask);
     }
     unsigned char* sY = stages + (t % (D + 1)) * YSTAGE;
 #pragma unroll
     for (int j = 0; j < DYI; ++j) {
-      const int chunk = wave + 8 * j;
+      const int chunk = wave + NW * j;
       const int p = p0 + chunk * RPIY + rry;
       const unsigned off = pix_off(p, ldy2, p < p_end);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t*)(sY + chunk * 1024), 16, (int)(off == OOB ? OOB : off + lane_y), 0, 0, 0);
@@ -250,16 +257,16 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
 #ifdef MDCV_WST_NOSKEW
   const bool late = false;
 #else
-  const bool late = NSUB == 1 && wave >= 4;                  // (two sub-steps per step: the skewed schedule spills)
+  const bool late = NSUB == 1 && wave >= NW / 2;             // (two sub-steps per step: the skewed schedule spills)
 #endif
   // channel-tiled instantiation: the reads run a few fragments ahead of the multiplies (wgrad_stream_pipe.inc, scripts/gen_wgrad_pipeline.py)
-  constexpr bool kPipe = TILED && NSUB == 2 && PG == 1 && A == 4 && g_pipe_enabled;
-  bf16x8_t fa2[2][4];
+  constexpr bool kPipe = TILED && NSUB == 2 && PG == 1 && (A == 4 || A == 8) && g_pipe_enabled;
+  bf16x8_t fa2[2][A];
   if constexpr (kPipe) {
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa2[n][i] = bf16x8_t{};
+      for (int i = 0; i < A; ++i) fa2[n][i] = bf16x8_t{};
   }
   auto step = [&](int t, int rho0, bool more, int t_new, int rho_new) {
 #ifdef MDCV_WST_NOCOMPUTE
@@ -275,7 +282,11 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
     if constexpr (kPipe) {
       const unsigned ystage = (unsigned)((t % (D + 1)) * YSTAGE);
       const unsigned xs0 = (unsigned)(rho0 * RBX);
+      if constexpr (A == 4) {
 #include "wgrad_stream_pipe.inc"
+      } else {
+#include "wgrad_stream_pipe8.inc"
+      }
     } else {
 #pragma unroll
       for (int s = 0; s < NSUB; ++s) {
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
   // prologue: the 2*hpad rows below the first step's new rows, then D steps ahead
   {
     const int nch = 2 * a.hpad / RPIX;
-    for (int c = wave; c < nch; c += 8) issue_x(p_lo + c * RPIX, c * RPIX);
+    for (int c = wave; c < nch; c += NW) issue_x(p_lo + c * RPIX, c * RPIX);
   }
   int issued = 0;
   int rho_new = (2 * a.hpad) & rmask;                        // ring row of the next step's first new activation row
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_stream_kernel(WgradStreamArgs a,
       __syncthreads();
     }
     constexpr int V4 = TGRP * CIN / 4;                       // float4 per staged row
-    for (int v = tid; v < COUT * V4; v += 512) {
+    for (int v = tid; v < COUT * V4; v += NW * 64) {
       const int row = v / V4, c4 = (v - row * V4) * 4;
       *reinterpret_cast<float4*>(ws + (size_t)row * a.Ktot + g0 * TGRP * a.Cin + c4) = *reinterpret_cast<const float4*>(so + row * OR + c4);
     }
@@ -472,11 +483,14 @@ __global__ __launch_bounds__(512) void wgrad7x7_stream_kernel(WgradStreamArgs a,
   }
 }
 
-struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; bool tiled = false; };
+struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; bool tiled = false; int nw = 8; };
 int g_stream_d = 0;        // tuning hook: force the prefetch depth (1..3); 0 = per-configuration default
 int g_stream_blocks = 0;   // tuning hook: force the target block count; 0 = default
 int g_stream_alt = 0;      // tuning hook: alternative wave grids (A = 2, two blocks per CU) for 32->64 and 64->64
 int g_stream_tiled = 1;    // 128 co x 64 ci tiles for the wide layers (Cin % 64 == 0, Cout % 128 == 0); tuning hook: 0 = off
+int g_stream_w4 = 0;       // tuning hook (MDCV_WGRAD_VARIANT=30001): tiled instantiation with 4 waves per block, each owning all 128 output channels
+                           // (A = 8: 17 transpose reads per 72 MFMAs instead of 13 per 36, 456 registers, one wave per SIMD).  Measured SLOWER: 52^2 128->256
+                           // 99 vs 80 us on 256 blocks, 149 vs 97 us on 128; YOLOv3 step 2044 vs 2142 img/s -- one wave per SIMD cannot cover the read latency
 int g_stream_tiled_blocks = 128;   // target block count of the tiled instantiation.  A block fills its CU (8 waves x 224 VGPRs, 112 KiB LDS), and the
                            // weight gradients run on a side stream BESIDE the main stream's kernels: with one block on every CU the main stream's
                            // workgroups wait for whole weight-gradient blocks to retire; 128 blocks leave half the CUs to the main stream
@@ -490,7 +504,10 @@ inline bool stream_cfg(int Cin, int Cout, StreamCfg& c) {
   else if (Cin == 32 && Cout == 64)  c = {2, 4, 4, 4, 128, 2, 3};
   else if (Cin == 64 && Cout == 64)  c = {4, 4, 4, 2, 64, 2, 3};
   else if (Cin == 64 && Cout == 128 && !g_stream_tiled) c = {4, 8, 4, 1, 64, 2, 1};
-  else if (g_stream_tiled && Cin % 64 == 0 && Cout % 128 == 0 && Cin <= 4096 && Cout <= 4096) { c = {4, 8, 4, 1, 64, 2, 1}; c.tiled = true; }
+  else if (g_stream_tiled && Cin % 64 == 0 && Cout % 128 == 0 && Cin <= 4096 && Cout <= 4096) {
+    c = {4, 8, 4, 1, 64, 2, 1}; c.tiled = true;
+    if (g_stream_w4) { c.a = 8; c.nw = 4; }
+  }
   else return false;
   if (g_stream_alt && Cin == 32 && Cout == 64) c = {2, 4, 2, 2, 128, 2, 3};
   if (g_stream_alt && Cin == 64 && Cout == 64) c = {4, 4, 2, 1, 64, 2, 3};
@@ -518,16 +535,16 @@ inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c) {
   return stream_lds(c, W, dil) <= 160 * 1024;
 }
 
-template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false>
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8>
 int launch_stream(const WgradStreamArgs& a, int lds, unsigned dyb, unsigned xb, hipStream_t st) {
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_lds = lds;
   }
-  MDCV_LAUNCH((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
+  MDCV_LAUNCH((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -604,6 +621,11 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   a.xcd_chunk = (nlayers * splits * a.tiles + 7) / 8;
   const int lds = stream_lds(c, W, dil);
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
+  if (c.tiled && c.nw == 4) {
+    if (c.d == 1) return launch_stream<4, 8, 8, 1, 64, 1, 1, true, 4>(a, lds, dyb, xb, st);
+    if (c.d == 2) return launch_stream<4, 8, 8, 1, 64, 2, 1, true, 4>(a, lds, dyb, xb, st);
+    return launch_stream<4, 8, 8, 1, 64, 3, 1, true, 4>(a, lds, dyb, xb, st);
+  }
   if (c.tiled) {
     if (c.d == 1) return launch_stream<4, 8, 4, 1, 64, 1, 1, true>(a, lds, dyb, xb, st);
     if (c.d == 2) return launch_stream<4, 8, 4, 1, 64, 2, 1, true>(a, lds, dyb, xb, st);
@@ -629,7 +651,10 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   return MDCV_EARG;
 }
 
-void mdcv_wgrad_stream_tiled_blocks(int blocks) { g_stream_tiled_blocks = blocks > 0 ? blocks : 128; }
+void mdcv_wgrad_stream_tiled_blocks(int blocks) {      // 30000 + n: block target ; 30001 / 30002: 4-wave / 8-wave form
+  if (blocks == 1 || blocks == 2) { g_stream_w4 = blocks == 1; return; }
+  g_stream_tiled_blocks = blocks > 0 ? blocks : 128;
+}
 void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_tiled = !(d & 8); g_stream_alt = (d & 4) != 0; g_stream_d = d & 3; g_stream_blocks = blocks; }
 
 // ---- 7x7 stem (see wgrad7x7_stream_kernel)
