@@ -6,7 +6,8 @@ import sys
 
 d = json.load(open(sys.argv[1]))
 agg = collections.OrderedDict()
-for name, ms, args in d:
+for rec in d:
+    name, ms, args = rec[0], rec[1], rec[2]
     if name in ("mdcv_conv2d", "mdcv_conv2d_dgrad_bnsums"):
         B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW, stride, pad, dil = args[:12]
         mode = args[-1]
