@@ -362,8 +362,11 @@ template <> struct FragSwz<float> {
 typedef __attribute__((address_space(3))) void lds_void_t;
 int g_conv_no_ut = 0;    // tuning/A-B: 1 disables the uniform-tap address path
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE, bool EPI = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, unsigned in_bytes, unsigned w_bytes) {
+// ALLCLS (MODE 2 only): the workgroup computes ALL FOUR output-parity classes of its tile of dY positions, one after the other (classes
+// have 1, 2, 2 and 4 taps: every workgroup gets the same 9 taps of work, and the dY rows a tile reads come from HBM once instead of
+// once per class launch -- 177 MB of dY per launch at 208^2 x 64 channels).  Needs even Hout / Wout (all classes share one Hs x Ws grid).
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE, bool EPI = false, bool ALLCLS = false>
+__global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a0, unsigned in_bytes, unsigned w_bytes) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int VEC = ET<T>::VEC;
   constexpr int BK = 4 * VEC;
@@ -382,16 +385,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
   constexpr unsigned OOB = 0x80000000u;                   // >= num_records of any descriptor we build (sizes are < 2 GiB)
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
-  const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
-  if (logical >= a.tiles_total) return;
+  static_assert(!ALLCLS || MODE == 2, "ALLCLS is a stride-2 data-gradient form");
+  const int logical = (int)(blockIdx.x & 7) * a0.xcd_chunk + (int)(blockIdx.x >> 3);
+  if (logical >= a0.tiles_total) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = logical / a.tiles_n, tile_n = logical % a.tiles_n;
+  const int tile_m = logical / a0.tiles_n, tile_n = logical % a0.tiles_n;
   const int lrow = lane >> 2;                              // row inside a chunk this lane fills
   const int kv = (lane & 3) ^ swz(lrow);                   // logical k-vector it fetches for that slot
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a0.in), 0, in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a0.w), 0, w_bytes, 0x00020000);
+  constexpr int NCLS = ALLCLS ? 4 : 1;
+#pragma unroll 1
+  for (int cls = 0; cls < NCLS; ++cls) {
+  ConvArgs a = a0;
+  if constexpr (ALLCLS) {                                  // class (ph, pw): its live taps kh = kh0 + 2i, kw = kw0 + 2j (see conv2d_impl)
+    a.ph = cls >> 1; a.pw = cls & 1;
+    a.kh0 = (a.ph + a.pad) & 1; a.kw0 = (a.pw + a.pad) & 1;
+    a.nkh = (a.KH - a.kh0 + 1) / 2; a.nkw = (a.KW - a.kw0 + 1) / 2;
+    a.Ktot = a.nkh * a.nkw * a.Cin;
+    a.fuse.row_base = cls * ((a.M + 127) >> 7);
+    if (cls) __syncthreads();                              // the previous class's epilogue is done with the LDS
+  }
 
   int bh[NPA], bw[NPA], ib[NPA];
   bool rv[NPA];
@@ -718,8 +734,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
       if (tile_m * BM + g0 < a.M)                      // block-uniform: a 256-row tile's second group may start past the last pixel,
         fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (tile_m * BM + g0) >> 7);   // and that row is not in the caller's buffer
     }
-    return;
-  }
+  } else {
   for (int v = tid; v < BM * VPRO; v += NT) {
     const int row = v / VPRO, cv = v - row * VPRO;
     const int m = tile_m * BM + row, n = tile_n * BN + cv * VEC;
@@ -742,9 +757,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a, uns
       *reinterpret_cast<uint4*>(out + (pix * a.out_ldc + n)) = d;
     }
   }
+  }
+  }   // class loop
 }
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE, bool EPI = false>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool FUSE, bool EPI = false, bool ALLCLS = false>
 int launch_conv_glds_f(const ConvArgs& a0, hipStream_t st, int B) {
   ConvArgs a = a0;
   constexpr int NWV = WM * WN;
@@ -752,7 +769,7 @@ int launch_conv_glds_f(const ConvArgs& a0, hipStream_t st, int B) {
   constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
   constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;   // + statistics / fused-sum scratch (NW*BN floats <= WM*2*BN)
   static bool attr_set = false;
-  auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN, STAGES, UT, FUSE, EPI>;
+  auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN, STAGES, UT, FUSE, EPI, ALLCLS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
@@ -768,8 +785,13 @@ int launch_conv_glds_f(const ConvArgs& a0, hipStream_t st, int B) {
   return MDCV_OK;
 }
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES, bool UT, bool ALLCLS = false>
 int launch_conv_glds_ut(const ConvArgs& a, hipStream_t st, int B) {
+  if constexpr (ALLCLS) {
+    if (a.epi.oscale || a.epi.act) return MDCV_EARG;
+    if (a.fuse.y) return launch_conv_glds_f<T, MODE, BM, BN, WM, WN, STAGES, UT, true, false, true>(a, st, B);
+    return launch_conv_glds_f<T, MODE, BM, BN, WM, WN, STAGES, UT, false, false, true>(a, st, B);
+  }
   if constexpr (MODE != 0) {                    // the fused BatchNorm-backward sums exist for data gradients only
     if (a.fuse.y) return launch_conv_glds_f<T, MODE, BM, BN, WM, WN, STAGES, UT, true>(a, st, B);
   }
@@ -780,11 +802,15 @@ int launch_conv_glds_ut(const ConvArgs& a, hipStream_t st, int B) {
   return launch_conv_glds_f<T, MODE, BM, BN, WM, WN, STAGES, UT, false>(a, st, B);
 }
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES = 2>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES = 2, bool ALLCLS = false>
 int launch_conv_glds(const ConvArgs& a, hipStream_t st, int B) {
   constexpr int BK = 4 * ET<T>::VEC;
   // uniform-tap fast path: K tiles never straddle a tap; the generic stride-2 dgrad (MODE 1, stride 2) keeps the per-lane cursor
   const bool ut = (a.Cin % BK == 0) && !(MODE == 1 && a.stride != 1) && g_conv_no_ut == 0;
+  if constexpr (ALLCLS) {                       // (bf16 layers of a Darknet: Cin is a multiple of 32; others keep the four launches)
+    if (!ut) return MDCV_EARG;
+    return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, true, true>(a, st, B);
+  }
   if (ut) return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, true>(a, st, B);
   return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, false>(a, st, B);
 }
@@ -863,6 +889,24 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
 
 int g_conv_tall_s2 = 1;      // (set_variant 18 = off; +0.3 % on the YOLOv3 step) the tall narrow tiles for the parity-class launches too
 int g_conv_deep_s2 = 1;      // (set_variant 20 = off; +0.6 % on the YOLOv3 step, same-box A/B) 3-stage ring for the parity-class launches of the stride-2 data gradients
+
+int g_conv_s2_allcls = 1;    // (set_variant 16 = off) one launch for the four parity classes of a stride-2 data gradient (conv_glds_kernel ALLCLS)
+
+// all four classes in one launch: same tile choice as the per-class dispatch below (a.M = positions of ONE class)
+static int dispatch_dgrad_s2_all(const ConvArgs& a, hipStream_t st, int B) {
+  typedef bf16_t T;
+  if (g_conv_tall_s2 && g_conv_tall_narrow && a.Nout <= 64 && a.M >= g_conv_tall_narrow * 1024) {
+    if (a.Nout > 32) return launch_conv_glds<T, 2, 256, 64, 4, 2, 3, true>(a, st, B);
+    if (a.Nout > 16) return launch_conv_glds<T, 2, 256, 32, 4, 1, 2, true>(a, st, B);
+    return MDCV_EARG;
+  }
+  // Measured per layer of yolo_baseline at batch 32 (one launch vs four): 208->416 279 -> 204 us, 104->208 139 -> 125, 52->104 98 -> 86, but
+  // 26->52 (338 tiles of 128 x 128: one sparse round of long workgroups) 136 -> 183 and 13->26 140 -> 139: only grids of >= 512 tiles take it.
+  const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
+  if (a.Nout <= 64 || t128 < 512) return MDCV_EARG;
+  if (t128 >= 1024) return launch_conv_glds<T, 2, 256, 128, 4, 2, 3, true>(a, st, B);
+  return launch_conv_glds<T, 2, 128, 128, 2, 2, 3, true>(a, st, B);
+}
 
 template <typename T>
 int dispatch_dgrad_s2(const ConvArgs& a, hipStream_t st, int B) {
@@ -1746,6 +1790,15 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   const bool small = (long long)B * Hin * Win * in_ldc * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31) &&
                      (long long)Nout * KH * KW * Cin * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31);
   if (mode == 1 && stride == 2 && dil == 1 && small && (g_conv_variant != 0 || fuse)) {
+    if (g_conv_s2_allcls && dtype == MDCV_BF16 && KH == 3 && KW == 3 && pad == 1 && !(Hout & 1) && !(Wout & 1) && (Cin % 32) == 0 && g_conv_deep_s2 &&
+        g_conv_tall_s2) {
+      ConvArgs c = a;                              // every class: Hs x Ws = Hout/2 x Wout/2 positions; taps and Ktot are set per class in the kernel
+      c.Hs = Hout / 2; c.Ws = Wout / 2;
+      c.M = B * c.Hs * c.Ws;
+      c.fuse.row_base = 0;
+      const int rc = dispatch_dgrad_s2_all(c, st, B);
+      if (rc != MDCV_EARG) return rc;              // (geometries without an all-class instantiation fall through to the four launches)
+    }
     int row_base = 0;
     for (int cls = 0; cls < 4; ++cls) {
       ConvArgs c = a;
@@ -1873,6 +1926,7 @@ int mdcv_conv2d_set_variant(int v) {
   if (v >= 60 && v < 93) { g_conv_deep_small = v - 60; return MDCV_OK; }
   if (v >= 30 && v < 60) { g_conv_deep_narrow = v - 30; return MDCV_OK; }
   if (v == 20 || v == 21) { g_conv_deep_s2 = v - 20; return MDCV_OK; }
+  if (v == 16 || v == 17) { g_conv_s2_allcls = v - 16; return MDCV_OK; }
   if (v == 18 || v == 19) { g_conv_tall_s2 = v - 18; return MDCV_OK; }
   if (v == 22 || v == 23) { g_conv_deep_narrow32 = v - 22; return MDCV_OK; }
   if (v >= 2000 && v < 3000) { g_conv_tall_narrow = v - 2000; return MDCV_OK; }

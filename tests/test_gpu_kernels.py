@@ -146,6 +146,53 @@ def test_conv_fwd_dgrad_wgrad(case, dt):
     np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-4 if dt == F32 else 2e-2, atol=(1e-4 if dt == F32 else 2e-2) * scale)
 
 
+@pytest.mark.parametrize("case", [(8, 128, 208, 208, 256, False), (8, 32, 416, 416, 64, False), (6, 128, 208, 160, 256, True)], ids=str)
+def test_stride2_dgrad_all_classes_in_one_launch(case):
+    """Large stride-2 data gradients (>= 512 tiles, even sizes, bf16) run the four output-parity classes inside ONE launch (each workgroup
+    walks the classes of its tile of dY positions: conv_glds_kernel ALLCLS); set_variant(16) restores the four launches.  Both == torch,
+    and the two forms agree bit for bit (same products, same K order per class); with the fused BatchNorm sums too."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, H, W, Co, fused = case
+    g = torch.Generator().manual_seed(B + Ci + H)
+    Ho, Wo = H // 2, W // 2
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    dy = torch.randn(B, Co, Ho, Wo, generator=g)
+    add = torch.randn(B, Ci, H, W, generator=g)
+    xr = torch.zeros(B, Ci, H, W, requires_grad=True)
+    torch.set_num_threads(16)
+    F.conv2d(xr, rnd(dt, w), None, stride=2, padding=1).backward(rnd(dt, dy))
+    ref = (xr.grad + rnd(dt, add)).numpy()
+    _, wd = pack(dt, w)
+    dyb, addb = to_nhwc(dy, dt), to_nhwc(add, dt)
+    outs, parts = {}, {}
+    yb = to_nhwc(torch.randn(B, Ci, H, W, generator=g), dt) if fused else None
+    coef = [torch.rand(Ci, generator=g).cuda() + 0.5 for _ in range(3)] if fused else None
+    for variant in (17, 16):
+        L.check(L.conv2d_set_variant(variant))
+        try:
+            dx = torch.full((B, H, W, Ci), 7.0, dtype=TD[dt], device="cuda")
+            if fused:
+                rows = L.conv2d_dgrad_bnsums_rows(dt, B, Ho, Wo, Co, H, W, Ci, 3, 3, 2, 1, 1, Co)
+                assert rows > 0
+                part = torch.full((rows, 2, Ci), float("nan"), dtype=torch.float32, device="cuda")
+                L.check(L.conv2d_dgrad_bnsums(dt, dyb.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, addb.data_ptr(), Ci, B, Ho, Wo, Co, H, W, Ci,
+                                              3, 3, 2, 1, 1, yb.data_ptr(), Ci, coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), 1, 0.1,
+                                              part.data_ptr(), st()), "dgrad bnsums")
+                parts[variant] = part.sum(0).cpu().numpy()
+                assert np.isfinite(parts[variant]).all()
+            else:
+                L.check(L.conv2d(dt, 1, dyb.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, None, addb.data_ptr(), Ci, None,
+                                 B, Ho, Wo, Co, H, W, Ci, 3, 3, 2, 1, 1, st()), "dgrad")
+            outs[variant] = to_nchw(dx, dt, Ci).numpy()
+        finally:
+            L.conv2d_set_variant(17)
+    np.testing.assert_allclose(outs[17], ref, rtol=3e-2, atol=3e-2)
+    np.testing.assert_array_equal(outs[17], outs[16])
+    if fused:
+        np.testing.assert_allclose(parts[17], parts[16], rtol=1e-4, atol=1e-2)
+
+
 VARIANT_CASES = [(2, 72, 15, 17, 255, 3, 1, 1, 1, True), (2, 136, 14, 14, 144, 3, 2, 1, 1, False), (3, 256, 9, 9, 160, 1, 1, 0, 1, False),
                  (2, 96, 12, 12, 192, 3, 1, 2, 2, True)]
 
