@@ -415,8 +415,7 @@ class FlatParamsMixin:
         pl = getattr(self, "_plist", None)
         if pl is None:
             return False
-        return pl[0].data_ptr() == self._flat_ptrs[0] and pl[-1].data_ptr() == self._flat_ptrs[-1] and \
-            pl[len(pl) // 2].data_ptr() == self._flat_ptrs[len(pl) // 2]
+        return all(p.data_ptr() == q for p, q in zip(pl, self._flat_ptrs))       # every parameter still is its view of the flat buffer (~15 us)
 
     def _grad_view(self, p):
         off, n = self._goff[id(p)]
