@@ -57,7 +57,28 @@ __global__ void yolo_assign_kernel(const float* __restrict__ tg, const float* __
   }
 }
 
+static unsigned grid_for(long long n) { long long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// out[0] += head loss ; out[1..6] += (x,y,w,h,obj,noobj) parts (models.py:199-211,332,338).  A launch of its own: folding it into the
+// last block of the loss kernel needs an agent-scope fence per block, and on eight L2s that tripled the loss kernel (11 -> 33 us).
+__global__ void yolo_finalize_kernel(const double* __restrict__ acc, float xy_loss, float wh_loss, float obj_loss, float noobj_loss,
+                                     float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double nM = acc[6], nN = acc[7];
+  const float lx = xy_loss * (float)(acc[0] / nM), ly = xy_loss * (float)(acc[1] / nM);      // mean over an empty selection = NaN,
+  const float lw = wh_loss * (float)(acc[2] / nM), lh = wh_loss * (float)(acc[3] / nM);      // exactly like the reference
+  const float lob = obj_loss * (float)(acc[4] / nM), lno = noobj_loss * (float)(acc[5] / nN);
+  const float loss = lx + ly + lw + lh + lno + lob;
+  out[0] += loss;
+  out[1] += lx; out[2] += ly; out[3] += lw; out[4] += lh; out[5] += lob; out[6] += lno;
+}
+
+// workspace of one head before the assignment: owner = -1 (no target), everything behind it (ignore, err, acc) = 0
+__global__ void yolo_init_kernel(int* __restrict__ ws, long long cells, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) ws[i] = i < cells ? -1 : 0;
+}
 
 struct LossArgs {
   const void* logits; const float* tg; const float* anchors; const int* owner; const int* ignore; double* acc;
@@ -114,19 +135,6 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(LossArgs a) {
   }
 }
 
-// out[0] += head loss ; out[1..6] += (x,y,w,h,obj,noobj) parts (models.py:199-211,332,338)
-__global__ void yolo_finalize_kernel(const double* __restrict__ acc, float xy_loss, float wh_loss, float obj_loss, float noobj_loss,
-                                     float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double nM = acc[6], nN = acc[7];
-  const float lx = xy_loss * (float)(acc[0] / nM), ly = xy_loss * (float)(acc[1] / nM);      // mean over an empty selection = NaN,
-  const float lw = wh_loss * (float)(acc[2] / nM), lh = wh_loss * (float)(acc[3] / nM);      // exactly like the reference
-  const float lob = obj_loss * (float)(acc[4] / nM), lno = noobj_loss * (float)(acc[5] / nN);
-  const float loss = lx + ly + lw + lh + lno + lob;
-  out[0] += loss;
-  out[1] += lx; out[2] += ly; out[3] += lw; out[4] += lh; out[5] += lob; out[6] += lno;
-}
-
 struct GradArgs {
   const void* logits; void* dlogits; const float* tg; const float* anchors; const int* owner; const int* ignore; const double* acc;
   const float* gscale;
@@ -134,11 +142,38 @@ struct GradArgs {
   float xy_loss, wh_loss, obj_loss, noobj_loss;
 };
 
-// d(loss)/d(logits) for every channel of every pixel; class channels and pad channels get exact zeros
+// d(loss)/d(logits) of one (pixel, channel) element; class channels and pad channels are exact zeros
+template <typename T>
+__device__ __forceinline__ float yolo_grad_elem(const GradArgs& a, const T* __restrict__ lg, long long pix, int ch, float nM, float nN) {
+  const HeadGeom& g = a.g;
+  const int attrs = 5 + g.C;
+  float gr = 0.f;
+  const int an = ch / attrs, at = ch - an * attrs;
+  if (an < g.A && at < 5) {
+    const int i = (int)(pix % g.Gw);
+    long long r = pix / g.Gw;
+    const int j = (int)(r % g.Gh), b = (int)(r / g.Gh);
+    const int t = a.owner[(((size_t)b * g.A + an) * g.Gh + j) * g.Gw + i];
+    const float s = ET<T>::ld(lg + pix * g.ldc + ch);
+    if (t >= 0) {
+      int src, gi, gj, best; bool over; float gx, gy, gw, gh;
+      assign_row(a.tg, a.anchors, g, b, t, src, gi, gj, best, over, gx, gy, gw, gh);
+      if (at == 0) { const float p = sigmoidf_(s); gr = a.xy_loss * 2.f * (p - (gx - (float)gi)) / nM * p * (1.f - p); }
+      else if (at == 1) { const float p = sigmoidf_(s); gr = a.xy_loss * 2.f * (p - (gy - (float)gj)) / nM * p * (1.f - p); }
+      else if (at == 2) gr = a.wh_loss * 2.f * (s - logf(gw / a.anchors[2 * an] + 1e-16f)) / nM;
+      else if (at == 3) gr = a.wh_loss * 2.f * (s - logf(gh / a.anchors[2 * an + 1] + 1e-16f)) / nM;
+      else { const float p = sigmoidf_(s), pq = p * (1.f - p); gr = a.obj_loss * (p - 1.f) * pq / fmaxf(pq, 1e-12f) / nM; }
+    } else if (at == 4 && a.ignore[j * g.Gw + i] == 0) {
+      const float p = sigmoidf_(s), pq = p * (1.f - p);
+      gr = a.noobj_loss * p * pq / fmaxf(pq, 1e-12f) / nN;
+    }
+  }
+  return gr;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void yolo_grad_kernel(GradArgs a) {
   const HeadGeom& g = a.g;
-  const int attrs = 5 + g.C;
   const long long total = (long long)g.B * g.Gh * g.Gw * a.Cpad;
   const T* lg = reinterpret_cast<const T*>(a.logits);
   T* dl = reinterpret_cast<T*>(a.dlogits);
@@ -147,29 +182,58 @@ __global__ __launch_bounds__(256) void yolo_grad_kernel(GradArgs a) {
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int ch = (int)(e % a.Cpad);
     const long long pix = e / a.Cpad;
-    float gr = 0.f;
-    const int an = ch / attrs, at = ch - an * attrs;
-    if (an < g.A && at < 5) {
-      const int i = (int)(pix % g.Gw);
-      long long r = pix / g.Gw;
-      const int j = (int)(r % g.Gh), b = (int)(r / g.Gh);
-      const int t = a.owner[(((size_t)b * g.A + an) * g.Gh + j) * g.Gw + i];
-      const float s = ET<T>::ld(lg + pix * g.ldc + ch);
-      if (t >= 0) {
-        int src, gi, gj, best; bool over; float gx, gy, gw, gh;
-        assign_row(a.tg, a.anchors, g, b, t, src, gi, gj, best, over, gx, gy, gw, gh);
-        if (at == 0) { const float p = sigmoidf_(s); gr = a.xy_loss * 2.f * (p - (gx - (float)gi)) / nM * p * (1.f - p); }
-        else if (at == 1) { const float p = sigmoidf_(s); gr = a.xy_loss * 2.f * (p - (gy - (float)gj)) / nM * p * (1.f - p); }
-        else if (at == 2) gr = a.wh_loss * 2.f * (s - logf(gw / a.anchors[2 * an] + 1e-16f)) / nM;
-        else if (at == 3) gr = a.wh_loss * 2.f * (s - logf(gh / a.anchors[2 * an + 1] + 1e-16f)) / nM;
-        else { const float p = sigmoidf_(s), pq = p * (1.f - p); gr = a.obj_loss * (p - 1.f) * pq / fmaxf(pq, 1e-12f) / nM; }
-      } else if (at == 4 && a.ignore[j * g.Gw + i] == 0) {
-        const float p = sigmoidf_(s), pq = p * (1.f - p);
-        gr = a.noobj_loss * p * pq / fmaxf(pq, 1e-12f) / nN;
-      }
-    }
-    ET<T>::st(dl + pix * a.ldd + ch, gr * up);
+    ET<T>::st(dl + pix * a.ldd + ch, yolo_grad_elem<T>(a, lg, pix, ch, nM, nN) * up);
   }
+}
+
+// The same values through an LDS tile of kGradPix pixels x Cpad channels: one thread per (pixel, anchor, x/y/w/h/conf) element computes
+// its gradient (the owner / logit loads of a block are all in flight together instead of chained inside one thread), then the tile
+// leaves as 16-byte stores.  With 80 classes 15 of the 255 channels carry a gradient, so the kernel is close to a fill of the
+// dlogits plane.  Needs Cpad % V == 0, ldd % V == 0, a 16-byte aligned base and a tile that fits LDS (checked by the launcher).
+constexpr int kGradPix = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void yolo_grad_tile_kernel(GradArgs a) {
+  constexpr int V = 16 / (int)sizeof(T);
+  extern __shared__ uint4 tile_raw[];
+  T* tile = reinterpret_cast<T*>(tile_raw);
+  const HeadGeom& g = a.g;
+  const int attrs = 5 + g.C;
+  const int nvec = a.Cpad / V;
+  const long long pixels = (long long)g.B * g.Gh * g.Gw;
+  const long long pix0 = (long long)blockIdx.x * kGradPix;
+  const int np = (int)(pixels - pix0 < kGradPix ? pixels - pix0 : kGradPix);
+  const T* lg = reinterpret_cast<const T*>(a.logits);
+  T* dl = reinterpret_cast<T*>(a.dlogits);
+  const float nM = (float)a.acc[6], nN = (float)a.acc[7];
+  const float up = a.gscale ? a.gscale[0] : 1.f;
+  alignas(16) T z[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) ET<T>::st(z + k, 0.f * up);
+  for (int v = threadIdx.x; v < np * nvec; v += blockDim.x) tile_raw[v] = *reinterpret_cast<const uint4*>(z);
+  __syncthreads();
+  const int live = g.A * 5;
+  for (int idx = threadIdx.x; idx < np * live; idx += blockDim.x) {
+    const int p = idx / live, r = idx - p * live;
+    const int an = r / 5, ch = an * attrs + (r - an * 5);
+    ET<T>::st(tile + p * a.Cpad + ch, yolo_grad_elem<T>(a, lg, pix0 + p, ch, nM, nN) * up);
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < np * nvec; v += blockDim.x) {
+    const int p = v / nvec, c = v - p * nvec;
+    *reinterpret_cast<uint4*>(dl + (size_t)(pix0 + p) * a.ldd + c * V) = tile_raw[v];
+  }
+}
+
+template <typename T>
+static void launch_yolo_grad(const GradArgs& ga, hipStream_t st) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const HeadGeom& g = ga.g;
+  const long long pixels = (long long)g.B * g.Gh * g.Gw;
+  const size_t lds = (size_t)kGradPix * ga.Cpad * sizeof(T);
+  const long long blocks = (pixels + kGradPix - 1) / kGradPix;
+  const bool tiled = ga.Cpad % V == 0 && ga.ldd % V == 0 && ((uintptr_t)ga.dlogits & 15) == 0 && lds <= 32768 && blocks < (1LL << 31);
+  if (tiled) MDCV_LAUNCH(yolo_grad_tile_kernel<T>, dim3((unsigned)blocks), dim3(256), lds, st, ga);
+  else MDCV_LAUNCH(yolo_grad_kernel<T>, dim3(grid_for(pixels * ga.Cpad)), dim3(256), 0, st, ga);
 }
 
 // eval: [B, rows_total, 5+C] fp32, this head's rows start at row_off ; row = (a*Gh + j)*Gw + i (models.py:215-220)
@@ -230,7 +294,6 @@ __global__ void bt_tcls_kernel(const float* __restrict__ tg, HeadGeom g, const i
   }
 }
 
-static unsigned grid_for(long long n) { long long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
 }  // namespace
 
@@ -256,8 +319,8 @@ int mdcv_yolo_head_train(int dtype, const void* logits, int ldc, void* dlogits, 
   long long ints = cells + (long long)Gh * Gw + 2; ints = (ints + 1) & ~1LL;
   int* owner = (int*)workspace; int* ignore = owner + cells; int* err = ignore + (long long)Gh * Gw;
   double* acc = (double*)((int*)workspace + ints);
-  hipError_t e = hipMemsetAsync(owner, 0xff, cells * 4, st); if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(ignore, 0, ((long long)Gh * Gw + 2) * 4 + (ints - (cells + (long long)Gh * Gw + 2)) * 4 + 64, st); if (e != hipSuccess) return (int)e;
+  MDCV_LAUNCH(yolo_init_kernel, dim3(grid_for(ints + 16)), dim3(256), 0, st, owner, cells, ints + 16);
+  MDCV_CHECK_LAUNCH();
   MDCV_LAUNCH(yolo_assign_kernel, dim3(grid_for((long long)B * T)), dim3(256), 0, st, targets, anchors_scaled, g, owner, ignore, (int*)nullptr, err);
   MDCV_CHECK_LAUNCH();
   LossArgs la{logits, targets, anchors_scaled, owner, ignore, acc, g};
@@ -269,9 +332,8 @@ int mdcv_yolo_head_train(int dtype, const void* logits, int ldc, void* dlogits, 
   MDCV_CHECK_LAUNCH();
   if (dlogits) {
     GradArgs ga{logits, dlogits, targets, anchors_scaled, owner, ignore, acc, gscale, g, ldd, Cpad, xy_loss, wh_loss, obj_loss, noobj_loss};
-    const long long total = (long long)B * Gh * Gw * Cpad;
-    if (dtype == MDCV_BF16) MDCV_LAUNCH(yolo_grad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, ga);
-    else MDCV_LAUNCH(yolo_grad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, ga);
+    if (dtype == MDCV_BF16) launch_yolo_grad<bf16_t>(ga, st);
+    else launch_yolo_grad<float>(ga, st);
     MDCV_CHECK_LAUNCH();
   }
   return MDCV_OK;
@@ -290,9 +352,8 @@ int mdcv_yolo_head_grad(int dtype, const void* logits, int ldc, void* dlogits, i
   int* owner = (int*)workspace; int* ignore = owner + cells;
   double* acc = (double*)((int*)workspace + ints);
   GradArgs ga{logits, dlogits, targets, anchors_scaled, owner, ignore, acc, gscale, g, ldd, Cpad, xy_loss, wh_loss, obj_loss, noobj_loss};
-  const long long total = (long long)B * Gh * Gw * Cpad;
-  if (dtype == MDCV_BF16) MDCV_LAUNCH(yolo_grad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, ga);
-  else if (dtype == MDCV_F32) MDCV_LAUNCH(yolo_grad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, ga);
+  if (dtype == MDCV_BF16) launch_yolo_grad<bf16_t>(ga, st);
+  else if (dtype == MDCV_F32) launch_yolo_grad<float>(ga, st);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;

@@ -999,3 +999,42 @@ def test_upsample_generic(dt, sc, H, W):
     np.testing.assert_array_equal(to_nchw(out, dt, C).numpy(), ref.detach().numpy())
     tol = 1e-5 if dt == F32 else 3e-2
     np.testing.assert_allclose(to_nchw(dx, dt, C).numpy(), xr.grad.numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("C,G", [(80, 13), (1, 13), (1, 7), (80, 5)])
+def test_yolo_head_grad_tile_kernel_equals_scalar_kernel(dt, C, G):
+    """mdcv_yolo_head_grad has a 16-pixel LDS-tile kernel (16-byte stores) and a per-element kernel for layouts the tile cannot take;
+    a dlogits base that is not 16-byte aligned selects the second one.  Same bits from both, pad channels and class channels zero."""
+    L = _lib.lib()
+    torch.manual_seed(C * 100 + G)
+    B, A, T_ = 3, 3, 6
+    attrs = 5 + C
+    cp = pad8(A * attrs)
+    lg = (torch.randn(B, G, G, cp) * 1.5).to(TD[dt]).cuda()
+    tg = torch.zeros(B, T_, 5)
+    tg[:, :4, 0] = torch.randint(0, max(C, 1), (B, 4)).float()
+    tg[:, :4, 1:3] = torch.rand(B, 4, 2) * 0.98 + 0.01
+    tg[:, :4, 3:5] = torch.rand(B, 4, 2) * 0.3 + 0.02
+    tg = tg.cuda()
+    anchors = torch.tensor([[1.2, 1.9], [2.5, 3.8], [4.9, 6.1]], device="cuda")
+    ws = torch.empty(int(L.yolo_head_workspace_bytes(B, A, G, G)), dtype=torch.uint8, device="cuda")
+    out7 = torch.zeros(7, device="cuda")
+    geo = (B, T_, A, C, G, G, 0.5, 2.0, 1.6, 25.0, 0.1)
+    L.check(L.yolo_head_train(dt, lg.data_ptr(), cp, None, 0, cp, tg.data_ptr(), anchors.data_ptr(), *geo, ws.data_ptr(), out7.data_ptr(), None, st()))
+    gs = torch.tensor([0.75], device="cuda")
+    d_tile = torch.full((B * G * G * cp,), 7.0, dtype=TD[dt], device="cuda")
+    L.check(L.yolo_head_grad(dt, lg.data_ptr(), cp, d_tile.data_ptr(), cp, cp, tg.data_ptr(), anchors.data_ptr(), *geo, ws.data_ptr(), gs.data_ptr(), st()))
+    raw = torch.full((B * G * G * cp + 8,), 7.0, dtype=TD[dt], device="cuda")
+    d_sc = raw[1:1 + B * G * G * cp]                                   # base + one element: no 16-byte stores possible
+    assert d_sc.data_ptr() % 16 != 0
+    L.check(L.yolo_head_grad(dt, lg.data_ptr(), cp, d_sc.data_ptr(), cp, cp, tg.data_ptr(), anchors.data_ptr(), *geo, ws.data_ptr(), gs.data_ptr(), st()))
+    torch.cuda.synchronize()
+    a, b = d_tile.float().view(B, G, G, cp).cpu(), d_sc.float().view(B, G, G, cp).cpu()
+    assert torch.equal(a, b)
+    assert float(raw[0]) == 7.0 and float(raw[1 + B * G * G * cp]) == 7.0
+    live = torch.zeros(cp, dtype=torch.bool)
+    for an in range(A):
+        live[an * attrs:an * attrs + 5] = True
+    assert float(a[..., ~live].abs().max()) == 0.0
+    assert float(a[..., live].abs().max()) > 0.0
