@@ -731,8 +731,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a0, un
           fz.add(a.fuse, x, yq[gi][u]);
         }
       }
-      if (tile_m * BM + g0 < a.M)                      // block-uniform: a 256-row tile's second group may start past the last pixel,
-        fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (tile_m * BM + g0) >> 7);   // and that row is not in the caller's buffer
+      if (tile_m * BM + g0 < a.M) {                    // block-uniform: a 256-row tile's second group may start past the last pixel,
+        if constexpr (Acc::kWaveFold)                    // and that row is not in the caller's buffer
+          fz.fold_wave(reinterpret_cast<float*>(smem + (g0 + wave * Acc::WROWS) * SROW), lane);   // the rows this wave read in its first pass: dead, private
+        else
+          fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (tile_m * BM + g0) >> 7);
+      }
+    }
+    if constexpr (Acc::kWaveFold) {                      // the waves meet once, behind the tile's last store
+      static_assert(Acc::WROWS * SROW >= 2 * BN * 4 && SROW % 4 == 0, "a wave's dead staging rows hold its 2*BN sums");
+      lds_only_barrier();
+      for (int t = tid; t < NG * 2 * BN; t += NT) {
+        const int gi = t / (2 * BN), g0 = gi * 128;
+        if (tile_m * BM + g0 < a.M)
+          Acc::write_row(a.fuse, reinterpret_cast<const float*>(smem + g0 * SROW), Acc::WROWS * SROW / 4, t - gi * 2 * BN, tile_n * BN, a.Nout,
+                         (tile_m * BM + g0) >> 7);
+      }
     }
   } else {
   for (int v = tid; v < BM * VPRO; v += NT) {
@@ -767,7 +781,7 @@ int launch_conv_glds_f(const ConvArgs& a0, hipStream_t st, int B) {
   constexpr int NWV = WM * WN;
   constexpr int PIPE = STAGES * (BM + BN) * 64 + ((STAGES > 2 && ((BM / 16) % NWV != 0 || (BN / 16) % NWV != 0)) ? 1024 : 0);   // + the DMA sink
   constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
-  constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;   // + statistics / fused-sum scratch (NW*BN floats <= WM*2*BN)
+  constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;   // + statistics / fp32 fused-sum scratch (NW*BN floats <= WM*2*BN)
   static bool attr_set = false;
   auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN, STAGES, UT, FUSE, EPI, ALLCLS>;
   if (!attr_set) {
@@ -825,6 +839,9 @@ int g_conv_deep4 = 0;        // tuning (set_variant 9000 + nk_min; 9000 = off): 
 int g_conv_deep_small = 8;   // 128x128 and 128x64 tiles take the 3-stage DMA ring from this many K steps (set_variant 60 + nk_min; 60 = never).
                              // Same-box A/B of the YOLOv3 step: never 2031, from 4 steps 2045, from 8 2050, from 16 2045, from 32 2034 img/s
 int g_conv_fuse_small = 0;   // tuning (set_variant 95 / 94): fused-sum data gradients with a short K loop take 128x128 two-stage tiles (4 workgroups per CU)
+int g_conv_fuse_narrow = 1;  // (set_variant 92 = off) 1x1 data gradients with fused BatchNorm sums take 128x64 tiles on the 3-stage ring: their store loop (loads of
+                             // the shortcut gradient and y, sums, partial-row flush) is serial per workgroup, and three or four narrow workgroups per CU overlap it
+                             // better than one or two wide ones.  Alone (scripts/pw_ab_dgrad.py): 52^2 60 -> 47 us, 104^2 103 -> 78, 26^2 35 -> 32, 13^2 21.5 -> 20
 int g_conv_midgrid = 0;    // tuning (set_variant 97 / 96): 256x128 tiles already from 300 tiles of 128x128 (1x1 layers at 52x52)
 int g_conv_variant = -1;   // -1: heuristic ; >= 0: forced tile configuration for wide layers (tuning / A-B benchmarking)
 
@@ -841,6 +858,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
       const int nk = a.Ktot / (4 * ET<T>::VEC);      // long K loops profit from the 3-stage DMA ring (scripts/conv_ab.py)
       v = t128 >= (g_conv_midgrid ? g_conv_midgrid : 1024) ? 11 : (nk >= 100 ? 9 : (t128 >= 300 ? 6 : 7));
       if (g_conv_fuse_small && MODE != 0 && a.fuse.y && nk <= 8 && v == 11) v = 6;
+      if (g_conv_fuse_narrow && MODE == 1 && a.fuse.y && a.KH == 1 && a.KW == 1) v = 10;
       if (g_conv_deep_small && nk >= g_conv_deep_small && (v == 6 || v == 7)) v += 3;   // 3-stage ring for the mid / sparse grids too
       if (g_conv_deep4 && nk >= g_conv_deep4 && t128 <= 512 && (v == 9 || v == 10)) v = v == 9 ? 12 : 14;   // sparse grids: 4 stages
     }
@@ -1923,7 +1941,8 @@ int mdcv_conv2d_set_variant(int v) {
   if (v >= 9000 && v < 9999) { g_conv_deep4 = v - 9000; return MDCV_OK; }
   if (v >= 3000 && v < 9000) { g_conv_midgrid = v - 3000; return MDCV_OK; }   // 3000 + first t128 that takes 256x128 tiles
   if (v == 95 || v == 94) { g_conv_fuse_small = v == 95; return MDCV_OK; }
-  if (v >= 60 && v < 93) { g_conv_deep_small = v - 60; return MDCV_OK; }
+  if (v == 93 || v == 92) { g_conv_fuse_narrow = v == 93; return MDCV_OK; }
+  if (v >= 60 && v < 92) { g_conv_deep_small = v - 60; return MDCV_OK; }
   if (v >= 30 && v < 60) { g_conv_deep_narrow = v - 30; return MDCV_OK; }
   if (v == 20 || v == 21) { g_conv_deep_s2 = v - 20; return MDCV_OK; }
   if (v == 16 || v == 17) { g_conv_s2_allcls = v - 16; return MDCV_OK; }

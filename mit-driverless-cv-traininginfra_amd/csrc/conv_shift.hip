@@ -389,7 +389,21 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
           fz.add(a.fuse, x, yq[gi][u]);
         }
       }
-      if (p0 + g0 < a.Mq) fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (p0 + g0) >> 7);   // block-uniform: rows past the stream do not exist
+      if (p0 + g0 < a.Mq) {                                // block-uniform: rows past the stream do not exist
+        if constexpr (Acc::kWaveFold)
+          fz.fold_wave(reinterpret_cast<float*>(smem + (g0 + wave * Acc::WROWS) * SROW), lane);   // the rows this wave read in its first pass: dead, private
+        else
+          fz.flush(a.fuse, fred, tid, tile_n * BN, a.Nout, (p0 + g0) >> 7);
+      }
+    }
+    if constexpr (Acc::kWaveFold) {                          // the waves meet once, behind the tile's last store (bn_fuse.h)
+      static_assert(Acc::WROWS * SROW >= 2 * BN * 4 && SROW % 4 == 0, "a wave's dead staging rows hold its 2*BN sums");
+      lds_only_barrier();
+      for (int t = tid; t < NG * 2 * BN; t += NW * 64) {
+        const int gi = t / (2 * BN), g0 = gi * 128;
+        if (p0 + g0 < a.Mq)
+          Acc::write_row(a.fuse, reinterpret_cast<const float*>(smem + g0 * SROW), Acc::WROWS * SROW / 4, t - gi * 2 * BN, tile_n * BN, a.Nout, (p0 + g0) >> 7);
+      }
     }
   }
 #if defined(MDCV_SHIFT_TS) || defined(MDCV_SHIFT_WG)
@@ -417,7 +431,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   a.xcd_chunk = (a.tiles_total + 7) / 8;
   a.nca = (BM + 2 * a.dil * (a.Wq + 1) + 15) / 16;         // KiB-chunks (16 stream rows each) of one activation chunk
   const int pipe = 2 * a.nca * 1024 + BRING * BTILE + 1024;
-  const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics / fused-sum scratch (NW*BN floats)
+  const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics (the fused sums fold inside dead staging rows)
   const int lds = pipe > epi ? pipe : epi;
   static int attr_lds = 0;
   auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE, WN, EPI, BN_>;
