@@ -1,0 +1,21 @@
+#!/bin/bash
+# Everything profiles/ holds for one round, in one GPU call:   gpurun -- bash scripts/round_evidence.sh r02
+#   full `pytest -m gpu`, the rocprofv3 / PMC sets of scripts/profile_round.sh for both workloads, the default and the joint bench lines,
+#   the per-geometry conv launch tables.  Output under gpurun_out/prof_<tag>/; copy into profiles/ and commit.
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd $R
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/${TAG}_pytest_gpu_tail.txt
+bash scripts/profile_round.sh $TAG yolo > /dev/null 2>&1
+bash scripts/profile_round.sh $TAG rektnet > /dev/null 2>&1
+cd $R
+cp $OUT/${TAG}_*.csv $OUT/${TAG}_pmc_*.json $OUT/${TAG}_*_under_rocprof.json $R/profiles/ 2>/dev/null   # bench.py quotes traffic / *_in_step from profiles/ when the fingerprint matches
+python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
+python bench.py --workload joint --no-cpu-baseline > $OUT/${TAG}_joint_bench.json 2> $OUT/joint.err
+python bench.py --workload yolo --no-cpu-baseline --no-fp32 --dump-launches $OUT/yolo_launches.json > /dev/null 2>&1 && python scripts/layer_table.py $OUT/yolo_launches.json > $OUT/${TAG}_yolo_conv_launch_table.txt
+python bench.py --workload rektnet --no-cpu-baseline --no-fp32 --dump-launches $OUT/rektnet_launches.json > /dev/null 2>&1 && python scripts/layer_table.py $OUT/rektnet_launches.json > $OUT/${TAG}_rektnet_conv_launch_table.txt
+rm -f $OUT/*_launches.json
+cat $OUT/${TAG}_pytest_gpu_tail.txt
+ls -la $OUT
