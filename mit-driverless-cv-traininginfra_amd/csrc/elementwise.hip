@@ -245,21 +245,26 @@ struct BnBwdArgs {
   int ldd, ld1, ld2, ldy1, ldy2, M, C, act, PB, CV, PPI;
   float slope;
 };
-template <typename T>
+template <typename T, bool DUAL>     // DUAL: see bn_act_bwd_apply_kernel
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdArgs a) {
   constexpr int VEC = ET<T>::VEC;
+  constexpr int ND = DUAL ? VEC : 1;
   __shared__ float red[256 * VEC];
   const int tid = threadIdx.x;
   const bool active = tid < a.PPI * a.CV;
   const int cv = active ? tid % a.CV : 0, pi = active ? tid / a.CV : 0;
-  const int nsum = a.y2 ? 3 : 2;
-  float s1[VEC], b1[VEC], m1[VEC], i1[VEC], s2[VEC], b2[VEC], m2[VEC], i2[VEC];
+  constexpr int nsum = DUAL ? 3 : 2;
+  float s1[VEC], b1[VEC], m1[VEC], i1[VEC], s2[ND], b2[ND], m2[ND], i2[ND];
   ldcoef<VEC>(a.s1, cv * VEC, s1, 1.f); ldcoef<VEC>(a.b1, cv * VEC, b1, 0.f); ldcoef<VEC>(a.m1, cv * VEC, m1, 0.f); ldcoef<VEC>(a.is1, cv * VEC, i1, 0.f);
-  ldcoef<VEC>(a.y2 ? a.s2 : nullptr, cv * VEC, s2, 0.f); ldcoef<VEC>(a.y2 ? a.b2 : nullptr, cv * VEC, b2, 0.f);
-  ldcoef<VEC>(a.y2 ? a.m2 : nullptr, cv * VEC, m2, 0.f); ldcoef<VEC>(a.y2 ? a.is2 : nullptr, cv * VEC, i2, 0.f);
-  float sg[VEC], sx1[VEC], sx2[VEC];
+  if constexpr (DUAL) {
+    ldcoef<VEC>(a.s2, cv * VEC, s2, 0.f); ldcoef<VEC>(a.b2, cv * VEC, b2, 0.f);
+    ldcoef<VEC>(a.m2, cv * VEC, m2, 0.f); ldcoef<VEC>(a.is2, cv * VEC, i2, 0.f);
+  }
+  float sg[VEC], sx1[VEC], sx2[ND];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) { sg[e] = 0.f; sx1[e] = 0.f; sx2[e] = 0.f; }
+  for (int e = 0; e < VEC; ++e) { sg[e] = 0.f; sx1[e] = 0.f; }
+#pragma unroll
+  for (int e = 0; e < ND; ++e) sx2[e] = 0.f;
   const long long p0 = (long long)blockIdx.x * a.PB;
   const long long p1 = min((long long)a.M, p0 + a.PB);
   const T* dout = reinterpret_cast<const T*>(a.dout);
@@ -267,31 +272,31 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdArgs a) {
   const T* y2 = reinterpret_cast<const T*>(a.y2);
   if (active)
     for (long long pb = p0 + pi; pb < p1; pb += 4 * a.PPI) {
-      uint4 qd[4], qv[4], qw[4];
+      uint4 qd[4], qv[4], qw[DUAL ? 4 : 1];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {                     // issue all loads of 4 pixels before touching any
         const long long p = pb + (long long)u * a.PPI;
         if (p < p1) {
           qd[u] = *reinterpret_cast<const uint4*>(dout + p * a.ldd + cv * VEC);
           qv[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
-          if (y2) qw[u] = *reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC);
+          if constexpr (DUAL) qw[u] = *reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC);
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
       if (pb + (long long)u * a.PPI >= p1) break;
-      float d[VEC], v[VEC], w[VEC];
+      float d[VEC], v[VEC], w[ND];
       ET<T>::unpack(qd[u], d);
       ET<T>::unpack(qv[u], v);
-      if (y2) ET<T>::unpack(qw[u], w);
+      if constexpr (DUAL) ET<T>::unpack(qw[u], w);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float pre = v[e] * s1[e] + b1[e];
-        if (y2) pre += w[e] * s2[e] + b2[e];
+        if constexpr (DUAL) pre += w[e] * s2[e] + b2[e];
         const float g = d[e] * act_grad(pre, a.act, a.slope);
         sg[e] += g;
         sx1[e] += g * (v[e] - m1[e]) * i1[e];
-        if (y2) sx2[e] += g * (w[e] - m2[e]) * i2[e];
+        if constexpr (DUAL) sx2[e] += g * (w[e] - m2[e]) * i2[e];
       }
       }
     }
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdArgs a) {
   if (tid < a.CV) *reinterpret_cast<uint4*>(prow + tid * VEC) = ET<float>::pack(sg), (VEC == 8 ? (void)(*reinterpret_cast<uint4*>(prow + tid * VEC + 4) = ET<float>::pack(sg + 4)) : (void)0);
   block_fold<VEC>(sx1, a.CV, red, tid);
   if (tid < a.CV) *reinterpret_cast<uint4*>(prow + a.C + tid * VEC) = ET<float>::pack(sx1), (VEC == 8 ? (void)(*reinterpret_cast<uint4*>(prow + a.C + tid * VEC + 4) = ET<float>::pack(sx1 + 4)) : (void)0);
-  if (nsum == 3) {
+  if constexpr (DUAL) {
     block_fold<VEC>(sx2, a.CV, red, tid);
     if (tid < a.CV) *reinterpret_cast<uint4*>(prow + 2 * a.C + tid * VEC) = ET<float>::pack(sx2), (VEC == 8 ? (void)(*reinterpret_cast<uint4*>(prow + 2 * a.C + tid * VEC + 4) = ET<float>::pack(sx2 + 4)) : (void)0);
   }
@@ -446,18 +451,23 @@ __global__ __launch_bounds__(1024) void bn_colfinal_kernel(ColFinArgs a) {
 }
 
 // backward, pass 2: dy_i = cA_i*g + cB_i*y_i + cC_i
-template <typename T>
+// DUAL: two BatchNorms feed one activation (RektNet's residual blocks).  A template parameter, not a runtime test of y2: the single form
+// then carries 40 coefficient registers instead of 80 (214 -> ~120 VGPRs), so four blocks fit on a CU instead of two -- the kernel shares
+// the chip with the side stream's weight gradients, whose blocks leave no registers on the CUs they occupy.
+template <typename T, bool DUAL>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnBwdArgs a) {
   constexpr int VEC = ET<T>::VEC;
+  constexpr int ND = DUAL ? VEC : 1;
   const int tid = threadIdx.x;
   if (tid >= a.PPI * a.CV) return;
   const int cv = tid % a.CV, pi = tid / a.CV;
-  float s1[VEC], b1[VEC], s2[VEC], b2[VEC], A1[VEC], B1[VEC], C1[VEC], A2[VEC], B2[VEC], C2[VEC];
+  float s1[VEC], b1[VEC], A1[VEC], B1[VEC], C1[VEC], s2[ND], b2[ND], A2[ND], B2[ND], C2[ND];
   ldcoef<VEC>(a.s1, cv * VEC, s1, 1.f); ldcoef<VEC>(a.b1, cv * VEC, b1, 0.f);
   ldcoef<VEC>(a.cA1, cv * VEC, A1, 0.f); ldcoef<VEC>(a.cB1, cv * VEC, B1, 0.f); ldcoef<VEC>(a.cC1, cv * VEC, C1, 0.f);
-  ldcoef<VEC>(a.y2 ? a.s2 : nullptr, cv * VEC, s2, 0.f); ldcoef<VEC>(a.y2 ? a.b2 : nullptr, cv * VEC, b2, 0.f);
-  ldcoef<VEC>(a.y2 ? a.cA2 : nullptr, cv * VEC, A2, 0.f); ldcoef<VEC>(a.y2 ? a.cB2 : nullptr, cv * VEC, B2, 0.f);
-  ldcoef<VEC>(a.y2 ? a.cC2 : nullptr, cv * VEC, C2, 0.f);
+  if constexpr (DUAL) {
+    ldcoef<VEC>(a.s2, cv * VEC, s2, 0.f); ldcoef<VEC>(a.b2, cv * VEC, b2, 0.f);
+    ldcoef<VEC>(a.cA2, cv * VEC, A2, 0.f); ldcoef<VEC>(a.cB2, cv * VEC, B2, 0.f); ldcoef<VEC>(a.cC2, cv * VEC, C2, 0.f);
+  }
   const long long p0 = (long long)blockIdx.x * a.PB;
   const long long p1 = min((long long)a.M, p0 + a.PB);
   const T* dout = reinterpret_cast<const T*>(a.dout);
@@ -466,34 +476,34 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnBwdArgs a) {
   T* dy1 = reinterpret_cast<T*>(a.dy1);
   T* dy2 = reinterpret_cast<T*>(a.dy2);
   for (long long pb = p0 + pi; pb < p1; pb += 4 * a.PPI) {
-    uint4 qd[4], qv[4], qw[4];
+    uint4 qd[4], qv[4], qw[DUAL ? 4 : 1];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long long p = pb + (long long)u * a.PPI;
       if (p < p1) {
         qd[u] = *reinterpret_cast<const uint4*>(dout + p * a.ldd + cv * VEC);
         qv[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
-        if (y2) qw[u] = *reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC);
+        if constexpr (DUAL) qw[u] = *reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC);
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long long p = pb + (long long)u * a.PPI;
       if (p >= p1) break;
-      float d[VEC], v[VEC], w[VEC], o1[VEC], o2[VEC];
+      float d[VEC], v[VEC], w[ND], o1[VEC], o2[ND];
       ET<T>::unpack(qd[u], d);
       ET<T>::unpack(qv[u], v);
-      if (y2) ET<T>::unpack(qw[u], w);
+      if constexpr (DUAL) ET<T>::unpack(qw[u], w);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float pre = v[e] * s1[e] + b1[e];
-        if (y2) pre += w[e] * s2[e] + b2[e];
+        if constexpr (DUAL) pre += w[e] * s2[e] + b2[e];
         const float g = d[e] * act_grad(pre, a.act, a.slope);
         o1[e] = A1[e] * g + B1[e] * v[e] + C1[e];
-        if (y2) o2[e] = A2[e] * g + B2[e] * w[e] + C2[e];
+        if constexpr (DUAL) o2[e] = A2[e] * g + B2[e] * w[e] + C2[e];
       }
       *reinterpret_cast<uint4*>(dy1 + p * a.ldy1 + cv * VEC) = ET<T>::pack(o1);
-      if (y2) *reinterpret_cast<uint4*>(dy2 + p * a.ldy2 + cv * VEC) = ET<T>::pack(o2);
+      if constexpr (DUAL) *reinterpret_cast<uint4*>(dy2 + p * a.ldy2 + cv * VEC) = ET<T>::pack(o2);
     }
   }
 }
@@ -913,11 +923,13 @@ int mdcv_bn_act_bwd_reduce(int dtype, const void* dout, int ldd, const void* y1,
   if (dtype == MDCV_BF16) {
     Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
-    MDCV_LAUNCH(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, a);
+    if (a.y2) MDCV_LAUNCH((bn_act_bwd_reduce_kernel<bf16_t, true>), dim3((unsigned)rows), dim3(256), 0, st, a);
+    else MDCV_LAUNCH((bn_act_bwd_reduce_kernel<bf16_t, false>), dim3((unsigned)rows), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
     Strip s = make_strip<float>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
-    MDCV_LAUNCH(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, a);
+    if (a.y2) MDCV_LAUNCH((bn_act_bwd_reduce_kernel<float, true>), dim3((unsigned)rows), dim3(256), 0, st, a);
+    else MDCV_LAUNCH((bn_act_bwd_reduce_kernel<float, false>), dim3((unsigned)rows), dim3(256), 0, st, a);
   } else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   const int cols = nsums * C;
@@ -953,11 +965,13 @@ int mdcv_bn_act_bwd_reduce_finalize(int dtype, const void* dout, int ldd, const 
   if (dtype == MDCV_BF16) {
     Strip s = make_strip<bf16_t>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
-    MDCV_LAUNCH(bn_act_bwd_reduce_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, st, a);
+    if (a.y2) MDCV_LAUNCH((bn_act_bwd_reduce_kernel<bf16_t, true>), dim3((unsigned)rows), dim3(256), 0, st, a);
+    else MDCV_LAUNCH((bn_act_bwd_reduce_kernel<bf16_t, false>), dim3((unsigned)rows), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
     Strip s = make_strip<float>(M, C, reduce_blocks(C, nsums), 8); if (s.CV > 256 || (256 % s.CV)) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI; rows = cdiv(M, s.PB);
-    MDCV_LAUNCH(bn_act_bwd_reduce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, a);
+    if (a.y2) MDCV_LAUNCH((bn_act_bwd_reduce_kernel<float, true>), dim3((unsigned)rows), dim3(256), 0, st, a);
+    else MDCV_LAUNCH((bn_act_bwd_reduce_kernel<float, false>), dim3((unsigned)rows), dim3(256), 0, st, a);
   } else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   ColFinArgs f = {};
@@ -995,11 +1009,13 @@ int mdcv_bn_act_bwd_apply(int dtype, const void* dout, int ldd, const void* y1, 
   if (dtype == MDCV_BF16) {
     Strip s = make_strip<bf16_t>(M, C, 2048, 4); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
-    MDCV_LAUNCH(bn_act_bwd_apply_kernel<bf16_t>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+    if (a.y2) MDCV_LAUNCH((bn_act_bwd_apply_kernel<bf16_t, true>), dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+    else MDCV_LAUNCH((bn_act_bwd_apply_kernel<bf16_t, false>), dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else if (dtype == MDCV_F32) {
     Strip s = make_strip<float>(M, C, 2048, 4); if (s.CV > 256) return MDCV_EARG;
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
-    MDCV_LAUNCH(bn_act_bwd_apply_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+    if (a.y2) MDCV_LAUNCH((bn_act_bwd_apply_kernel<float, true>), dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
+    else MDCV_LAUNCH((bn_act_bwd_apply_kernel<float, false>), dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
