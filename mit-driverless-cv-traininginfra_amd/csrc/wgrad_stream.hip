@@ -491,10 +491,17 @@ int g_stream_tiled = 1;    // 128 co x 64 ci tiles for the wide layers (Cin % 64
 int g_stream_w4 = 0;       // tuning hook (MDCV_WGRAD_VARIANT=30001): tiled instantiation with 4 waves per block, each owning all 128 output channels
                            // (A = 8: 17 transpose reads per 72 MFMAs instead of 13 per 36, 456 registers, one wave per SIMD).  Measured SLOWER: 52^2 128->256
                            // 99 vs 80 us on 256 blocks, 149 vs 97 us on 128; YOLOv3 step 2044 vs 2142 img/s -- one wave per SIMD cannot cover the read latency
+int g_stream_tiled_blocks_13 = 0, g_stream_tiled_blocks_26 = 0;   // tuning: block targets for images of at most 16 / 32 rows (0: the common target)
 int g_stream_tiled_blocks = 128;   // target block count of the tiled instantiation.  A block fills its CU (8 waves x 224 VGPRs, 112 KiB LDS), and the
                            // weight gradients run on a side stream BESIDE the main stream's kernels: with one block on every CU the main stream's
                            // workgroups wait for whole weight-gradient blocks to retire; 128 blocks leave half the CUs to the main stream
                            // (YOLOv3 step, same-box A/B: 256 blocks 2033, 192: 2080, 128: 2103, 64: 2033 img/s)
+static int tiled_blocks_for(int H) {
+  if (H <= 16 && g_stream_tiled_blocks_13 > 0) return g_stream_tiled_blocks_13;
+  if (H <= 32 && g_stream_tiled_blocks_26 > 0) return g_stream_tiled_blocks_26;
+  return g_stream_tiled_blocks;
+}
+
 
 // (Cin, Cout) -> instantiation; false if unsupported
 inline bool stream_cfg(int Cin, int Cout, StreamCfg& c) {
@@ -570,7 +577,7 @@ int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil) {
   if (!stream_cfg(Cin, Cout, c)) return 1;
   const int Mq = B * (H + dil) * (W + dil);
   int s = g_stream_blocks > 0 ? g_stream_blocks : (c.a <= 2 ? 512 : 256);
-  if (c.tiled) s = ((g_stream_blocks > 0 ? g_stream_blocks : g_stream_tiled_blocks) + (Cout / 128) * (Cin / 64) - 1) / ((Cout / 128) * (Cin / 64));   // blocks = splits x channel tiles
+  if (c.tiled) s = ((g_stream_blocks > 0 ? g_stream_blocks : tiled_blocks_for(H)) + (Cout / 128) * (Cin / 64) - 1) / ((Cout / 128) * (Cin / 64));   // blocks = splits x channel tiles
   const int max_s = (Mq + c.bp * 4 - 1) / (c.bp * 4);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -651,8 +658,10 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   return MDCV_EARG;
 }
 
-void mdcv_wgrad_stream_tiled_blocks(int blocks) {      // 30000 + n: block target ; 30001 / 30002: 4-wave / 8-wave form
+void mdcv_wgrad_stream_tiled_blocks(int blocks) {      // 30000 + n: block target ; 30001 / 30002: 4-wave / 8-wave form ; 35000 + n: images of at most 16 rows ; 37000 + n: at most 32 rows
   if (blocks == 1 || blocks == 2) { g_stream_w4 = blocks == 1; return; }
+  if (blocks >= 7000 && blocks < 9000) { g_stream_tiled_blocks_26 = blocks - 7000; return; }
+  if (blocks >= 5000 && blocks < 7000) { g_stream_tiled_blocks_13 = blocks - 5000; return; }
   g_stream_tiled_blocks = blocks > 0 ? blocks : 128;
 }
 void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_tiled = !(d & 8); g_stream_alt = (d & 4) != 0; g_stream_d = d & 3; g_stream_blocks = blocks; }
