@@ -491,6 +491,7 @@ int g_stream_tiled = 1;    // 128 co x 64 ci tiles for the wide layers (Cin % 64
 int g_stream_w4 = 0;       // tuning hook (MDCV_WGRAD_VARIANT=30001): tiled instantiation with 4 waves per block, each owning all 128 output channels
                            // (A = 8: 17 transpose reads per 72 MFMAs instead of 13 per 36, 456 registers, one wave per SIMD).  Measured SLOWER: 52^2 128->256
                            // 99 vs 80 us on 256 blocks, 149 vs 97 us on 128; YOLOv3 step 2044 vs 2142 img/s -- one wave per SIMD cannot cover the read latency
+int g_stream_tiled_wmask = 15;   // tuning (39000 + mask): image widths that take the tiled instantiation, 1: <= 16, 2: <= 32, 4: <= 64, 8: wider
 int g_stream_tiled_blocks_13 = 0, g_stream_tiled_blocks_26 = 0;   // tuning: block targets for images of at most 16 / 32 rows (0: the common target)
 int g_stream_tiled_blocks = 128;   // target block count of the tiled instantiation.  A block fills its CU (8 waves x 224 VGPRs, 112 KiB LDS), and the
                            // weight gradients run on a side stream BESIDE the main stream's kernels: with one block on every CU the main stream's
@@ -538,6 +539,7 @@ inline int stream_lds(const StreamCfg& c, int W, int dil) {
 // configuration for a layer geometry: the prefetch depth shrinks until ring + stages fit the 160 KiB of a CU
 inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c) {
   if (!stream_cfg(Cin, Cout, c)) return false;
+  if (c.tiled && !(g_stream_tiled_wmask & (W <= 16 ? 1 : (W <= 32 ? 2 : (W <= 64 ? 4 : 8))))) return false;   // tuning: the generic kernel for this image size
   while (c.d > 1 && stream_lds(c, W, dil) > 160 * 1024) --c.d;
   return stream_lds(c, W, dil) <= 160 * 1024;
 }
@@ -660,6 +662,7 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
 
 void mdcv_wgrad_stream_tiled_blocks(int blocks) {      // 30000 + n: block target ; 30001 / 30002: 4-wave / 8-wave form ; 35000 + n: images of at most 16 rows ; 37000 + n: at most 32 rows
   if (blocks == 1 || blocks == 2) { g_stream_w4 = blocks == 1; return; }
+  if (blocks >= 9000 && blocks < 9016) { g_stream_tiled_wmask = blocks - 9000; return; }
   if (blocks >= 7000 && blocks < 9000) { g_stream_tiled_blocks_26 = blocks - 7000; return; }
   if (blocks >= 5000 && blocks < 7000) { g_stream_tiled_blocks_13 = blocks - 5000; return; }
   g_stream_tiled_blocks = blocks > 0 ? blocks : 128;
