@@ -76,7 +76,7 @@ template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[4], bf1
 // NW: waves per block (8, or 4 for the one-wave-per-SIMD instantiation whose waves own all 128 output channels: A = 8, 288 accumulator
 // registers, 17 fragment reads per 72 MFMAs instead of 13 per 36).
 template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8>
-__global__ __launch_bounds__(NW * 64) void wgrad3x3_stream_kernel(WgradStreamArgs a, unsigned dy_bytes, unsigned x_bytes) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3x3_stream_kernel(WgradStreamArgs a, unsigned dy_bytes, unsigned x_bytes) {
   constexpr int RBX = NCI * 32, RBY = NCO * 32;            // row bytes
   constexpr int LPRX = 2 * NCI, LPRY = 2 * NCO;            // 16-byte slots (= DMA lanes) per row
   constexpr int RPIX = 64 / LPRX, RPIY = 64 / LPRY;        // rows per 1 KiB DMA instruction
@@ -491,6 +491,15 @@ int g_stream_tiled = 1;    // 128 co x 64 ci tiles for the wide layers (Cin % 64
 int g_stream_w4 = 0;       // tuning hook (MDCV_WGRAD_VARIANT=30001): tiled instantiation with 4 waves per block, each owning all 128 output channels
                            // (A = 8: 17 transpose reads per 72 MFMAs instead of 13 per 36, 456 registers, one wave per SIMD).  Measured SLOWER: 52^2 128->256
                            // 99 vs 80 us on 256 blocks, 149 vs 97 us on 128; YOLOv3 step 2044 vs 2142 img/s -- one wave per SIMD cannot cover the read latency
+// Light form of the tiled instantiation: 64 co x 64 ci per block, FOUR waves (one per SIMD, 216 VGPRs), prefetch depth 1, 48 KiB of LDS -- about
+// half a CU, on 256 blocks.  The 8-wave form owns its CU outright (2 x 232 VGPRs per SIMD, 112 KiB) and runs on 128 blocks so that the main
+// stream keeps the other half of the chip; the light form leaves room for main-stream workgroups on EVERY CU instead (296 registers per lane,
+// 112 KiB), and their waves fill the issue slots its single wave per SIMD leaves open.  Same-box A/B of the YOLOv3 step: 14.45 -> 14.32 ms
+// (256 blocks; 192: 14.62, 224: 14.35, 288: 14.39, 320: 14.54, 384: 14.77; depth 2: 14.60).  Layers with long position streams stay on the
+// 8-wave form: RektNet's 80^2 x 256-image layers (1.68 M positions) lose 1.3 % with the light form.
+int g_stream_light_maxpos = 600000;   // light form up to this many padded stream positions (tuning: 30003 / 30004 force it with depth 1 / 2, 30005 = never)
+int g_stream_light_blocks = 256;      // its block target (tuning: 33000 + n)
+int g_stream_light_d = 1;
 int g_stream_tiled_wmask = 15;   // tuning (39000 + mask): image widths that take the tiled instantiation, 1: <= 16, 2: <= 32, 4: <= 64, 8: wider
 int g_stream_tiled_blocks_13 = 0, g_stream_tiled_blocks_26 = 0;   // tuning: block targets for images of at most 16 / 32 rows (0: the common target)
 int g_stream_tiled_blocks = 128;   // target block count of the tiled instantiation.  A block fills its CU (8 waves x 224 VGPRs, 112 KiB LDS), and the
@@ -505,7 +514,7 @@ static int tiled_blocks_for(int H) {
 
 
 // (Cin, Cout) -> instantiation; false if unsupported
-inline bool stream_cfg(int Cin, int Cout, StreamCfg& c) {
+inline bool stream_cfg(int Cin, int Cout, StreamCfg& c, long long Mq = 0) {     // Mq: padded stream positions (0: unknown -> the 8-wave form)
   if (Cin == 16 && Cout == 16)       c = {1, 1, 1, 8, 256, 2, 9};
   else if (Cin == 16 && Cout == 32)  c = {1, 2, 2, 8, 256, 2, 9};
   else if (Cin == 32 && Cout == 32)  c = {2, 2, 2, 4, 128, 2, 9};
@@ -514,7 +523,8 @@ inline bool stream_cfg(int Cin, int Cout, StreamCfg& c) {
   else if (Cin == 64 && Cout == 128 && !g_stream_tiled) c = {4, 8, 4, 1, 64, 2, 1};
   else if (g_stream_tiled && Cin % 64 == 0 && Cout % 128 == 0 && Cin <= 4096 && Cout <= 4096) {
     c = {4, 8, 4, 1, 64, 2, 1}; c.tiled = true;
-    if (g_stream_w4) { c.a = 8; c.nw = 4; }
+    if (g_stream_w4 == 1) { c.a = 8; c.nw = 4; }
+    if (g_stream_w4 == 2 || (g_stream_w4 == 0 && Mq > 0 && Mq <= g_stream_light_maxpos)) { c.nco = 4; c.nw = 4; c.d = g_stream_light_d; }   // light form
   }
   else return false;
   if (g_stream_alt && Cin == 32 && Cout == 64) c = {2, 4, 2, 2, 128, 2, 3};
@@ -537,8 +547,8 @@ inline int stream_lds(const StreamCfg& c, int W, int dil) {
 }
 
 // configuration for a layer geometry: the prefetch depth shrinks until ring + stages fit the 160 KiB of a CU
-inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c) {
-  if (!stream_cfg(Cin, Cout, c)) return false;
+inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c, long long Mq = 0) {
+  if (!stream_cfg(Cin, Cout, c, Mq)) return false;
   if (c.tiled && !(g_stream_tiled_wmask & (W <= 16 ? 1 : (W <= 32 ? 2 : (W <= 64 ? 4 : 8))))) return false;   // tuning: the generic kernel for this image size
   while (c.d > 1 && stream_lds(c, W, dil) > 160 * 1024) --c.d;
   return stream_lds(c, W, dil) <= 160 * 1024;
@@ -565,8 +575,8 @@ bool mdcv_wgrad_stream_eligible(int dtype, int B, int H, int W, int Cin, int Cou
   if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != dil || (dil != 1 && dil != 2)) return false;
   StreamCfg c;
   if (H < 4 || W < 4) return false;
-  if (!stream_cfg_geom(Cin, Cout, W, dil, c)) return false;
   const long long Mq = (long long)B * (H + dil) * (W + dil);
+  if (!stream_cfg_geom(Cin, Cout, W, dil, c, Mq)) return false;
   if (Mq + 4096 >= (1LL << 24) || (long long)B * H * W >= (1LL << 24)) return false;          // 24-bit multiplies / float divmod
   if ((long long)B * H * W * dy_ldc * 2 >= (1LL << 31) || (long long)B * H * W * x_ldc * 2 >= (1LL << 31)) return false;
   if (dy_ldc >= (1 << 23) || x_ldc >= (1 << 23)) return false;
@@ -576,10 +586,10 @@ bool mdcv_wgrad_stream_eligible(int dtype, int B, int H, int W, int Cin, int Cou
 // blocks = splits: two resident blocks per CU for the light configurations (A <= 2), one for A = 4; never less than 4 steps per split
 int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil) {
   StreamCfg c;
-  if (!stream_cfg(Cin, Cout, c)) return 1;
   const int Mq = B * (H + dil) * (W + dil);
+  if (!stream_cfg(Cin, Cout, c, Mq)) return 1;
   int s = g_stream_blocks > 0 ? g_stream_blocks : (c.a <= 2 ? 512 : 256);
-  if (c.tiled) s = ((g_stream_blocks > 0 ? g_stream_blocks : tiled_blocks_for(H)) + (Cout / 128) * (Cin / 64) - 1) / ((Cout / 128) * (Cin / 64));   // blocks = splits x channel tiles
+  if (c.tiled) s = ((g_stream_blocks > 0 ? g_stream_blocks : (c.nco == 4 ? g_stream_light_blocks : tiled_blocks_for(H))) + (Cout / (16 * c.nco)) * (Cin / 64) - 1) / ((Cout / (16 * c.nco)) * (Cin / 64));   // blocks = splits x channel tiles
   const int max_s = (Mq + c.bp * 4 - 1) / (c.bp * 4);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -589,8 +599,8 @@ int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil) {
 
 bool mdcv_wgrad_stream_splits_ok(int splits, int B, int H, int W, int Cin, int Cout, int dil) {
   StreamCfg c;
-  if (splits < 1 || !stream_cfg(Cin, Cout, c)) return false;
   const int Mq = B * (H + dil) * (W + dil);
+  if (splits < 1 || !stream_cfg(Cin, Cout, c, Mq)) return false;
   const int pps = ((Mq + splits - 1) / splits + c.bp - 1) / c.bp * c.bp;
   return (Mq + pps - 1) / pps == splits;
 }
@@ -601,7 +611,7 @@ int mdcv_wgrad_stream_batch_splits(int nlayers, int B, int H, int W, int Cin, in
   StreamCfg c;
   if (nlayers < 1 || !stream_cfg_geom(Cin, Cout, W, dil, c) || !c.tiled) return 0;
   const int Mq = B * (H + dil) * (W + dil);
-  const int tiles = (Cout / 128) * (Cin / 64) * nlayers;
+  const int tiles = (Cout / (16 * c.nco)) * (Cin / 64) * nlayers;
   int s = ((g_stream_blocks > 0 ? g_stream_blocks : g_stream_tiled_blocks) + tiles - 1) / tiles;
   const int max_s = (Mq + c.bp * 4 - 1) / (c.bp * 4);
   if (s > max_s) s = max_s;
@@ -613,8 +623,9 @@ int mdcv_wgrad_stream_batch_splits(int nlayers, int B, int H, int W, int Cin, in
 int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, int Cin, int Cout,
                       int dil, hipStream_t st, const void* table, int nlayers) {
   StreamCfg c;
-  if (!stream_cfg_geom(Cin, Cout, W, dil, c)) return MDCV_EARG;
-  if ((table || nlayers != 1) && !c.tiled) return MDCV_EARG;
+  const bool batch = table || nlayers != 1;                  // batches keep the 8-wave form (mdcv_wgrad_stream_batch_splits)
+  if (!stream_cfg_geom(Cin, Cout, W, dil, c, batch ? 0 : (long long)B * (H + dil) * (W + dil))) return MDCV_EARG;
+  if (batch && !c.tiled) return MDCV_EARG;
   WgradStreamArgs a;
   a.dy = dy; a.x = x; a.ws = ws; a.dy_ldc = dy_ldc; a.x_ldc = x_ldc;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Ktot = 9 * Cin; a.dil = dil;
@@ -625,11 +636,15 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   if ((a.Mq + a.pos_per_split - 1) / a.pos_per_split != splits) return MDCV_EARG;
   a.splits = splits;
   a.tiles_ci = c.tiled ? Cin / 64 : 1;
-  a.tiles = c.tiled ? (Cout / 128) * a.tiles_ci : 1;
+  a.tiles = c.tiled ? (Cout / (16 * c.nco)) * a.tiles_ci : 1;
   a.table = table; a.nlayers = nlayers;
   a.xcd_chunk = (nlayers * splits * a.tiles + 7) / 8;
   const int lds = stream_lds(c, W, dil);
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
+  if (c.tiled && c.nw == 4 && c.nco == 4) {
+    if (c.d == 1) return launch_stream<4, 4, 4, 1, 64, 1, 1, true, 4>(a, lds, dyb, xb, st);
+    return launch_stream<4, 4, 4, 1, 64, 2, 1, true, 4>(a, lds, dyb, xb, st);
+  }
   if (c.tiled && c.nw == 4) {
     if (c.d == 1) return launch_stream<4, 8, 8, 1, 64, 1, 1, true, 4>(a, lds, dyb, xb, st);
     if (c.d == 2) return launch_stream<4, 8, 8, 1, 64, 2, 1, true, 4>(a, lds, dyb, xb, st);
@@ -660,8 +675,13 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   return MDCV_EARG;
 }
 
-void mdcv_wgrad_stream_tiled_blocks(int blocks) {      // 30000 + n: block target ; 30001 / 30002: 4-wave / 8-wave form ; 35000 + n: images of at most 16 rows ; 37000 + n: at most 32 rows
-  if (blocks == 1 || blocks == 2) { g_stream_w4 = blocks == 1; return; }
+void mdcv_wgrad_stream_tiled_blocks(int blocks) {      // 30000 + n: block target of the 8-wave form ; 30001: 4 waves x 128 co ; 30002: default choice ; 30003 / 30004: light form everywhere
+                                                       // (depth 1 / 2) ; 30005: never ; 33000 + n: its block target ; 35000 + n: images of at most 16 rows ; 37000 + n: at most 32 rows
+  if (blocks == 1) { g_stream_w4 = 1; return; }
+  if (blocks == 2) { g_stream_w4 = 0; g_stream_light_maxpos = 600000; g_stream_light_d = 1; return; }   // the default: light form for short streams
+  if (blocks == 3 || blocks == 4) { g_stream_w4 = 2; g_stream_light_d = blocks - 2; return; }   // light form everywhere (64 co x 64 ci, 4 waves)
+  if (blocks == 5) { g_stream_w4 = 0; g_stream_light_maxpos = 0; return; }                        // light form never
+  if (blocks >= 3000 && blocks < 5000) { g_stream_light_blocks = blocks - 3000; return; }
   if (blocks >= 9000 && blocks < 9016) { g_stream_tiled_wmask = blocks - 9000; return; }
   if (blocks >= 7000 && blocks < 9000) { g_stream_tiled_blocks_26 = blocks - 7000; return; }
   if (blocks >= 5000 && blocks < 7000) { g_stream_tiled_blocks_13 = blocks - 5000; return; }

@@ -677,6 +677,44 @@ def test_wgrad_stream_kernel(case):
     np.testing.assert_allclose(outs[0][0], outs[9][0], rtol=1e-3, atol=1e-3 * scale)      # same bf16 products, fp32 sums in another order
 
 
+@pytest.mark.parametrize("case", [(4, 128, 256, 13, 13, 1), (2, 64, 128, 26, 20, 1), (3, 256, 128, 9, 17, 2), (2, 128, 128, 52, 52, 1)], ids=str)
+def test_wgrad_tiled_light_and_heavy_forms(case):
+    """The channel-tiled LDS-ring weight gradient has two forms: 128 co x 64 ci per block on 8 waves (it owns its CU) and the light one,
+    64 co x 64 ci on 4 waves (half a CU, the default for position streams of up to 600 K), csrc/wgrad_stream.hip.  Both == torch, both
+    deterministic, and they agree to fp32 summation order (different splits)."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, Co, H, W, dil = case
+    g = torch.Generator().manual_seed(Ci + Co + H + W)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(rnd(dt, x), w, None, stride=1, padding=dil, dilation=dil).backward(rnd(dt, dy))
+    ref = w.grad.numpy()
+    xb, dyb = to_nhwc(x, dt), to_nhwc(dy, dt)
+    outs = {}
+    try:
+        for form, code in (("heavy", 30005), ("light", 30003), ("light, depth 2", 30004)):
+            L.check(L.conv2d_wgrad_set_variant(code))
+            runs = []
+            for _ in range(2):
+                splits = L.conv2d_wgrad_splits_geom(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, dil, dil, Co, Ci)
+                ws = torch.full((splits * Co * 9 * Ci,), float("nan"), dtype=torch.float32, device="cuda")
+                dw = torch.full((Co, Ci, 3, 3), 7.0, dtype=torch.float32, device="cuda")
+                L.check(L.conv2d_wgrad(dt, dyb.data_ptr(), Co, xb.data_ptr(), Ci, ws.data_ptr(), splits, dw.data_ptr(), 0, B, H, W, Ci, Ci,
+                                       H, W, Co, Co, 3, 3, 1, dil, dil, st()), "wgrad " + form)
+                torch.cuda.synchronize()
+                runs.append(dw.cpu().numpy())
+            assert np.array_equal(runs[0], runs[1]), form
+            outs[form] = runs[0]
+    finally:
+        L.conv2d_wgrad_set_variant(30002)          # back to the automatic choice
+    scale = max(1.0, float(np.abs(ref).max()))
+    for form, got in outs.items():
+        np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * scale, err_msg=form)
+    np.testing.assert_allclose(outs["light"], outs["heavy"], rtol=1e-3, atol=1e-3 * scale)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 64, 20, 13, 1), (1, 16, 16, 9, 31, 2), (3, 64, 128, 16, 16, 1)], ids=str)
 def test_wgrad_stream_kernel_channel_slices(case):
     """The LDS-ring weight gradient on operands that are channel slices of wider NHWC buffers (route / concat buffers: ldc > C,
