@@ -143,8 +143,10 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   } while (0)
 #define ISSUE_A_SINK(RS)                     /* the fill behind the last chunk: same DMA count, zeros into the sink */             \
   do {                                                                                                              \
-    _Pragma("unroll") for (int k = 0; k < NPA; ++k)                                                                 \
+    _Pragma("unroll") for (int k = 0; k < NPA; ++k) {                                                               \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + SINK), 16, (int)OOB, 0, 0, 0);              \
+      asm volatile("" ::: "memory");         /* NPA identical DMAs: without the barrier all but the last are dropped as dead stores */ \
+    }                                                                                                               \
   } while (0)
 #define ISSUE_B(RS, TAP, CHUNK, SLOT)                                                                               \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + (wave < BN / 16 ? BBASE + (SLOT) * BTILE + wave * 1024 : SINK)), 16, (int)bvo, \
