@@ -75,14 +75,14 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   constexpr int NW = WM * WN, TN = BN / WN, FN = TN / 16;
   constexpr int TM = BM / WM, FM = TM / 16;
   static_assert(!FUSE || (WN == 2 && BM % 128 == 0), "the fused sums: 8 waves, one partial row per 128 positions");
-  // LDS: [A0: nca KiB][A1: nca KiB (absent when the layer has a single 32-channel chunk)][weight ring: BRING x 8 KiB][1 KiB sink for the surplus chunk DMAs]; the epilogue reuses it
+  // LDS: [A0: nca KiB][A1: nca KiB][weight ring: BRING x 8 KiB][1 KiB sink for the surplus chunk DMAs]; the epilogue reuses it
   // as [bf16 staging BM x SROW][rowpix BM ints][statistics WM*2*BN floats].
   constexpr int STAGE = BM * SROW;
   constexpr int PIX_OFF = STAGE;                           // int rowpix[BM]
   constexpr int STAT_OFF = STAGE + BM * 4;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int ABYTES = a.nca * 1024;
-  const int BBASE = (a.nchunks == 1 ? 1 : 2) * ABYTES;     // a single 32-channel chunk needs no second activation buffer: half the LDS, twice the workgroups per CU
+  const int BBASE = 2 * ABYTES;
   const int SINK = BBASE + BRING * BTILE;
 
   const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
@@ -139,13 +139,6 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
       const int ch__ = wave + k * NW;             /* every wave issues NPA DMAs; chunks past the last go to the sink */ \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + (ch__ < a.nca ? base__ + ch__ * 1024 : SINK)), 16, \
                                                (int)avo[k], so__, 0, 0);                                            \
-    }                                                                                                               \
-  } while (0)
-#define ISSUE_A_SINK(RS)                     /* the fill behind the last chunk: same DMA count, zeros into the sink */             \
-  do {                                                                                                              \
-    _Pragma("unroll") for (int k = 0; k < NPA; ++k) {                                                               \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + SINK), 16, (int)OOB, 0, 0, 0);              \
-      asm volatile("" ::: "memory");         /* NPA identical DMAs: without the barrier all but the last are dropped as dead stores */ \
     }                                                                                                               \
   } while (0)
 #define ISSUE_B(RS, TAP, CHUNK, SLOT)                                                                               \
@@ -210,7 +203,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
             else ISSUE_B(rw, t2, c2, wslot);
           }
           if (tap == 0) {
-            if (lastc) ISSUE_A_SINK(rin0);
+            if (lastc) ISSUE_A(rin0, c + 1, (cc + 1) & 1);
             else ISSUE_A(rin, c + 1, (cc + 1) & 1);
           }
 #ifdef MDCV_SHIFT_PRIO
@@ -437,7 +430,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   a.tiles_total = tiles_m * a.tiles_n;
   a.xcd_chunk = (a.tiles_total + 7) / 8;
   a.nca = (BM + 2 * a.dil * (a.Wq + 1) + 15) / 16;         // KiB-chunks (16 stream rows each) of one activation chunk
-  const int pipe = (a.nchunks == 1 ? 1 : 2) * a.nca * 1024 + BRING * BTILE + 1024;
+  const int pipe = 2 * a.nca * 1024 + BRING * BTILE + 1024;
   const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics (the fused sums fold inside dead staging rows)
   const int lds = pipe > epi ? pipe : epi;
   static int attr_lds = 0;
