@@ -113,6 +113,9 @@ def call_work(name, args):
     one MAC per (dy pixel, tap, ci, co)).  BatchNorm / activation passes: every operand tensor once."""
     if name == "mdcv_conv2d":
         return conv_flops(args), 0.0
+    if name == "mdcv_conv2d_affine_act":     # inference conv + BatchNorm(running stats) + activation: (dt, x, ldx, w, out, ldo, scale, shift, resid, ldr, act, slope, B, H, W, Cin, Ho, Wo, Cout, kh, kw, ...)
+        B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW = args[12:21]
+        return 2.0 * B * Hout * Wout * Nout * KH * KW * Cin, 0.0
     if name == "mdcv_conv2d_dgrad_bnsums":
         Bq, Hin, Win, Cin, Hout, Wout, Nout, KH, KW = args[8:17]
         return 2.0 * Bq * Hin * Win * Cin * KH * KW * Nout, 0.0
@@ -181,7 +184,6 @@ def kernel_breakdown(model, plan, step_fn):
                 LAUNCH_DUMP.append((name, ms, list(args), [(short_symbol(k), t) for k, t in kern]))
             elif name.startswith("mdcv_bn_act") or name in ("mdcv_partial_reduce",):
                 LAUNCH_DUMP.append((name, ms, [int(v) for v in args if isinstance(v, int) and 0 < v < (1 << 31)][-6:]))
-    orig_run = plan.run
 
     def run_and_time(lst, stream=None):
         add(run_timed(plan, lst, stream, kernels=True))
@@ -192,19 +194,49 @@ def kernel_breakdown(model, plan, step_fn):
         step_fn()
         torch.cuda.synchronize()
     finally:
-        plan.run = orig_run
+        plan.__dict__.pop("run", None)             # (an instance attribute `run` keeps run_bwd_list serial: remove it, do not re-assign)
         plan.use_graph = g
     return rec, krec
 
 
+def in_step_kernel_times(step_fn, steps=3):
+    """Per-kernel durations INSIDE the normal training step, measured live: the in-library profiler (csrc/runtime.hip) binds a start /
+    stop HIP event pair to every dispatch on the stream it is launched on (main stream and the weight-gradient side stream alike),
+    so kernels of the two streams share the CUs exactly as in the timed region.  -> {short symbol: [launches per step, ms per step]}"""
+    import ctypes
+    from mdcv import _lib
+    L = _lib.lib()
+    step_fn()
+    torch.cuda.synchronize()
+    L.check(L.profile_begin(), "profile_begin")
+    try:
+        for _ in range(steps):
+            step_fn()
+        torch.cuda.synchronize()
+    finally:
+        nrec = L.profile_stop()
+    if nrec < 0:
+        raise _lib.MdcvError(f"mdcv_profile_stop failed ({nrec})")
+    out = {}
+    buf = ctypes.create_string_buffer(1024)
+    ms = ctypes.c_float()
+    for i in range(nrec):
+        L.check(L.profile_read(i, ctypes.byref(ms), buf, 1024), "profile_read")
+        e = out.setdefault(short_symbol(buf.value.decode()), [0.0, 0.0])
+        e[0] += 1.0 / steps
+        e[1] += ms.value / steps
+    L.profile_begin()            # drop the records (events) ...
+    L.profile_stop()             # ... and leave the profiler off
+    return out
+
+
 def roofline_objects(krec, precision, traffic, in_step=None):
-    """`roofline` = the ONE kernel symbol with the largest share of the step's kernel time among the kernels whose algorithmic work
-    is modelled; `roofline_kernels` = every modelled kernel symbol (MFMA-bound convolutions / weight gradients in TFLOP/s, HBM-bound
-    BatchNorm passes in GB/s), largest total time first.  `avg_us` / `achieved` / `frac`: the in-library start / stop HIP event pair of
-    each dispatch on its launch stream (hipExtLaunchKernel) in one instrumented step that runs every kernel ALONE on the GPU -- the
-    kernel's own quality.  In the timed steps the weight gradients run on a side stream beside the main stream's kernels and both
-    stretch; `avg_us_in_step` / `achieved_in_step` quote that from the rocprofv3 kernel trace of this same command committed under
-    profiles/ (only when it was taken with this tree's kernels)."""
+    """Every kernel symbol whose algorithmic work is modelled (MFMA-bound convolutions / weight gradients in TFLOP/s, HBM-bound
+    BatchNorm passes in GB/s), largest share of the step first.  Work per launch comes from one instrumented SERIAL step (krec: every
+    kernel alone on the GPU -> `avg_us_alone`, `frac_alone` = the kernel's own quality).  `avg_us`, `achieved`, `frac` are the IN-STEP
+    figures: the same start / stop event pairs taken live inside normal steps (in_step_kernel_times), where the side stream's weight
+    gradients and the main stream's kernels share the CUs -- what the timed region contains and what a rocprofv3 kernel trace of this
+    command reports.  Returns (dominant row, all rows)."""
     peak_f = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
     rows = []
     for sym, e in krec.items():
@@ -212,38 +244,25 @@ def roofline_objects(krec, precision, traffic, in_step=None):
             continue
         mf = e["flops"] > 0
         work, div = (e["flops"], 1e12) if mf else (e["bytes"], 1e9)
-        ach = work / (e["ms"] * 1e-3) / div
         peak = peak_f if mf else PEAK_HBM_GBS
-        row = {"kernel": short_symbol(sym), "symbol": sym, "bound": "mfma" if mf else "hbm", "launches": e["launches"],
-               "avg_us": 1e3 * e["ms"] / e["launches"], "total_ms": e["ms"], "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mf else "GB/s",
-               "frac": ach / peak, ("flops_per_launch" if mf else "bytes_per_launch"): work / e["launches"]}
-        ns = (in_step or {}).get(short_symbol(sym))
-        if ns:
-            row["avg_us_in_step"] = ns / 1e3
-            row["achieved_in_step"] = work / e["launches"] / (ns * 1e-9) / div
+        per_launch = work / e["launches"]
+        us_alone = 1e3 * e["ms"] / e["launches"]
+        row = {"kernel": short_symbol(sym), "bound": "mfma" if mf else "hbm", "launches": e["launches"], "peak": peak,
+               "unit": "TFLOP/s" if mf else "GB/s", ("flops_per_launch" if mf else "bytes_per_launch"): per_launch,
+               "avg_us_alone": us_alone, "frac_alone": per_launch / (us_alone * 1e-6) / div / peak}
+        st = (in_step or {}).get(short_symbol(sym))
+        if st and st[0] > 0:
+            us = 1e3 * st[1] / st[0]
+            row.update(avg_us=us, achieved=per_launch / (us * 1e-6) / div, total_ms=st[1], timing="in-step (live HIP event pairs, both streams running)")
+        else:
+            row.update(avg_us=us_alone, achieved=per_launch / (us_alone * 1e-6) / div, total_ms=e["ms"], timing="alone (serial instrumented step)")
+        row["frac"] = row["achieved"] / peak
         t = (traffic or {}).get("kernels", {}).get(short_symbol(sym)) if traffic else None
         row["traffic"] = (t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) if t else None
         rows.append(row)
     rows.sort(key=lambda r: -r["total_ms"])
     top = dict(rows[0]) if rows else None
     return top, rows
-
-
-def load_in_step_stats(workload):
-    """{kernel: average ns} from the newest profiles/rNN_<workload>_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this very
-    command, scripts/profile_round.sh) whose companion JSON line carries this tree's kernel fingerprint; else (None, reason)."""
-    import csv
-    import glob
-    from mdcv._fingerprint import kernel_fingerprint
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{workload}_bench_under_rocprof.json")), reverse=True):
-        try:
-            line = json.loads([ln for ln in open(f).read().splitlines() if ln.startswith("{")][-1])
-        except Exception:
-            continue
-        c = f.replace("_bench_under_rocprof.json", "_bench_kernel_stats.csv")
-        if line.get("fingerprint") == kernel_fingerprint() and os.path.exists(c):
-            return {short_symbol(r["Name"]): float(r["AverageNs"]) for r in csv.DictReader(open(c))}, os.path.basename(c)
-    return None, "no rocprofv3 kernel stats under profiles/ taken with this tree's kernels"
 
 
 def load_traffic():
@@ -363,6 +382,125 @@ def cpu_baseline_post(out_np, tg_np, budget_s=10.0):
             "sample": f"numpy oracle of validate.py:80-141 on {n} images of the same batch ([10647, 85] rows each)"}
 
 
+def cpu_baseline_joint(cfg_path, workdir, frames=1):
+    """The chained CPU oracles of the joint path on the host cores: Darknet eval forward at 608^2 -> per-image conf filter / NMS ->
+    8-bit crop + resize -> KeypointNet eval on the crops.  A random-init detector has no confident rows, so (as in the GPU leg) the
+    stages behind it run on 16 synthetic cone boxes per frame."""
+    from oracle import yolo_oracle as yo, postprocess_oracle as PO, pipeline_oracle as PL, rektnet_oracle as ro
+    torch.set_num_threads(min(os.cpu_count(), CPU_THREADS))
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        cfg608 = write_yolo_cfg(workdir, size=608, classes=int(open(cfg_path).read().split("classes=")[1].split()[0]))
+        orc = yo.DarknetOracle(cfg608, anchors=yo.VANILLA_ANCHORS, seed=0)
+    finally:
+        os.chdir(cwd)
+    rng = np.random.default_rng(5)
+    f8 = rng.integers(0, 256, (frames, 3, 608, 608), dtype=np.uint8)
+    x = torch.from_numpy((f8.astype(np.float32) / 255.0))
+    sd = ro.init_state(0)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        rows = orc.forward(x, None, bn_train=False).numpy()
+    boxes = np.zeros((frames, 16, 4), np.float32)
+    count = np.full(frames, 16, np.int32)
+    for b in range(frames):
+        c = rng.random((16, 2)) * 540 + 34
+        wh = np.stack([rng.random(16) * 40 + 14, rng.random(16) * 60 + 20], 1)
+        rows[b, :16, 0:2], rows[b, :16, 2:4], rows[b, :16, 4] = c, wh, 0.9
+        r = PO.postprocess_image(rows[b], np.zeros((1, 5), np.float32), 0.8, 0.25, 0.5, 608, 608)
+        n = min(r["count"], 16)
+        boxes[b, :n], count[b] = r["boxes"][:n], n
+    crops, _ = PL.crop_resize(f8, boxes, count, 80, 80, u8=True)
+    with torch.no_grad():
+        ro.keypoint_forward(torch.from_numpy(crops), sd, train=False)
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"chained CPU oracles on {frames} frame(s) 608^2: Darknet eval -> NMS -> {int(count.sum())} u8 crops -> KeypointNet eval"}
+
+
+MAX_LINE_BYTES = 3500      # the driver keeps an 8.4 KB tail of stdout and parses the last line whole: stay far below it
+
+
+def _r(v, nd=4):
+    """floats rounded to `nd` significant digits (the line is for reading and parsing, the detail file keeps full precision)"""
+    if isinstance(v, float):
+        return float(f"{v:.{nd}g}")
+    if isinstance(v, dict):
+        return {k: _r(x, nd) for k, x in v.items()}
+    if isinstance(v, list):
+        return [_r(x, nd) for x in v]
+    return v
+
+
+def compact(line):
+    """The ONE stdout line: rounded, and -- should a future field push it over MAX_LINE_BYTES -- the optional blocks are dropped in a
+    fixed order (never metric / value / ms_per_step / config / roofline / cpu_baseline)."""
+    out = _r(line, 5)
+    for k in ("value", "ms_per_step"):
+        out[k] = line[k]
+    for victim in ("workloads", "env_overrides", "detail"):
+        if len(json.dumps(out)) <= MAX_LINE_BYTES:
+            break
+        out.pop(victim, None)
+    assert len(json.dumps(out)) <= MAX_LINE_BYTES, len(json.dumps(out))
+    return out
+
+
+ROOFLINE_KEYS = ("kernel", "bound", "launches", "avg_us", "achieved", "peak", "unit", "frac", "timing", "avg_us_alone", "frac_alone",
+                 "flops_per_launch", "bytes_per_launch", "traffic", "traffic_source")
+
+
+def live_env_overrides():
+    """MDCV_* variables that change what the timed step launches; stamped into the line."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("MDCV_") and k not in ("MDCV_GRAPH", "MDCV_DIST_BACKEND")}
+
+
+def build_line(a, world, primary, result, extra, cpu_baseline):
+    from mdcv._fingerprint import kernel_fingerprint
+    from mdcv import _lib
+    roof = result.get("roofline")
+    line = {
+        "metric": ("images/sec training (YOLOv3 416^2 + RektNet 80^2)" if primary in ("yolo", "rektnet") else
+                   "images/sec validation post-processing" if primary == "postprocess" else
+                   "images/sec joint detect->keypoints inference"), "value": result["value"], "unit": "images/sec",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": result["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+        "config": {"workload": {"yolo": "CVC-YOLOv3 yolo_baseline 416x416 classes=%d, train step (fwd+bwd+Adam), %d img/GPU" % (a.yolo_classes, a.yolo_batch),
+                                "rektnet": "RektNet KeypointNet 80x80 train step (l1_softargmax+geo, Adam), %d img/GPU" % a.rekt_batch,
+                                "postprocess": "validate.py per-image loop (conf 0.8, NMS 0.25 top-200, AP) on [%d,10647,85] eval outputs"
+                                               % a.post_batch,
+                                "joint": "YOLOv3 608x608 eval -> conf/NMS -> <=16 crops/frame 80x80 -> KeypointNet eval, %d frames/GPU"
+                                         % a.joint_batch}[primary],
+                   "global_batch": {"yolo": a.yolo_batch, "rektnet": a.rekt_batch, "postprocess": a.post_batch, "joint": a.joint_batch}[primary] * world,
+                   "parallelism": f"dp{world}", "hipgraph": bool(a.graph), "optimizer": "FusedAdam"},
+        "roofline": {k: roof[k] for k in ROOFLINE_KEYS if k in roof} if roof else None,
+        "cpu_baseline": cpu_baseline,
+        "host_cores": os.cpu_count(),
+        "fingerprint": kernel_fingerprint(),
+        "workloads": extra,
+    }
+    env = live_env_overrides()
+    if env:
+        line["env_overrides"] = env
+    if os.environ.get("MDCV_LIB"):
+        line["lib_path"] = _lib.LIB_PATH
+    return line
+
+
+def write_detail(line, extra, detail):
+    """Per-kernel tables (every modelled kernel's roofline row, per-call and per-kernel times, launch counts) go to bench_detail.json:
+    gpurun_out/ when it exists (it is merged back from the GPU box), else the repo root; scripts/profile_round.sh copies it to profiles/."""
+    d = os.path.join(ROOT, "gpurun_out")
+    path = os.path.join(d if os.path.isdir(d) else ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as f:
+            json.dump({"line": line, "workloads": extra, **detail}, f, indent=1)
+        return path
+    except OSError:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -433,6 +571,7 @@ def main():
 
     result = {}
     extra = {}
+    detail = {}            # per-kernel tables: written to bench_detail.json, NOT into the one line the driver parses
     tmp = tempfile.mkdtemp(prefix="mdcv_bench_")
     cfg = write_yolo_cfg(tmp, classes=a.yolo_classes)
 
@@ -489,29 +628,41 @@ def main():
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             extra["yolo"]["replicas_in_sync"] = bool((hi - lo).abs().item() <= 1e-6 * max(1.0, abs(hi.item())))
             extra["yolo"]["comm"] = dict(comm or {}, backend="rccl" if backend == "nccl" else backend, ranks=dist.get_world_size(),
-                                         gradient_bytes=int(net.flat_parameters()[1].numel() * 4), bucket_mb=32.0,
-                                         note="allreduce_busy_ms = time the comm stream spent inside all-reduce calls per step; exposed_comm_ms = how "
-                                              "long after the last compute kernel of backward the last bucket finished (rank 0, HIP events)")
-        if not a.no_breakdown:        # every rank runs the instrumented step (it contains the collective); rank 0 reports
+                                         gradient_bytes=int(net.flat_parameters()[1].numel() * 4), bucket_mb=32.0)
+            # allreduce_busy_ms = time the comm stream spent inside all-reduce calls per step; exposed_comm_ms = how long after the last
+            # compute kernel of backward the last bucket finished (rank 0, HIP events)
+        if not a.no_breakdown:        # every rank runs the instrumented steps (they contain the collective); rank 0 reports
             plan = [p for p in net._plans.values() if p.has_bwd][0]
-            rec, krec = kernel_breakdown(net, plan, yolo_step)
+            in_step = in_step_kernel_times(yolo_step)            # live, inside normal two-stream steps
+            rec, krec = kernel_breakdown(net, plan, yolo_step)   # one serial step: work per launch + kernel-alone durations
             tot = sum(v[1] for v in rec.values())
-            extra["yolo"]["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])}
-            extra["yolo"]["kernel_launches_per_step"] = {k: v[0] for k, v in rec.items()}
-            extra["yolo"]["sum_kernel_ms"] = round(tot, 3)
-            traffic, why = (load_traffic() if (B == 32 and a.precision == "bf16" and a.yolo_classes == 80) else (None, "non-default workload"))
-            in_step, src = load_in_step_stats("yolo") if (B == 32 and a.precision == "bf16" and a.yolo_classes == 80) else (None, "non-default workload")
+            detail["yolo_call_ms_per_serial_step"] = {k: round(v[1], 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])}
+            detail["yolo_call_launches_per_step"] = {k: v[0] for k, v in rec.items()}
+            detail["yolo_kernel_ms_in_step"] = {k: [round(v[0], 2), round(v[1], 4)] for k, v in sorted(in_step.items(), key=lambda kv: -kv[1][1])}
+            extra["yolo"]["sum_kernel_ms_serial"] = round(tot, 3)
+            extra["yolo"]["kernel_launches_per_step"] = int(round(sum(v[0] for v in in_step.values())))
+            default_cfg = B == 32 and a.precision == "bf16" and a.yolo_classes == 80
+            traffic, why = load_traffic() if default_cfg else (None, "non-default workload")
             top, rows = roofline_objects(krec, a.precision, traffic, in_step)
             if top:
-                top["traffic_source"] = traffic["_file"] if traffic else None
-                if not traffic:
-                    top["traffic_reason"] = why
-                top["in_step_source"] = src
-                top["note"] = ("dominant kernel of the step by total time; achieved = algorithmic FLOPs of the launches dispatched to this symbol / their "
-                               "summed duration (start / stop HIP events of each dispatch on its launch stream, one instrumented step, kernels alone on "
-                               "the GPU); *_in_step: the same from the rocprofv3 trace of this command, where side-stream and main-stream kernels share the CUs")
+                top["traffic_source"] = traffic["_file"] if traffic else why
                 result["roofline"] = top
-                result["roofline_kernels"] = [{k: v for k, v in r.items() if k != "symbol"} for r in rows]
+                detail["yolo_roofline_kernels"] = rows
+                if traffic:
+                    extra["yolo"]["hbm_bytes_per_step"] = traffic.get("total_bytes_per_step")
+        if world > 1:
+            # the number that decides the exchange design on hardware: the same step on the same ranks with the reducer DETACHED (no
+            # all-reduce; replicas diverge from here on, so this runs last).  stretch = attached / detached.
+            net._dp_reducer = None
+            nd = max(3, min(10, a.steps))
+
+            def yolo_step_local():
+                opt.zero_grad()
+                net(x, tg)[0].sum().backward()
+                opt.step()
+            dtd = timed_region(yolo_step_local, nd, 3, device, world)
+            extra["yolo"]["comm"]["ms_per_step_reducer_detached"] = 1e3 * dtd / nd
+            extra["yolo"]["comm"]["step_stretch_with_reducer"] = (dt / a.steps) / (dtd / nd)
         if world == 1 and a.precision == "bf16" and not a.no_fp32 and a.workload in ("both", "yolo"):
             # the reference computes in fp32: the same step with the fp32 kernels (exact-f32 MFMA), reported beside the bf16 value
             del opt
@@ -534,7 +685,7 @@ def main():
             n32 = max(2, min(5, a.steps))
             dt32 = timed_region(yolo_step32, n32, 2, device, 1)
             extra["yolo"]["fp32_images_per_sec"] = B * n32 / dt32
-            extra["yolo"]["fp32_note"] = f"same step with precision='fp32' (fp32 storage, v_mfma_f32_16x16x4_f32), {n32} timed steps after 2 warm-up"
+            detail["yolo_fp32_note"] = f"same step with precision='fp32' (fp32 storage, v_mfma_f32_16x16x4_f32), {n32} timed steps after 2 warm-up"
             del net32, opt32
             opt = None
         del net, opt
@@ -568,18 +719,21 @@ def main():
                             "hbm_frac_step": ips * REKT_TRAIN_MB_PER_IMG / 1e3 / (PEAK_HBM_GBS * world)}
         if not a.no_breakdown:
             plan = [p for p in kp._plans.values() if p.has_bwd][0]
+            in_step = in_step_kernel_times(rekt_step)
             rec, krec = kernel_breakdown(kp, plan, rekt_step)
-            extra["rektnet"]["kernel_ms_per_step"] = {k: round(v[1], 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])}
-            top, rows = roofline_objects(krec, a.precision, None)
-            extra["rektnet"]["roofline_kernels"] = [{k: v for k, v in r.items() if k != "symbol"} for r in rows]
-            if a.workload == "rektnet" and top:
-                top["traffic_source"] = None
-                result_roof = top
+            detail["rektnet_call_ms_per_serial_step"] = {k: round(v[1], 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])}
+            detail["rektnet_kernel_ms_in_step"] = {k: [round(v[0], 2), round(v[1], 4)] for k, v in sorted(in_step.items(), key=lambda kv: -kv[1][1])}
+            top, rows = roofline_objects(krec, a.precision, None, in_step)
+            detail["rektnet_roofline_kernels"] = rows
+            if top:
+                top["traffic_source"] = "not collected for this workload"
+                extra["rektnet"]["dominant_kernel"] = {k: top[k] for k in ("kernel", "bound", "avg_us", "frac", "frac_alone")}
+                if a.workload == "rektnet":
+                    result_roof = top
         if a.workload == "rektnet":
             result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
             if not a.no_breakdown and top:
                 result["roofline"] = result_roof
-                result["roofline_kernels"] = extra["rektnet"]["roofline_kernels"]
 
     if a.workload in ("both", "postprocess"):
         # validate.py's per-image loop for one batch of eval outputs [B, 10647, 85] (416^2, 80 classes),
@@ -681,37 +835,42 @@ def main():
                           "conf_thres": thr, "kept_per_frame_mean": float(det.count.float().mean()), "stage_ms": {k: round(v, 4) for k, v in stages.items()},
                           "stage_images_per_sec": {k: round(B * world / (v * 1e-3), 1) for k, v in stages.items()}}
         result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
+        if not a.no_breakdown:
+            def joint_step():
+                with torch.no_grad():
+                    pipe(x, frames=x8)
+            plan = [p for p in net._plans.values() if not p.has_bwd][0]
+            in_step = in_step_kernel_times(joint_step)
+
+            def det_step():
+                with torch.no_grad():
+                    net(x)
+            rec, krec = kernel_breakdown(net, plan, det_step)
+            top, rows = roofline_objects(krec, a.precision, None, in_step)
+            detail["joint_roofline_kernels"] = rows
+            detail["joint_kernel_ms_in_step"] = {k: [round(v[0], 2), round(v[1], 4)] for k, v in sorted(in_step.items(), key=lambda kv: -kv[1][1])}
+            if top:
+                top["traffic_source"] = "not collected for this workload"
+                result["roofline"] = top
 
     if rank == 0:
         primary = a.workload if a.workload in ("rektnet", "postprocess", "joint") else "yolo"
-        line = {
-            "metric": ("images/sec training (YOLOv3 416^2 + RektNet 80^2)" if primary in ("yolo", "rektnet") else
-                       "images/sec validation post-processing" if primary == "postprocess" else
-                       "images/sec joint detect->keypoints inference"), "value": result["value"], "unit": "images/sec",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": result["ms_per_step"], "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": {"yolo": "CVC-YOLOv3 yolo_baseline 416x416 classes=%d, train step (fwd+bwd+Adam), %d img/GPU" % (a.yolo_classes, a.yolo_batch),
-                                    "rektnet": "RektNet KeypointNet 80x80 train step (l1_softargmax+geo, Adam), %d img/GPU" % a.rekt_batch,
-                                    "postprocess": "validate.py per-image loop (conf 0.8, NMS 0.25 top-200, AP) on [%d,10647,85] eval outputs"
-                                                   % a.post_batch,
-                                    "joint": "YOLOv3 608x608 eval -> conf/NMS -> <=16 crops/frame 80x80 -> KeypointNet eval, %d frames/GPU"
-                                             % a.joint_batch}[primary],
-                       "global_batch": {"yolo": a.yolo_batch, "rektnet": a.rekt_batch, "postprocess": a.post_batch, "joint": a.joint_batch}[primary] * world,
-                       "parallelism": f"dp{world}", "hipgraph": bool(a.graph), "optimizer": "FusedAdam" + (" (pipelined under the next forward)" if OPT_PIPELINE else "")},
-            "workloads": extra,
-        }
-        line["roofline"] = result.get("roofline")
-        line["roofline_kernels"] = result.get("roofline_kernels")
-        line["host_cores"] = os.cpu_count()
-        from mdcv._fingerprint import kernel_fingerprint
-        line["fingerprint"] = kernel_fingerprint()
+        cb = None
         if world == 1 and not a.no_cpu_baseline:
             cb = (cpu_baseline_yolo(cfg, tmp) if primary == "yolo" else cpu_baseline_rektnet() if primary == "rektnet"
-                  else extra["postprocess"]["cpu_baseline"] if primary == "postprocess" else None)
-            line["cpu_baseline"] = cb
+                  else extra["postprocess"].pop("cpu_baseline", None) if primary == "postprocess" else cpu_baseline_joint(cfg, tmp))
             if a.workload == "both":
-                line["workloads"]["rektnet"]["cpu_baseline"] = cpu_baseline_rektnet()
-        print(json.dumps(line))
+                rb = cpu_baseline_rektnet()
+                detail["rektnet_cpu_baseline"] = rb
+                extra["rektnet"]["cpu_images_per_sec"] = rb["value"]
+                pb = extra["postprocess"].pop("cpu_baseline", None)
+                if pb:
+                    detail["postprocess_cpu_baseline"] = pb
+                    extra["postprocess"]["cpu_images_per_sec"] = pb["value"]
+        line = build_line(a, world, primary, result, extra, cb)
+        detail_path = write_detail(line, extra, detail)
+        line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+        print(json.dumps(compact(line)))
     if rank == 0 and a.dump_launches:
         with open(a.dump_launches, "w") as f:
             json.dump(LAUNCH_DUMP, f)

@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def fingerprint_files():
-    pats = ["csrc/*.hip", "csrc/*.h", "csrc/Makefile", "engine.py", "yolo/models.py", "rektnet/keypoint_net.py", "optim.py"]
+    pats = ["csrc/*.hip", "csrc/*.h", "csrc/*.inc", "csrc/Makefile", "engine.py", "_lib.py", "yolo/models.py", "rektnet/keypoint_net.py",
+            "rektnet/resnet.py", "optim.py", "pipeline.py", "parallel.py"]
     out = []
     for p in pats:
         out += sorted(glob.glob(os.path.join(_HERE, p)))

@@ -139,6 +139,7 @@ class Plan:
         self._pending_updates = []         # deferred group updates (closures), launched from the forward list
         self._packed_ahead = False         # the optimizer already re-packed every layer for the coming forward
         self._packed_version = -1
+        self._packed_tversion = -1
         self.owner = None                  # the model (FlatParamsMixin) whose parameters this plan reads
         self.grad_offset = None            # callable(param) -> offset in the flat gradient buffer
         self.low_water = 1 << 62
@@ -559,7 +560,12 @@ class Plan:
             owner = plan.owner
             if plan._packed_ahead:                       # the optimizer packed every layer behind its update (optim.py, pipeline=True);
                 plan._packed_ahead = False               # the per-group waits further down this list order the forward behind it
-                if owner is None or getattr(owner, "_param_epoch", 0) == plan._packed_version:
+                # two guards: the parameter epoch (load_weights / load_state_dict / re-flatten / another optimizer step; the raw kernels
+                # bump no tensor version) AND the parameters' own version counters (user code editing parameters in place between step()
+                # and this forward: nn.init.*, p.clamp_() under no_grad, EMA copy-back -- a Parameter whose .data is a view of the flat
+                # buffer keeps its OWN counter, the flat buffer's does not move)
+                if owner is None or (getattr(owner, "_param_epoch", 0) == plan._packed_version
+                                     and owner._param_versions() == plan._packed_tversion):
                     return 0
             if owner is not None:
                 owner._param_sync()

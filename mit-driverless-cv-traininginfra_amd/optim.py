@@ -102,6 +102,7 @@ class FusedAdam(_FlatOptimizer):
         plan._packed_ahead = True
         model._params_changed()                                     # every other plan's packed operands are stale from here on
         plan._packed_version = model._param_epoch                   # (load_weights / load_state_dict bump the epoch too: this pack is then redone)
+        plan._packed_tversion = model._param_versions()             # (in-place edits of a parameter by user code bump ITS version counter)
         model._pipe_plan = plan
 
     @torch.no_grad()

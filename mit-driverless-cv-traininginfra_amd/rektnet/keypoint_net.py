@@ -55,7 +55,7 @@ class _KpPlan(_NetPlan):
             self.run_bwd_list()
 
 
-class KeypointNet(nn.Module, FlatParamsMixin):
+class KeypointNet(FlatParamsMixin, nn.Module):
     def __init__(self, num_kpt=7, image_size=(80, 80), onnx_mode=False, init_weight=True, precision=None):
         super().__init__()
         width = 16
@@ -99,6 +99,13 @@ class KeypointNet(nn.Module, FlatParamsMixin):
             elif isinstance(m, nn.Linear):
                 nn.init.normal_(m.weight, 0, 0.01)
                 nn.init.constant_(m.bias, 0)
+
+    def _flatten(self):
+        import weakref
+        super()._flatten()
+        for m in self.modules():                 # the blocks' parameters are views of THIS module's flat buffer now: a stand-alone call of a
+            if isinstance(m, ResNet):            # block would re-flatten them out of it (ResNet.forward refuses while the parent is intact)
+                m._flat_parent = weakref.ref(self)
 
     def forward(self, x):
         _lib.require_gpu(x)

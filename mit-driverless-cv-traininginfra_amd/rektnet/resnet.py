@@ -87,7 +87,7 @@ class _BlockPlan(_NetPlan):
     def run_backward(self, gout):
         self.run_bwd_list()
 
-class ResNet(nn.Module, FlatParamsMixin):
+class ResNet(FlatParamsMixin, nn.Module):
     def __init__(self, in_channels, out_channels, precision=None):
         super().__init__()
         self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=2, dilation=2)
@@ -109,6 +109,16 @@ class ResNet(nn.Module, FlatParamsMixin):
     def forward(self, x):
         """Stand-alone block (inside KeypointNet the blocks run as part of the network's plan and this is not called)."""
         _lib.require_gpu(x)
+        parent = getattr(self, "_flat_parent", None)
+        if parent is not None and parent() is not None and parent()._flat_ok():
+            raise RuntimeError("this ResNet block's parameters are views of its KeypointNet's flat buffer: calling the block on its own would "
+                               "re-flatten them out of the parent (dropping the parent's launch plans). Run the block through the network, or "
+                               "copy.deepcopy() it first.")
+        if not self.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # the reference block is differentiable in eval mode; this build has no BatchNorm-eval backward (not on the training hot path):
+            # refuse instead of returning a tensor without a graph (silently zero / None gradients)
+            raise NotImplementedError("ResNet block in eval mode with gradients enabled: wrap the call in torch.no_grad() (inference) or "
+                                      "switch to .train() -- there is no BatchNorm-eval backward on the HIP path")
         if not self._flat_ok():
             self._flatten()
         B, C, H, W = x.shape

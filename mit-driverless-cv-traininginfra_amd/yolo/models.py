@@ -206,7 +206,6 @@ class _DarknetTrainFn(torch.autograd.Function):
 
 
 _TAIL_PROBE = os.environ.get("MDCV_TAIL_PROBE", "0") == "1"
-_ABLATE = frozenset(v for v in os.environ.get("MDCV_ABLATE", "").split(",") if v)     # timing experiments: results are wrong by construction
 _CHECK_TARGETS = os.environ.get("MDCV_CHECK_TARGETS", "1") == "1"
 _BAD_TARGET_MSG = ("index out of range in build_targets: a target has cx >= 1.0 or cy >= 1.0 (grid cell == grid size), where the reference "
                    "raises IndexError at utils/utils.py:262")
@@ -299,10 +298,6 @@ class _NetPlan(Plan):
 
     def run_bwd_list(self):
         """The backward launch list on the current stream, weight gradients on the side stream (see above)."""
-        if _ABLATE and not getattr(self, "_ablated", False):          # timing experiments only (scripts/ablate.sh): drop launches by name
-            self._ablated = True
-            self.fwd = [(f, a) for f, a in self.fwd if getattr(f, "__name__", "") not in _ABLATE]
-            self.bwd = [(f, a) for f, a in self.bwd if getattr(f, "__name__", "") not in _ABLATE]
         cur = torch.cuda.current_stream()
         if not self.overlap_wgrad or "run" in self.__dict__:                   # (bench.py's per-kernel timing swaps `run`)
             self.run(self.bwd, cur.cuda_stream)
@@ -359,12 +354,24 @@ class FlatParamsMixin:
         self._flat_ptrs = [p.data_ptr() for p in plist]
         self._plans = {}
         self._pipe_plan = None
+        self._last_train_plan = None         # it was built on the old flat buffers: a pipelined optimizer step must not reuse its pack table
         self._params_changed()
 
     # run-time caches that must not travel with a copy / pickle of the model: launch plans hold ctypes function pointers, raw device
     # pointers and closures (copy.deepcopy(model) after a forward -- RektNet/train_eval.py:99 -- raised "ctypes objects containing
     # pointers cannot be pickled"); the copy re-flattens its parameters and rebuilds its plans on first use.
-    _TRANSIENT = ("_plans", "_pipe_plan", "_last_train_plan", "_dp_reducer", "_pflat", "_gflat", "_flat_ptrs", "_goff", "_plist")
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel (reference train.py:193-195 wraps the model when torch.cuda.device_count() > 1) copies the module tree onto
+        every device per forward.  These models own flat parameter / gradient buffers, ctypes launch plans bound to raw device
+        pointers, and side streams: a replica would launch kernels on device 0's memory.  Fail loudly instead."""
+        raise RuntimeError(
+            f"{type(self).__name__} cannot be replicated by torch.nn.DataParallel: the MI355X-native path is one process per GPU. "
+            "Launch the script with `python -m torch.distributed.run --nproc-per-node N ...`, give every rank its shard of the batch and "
+            "attach `mdcv.parallel.GradAllReducer.attach(model)` (all-reduce(SUM) of the flat gradient over RCCL -- the same per-shard "
+            "BatchNorm / build_targets + summed-gradient semantics as DataParallel), or hide the other GPUs from a single-process run "
+            "(HIP_VISIBLE_DEVICES=0).  See INTEGRATION.md §1.")
+
+    _TRANSIENT = ("_plans", "_pipe_plan", "_last_train_plan", "_dp_reducer", "_pflat", "_gflat", "_flat_ptrs", "_goff", "_plist", "_flat_parent")
 
     def _state_without_plans(self):
         d = {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
@@ -393,6 +400,8 @@ class FlatParamsMixin:
 
     def _evict_plan(self, key):
         plan = self._plans.pop(key)
+        if getattr(plan, "err_views", ()) and _CHECK_TARGETS:
+            plan.check_targets()                             # a pending bad-label flag must not be lost with the plan (last batch of a run)
         if getattr(self, "_pipe_plan", None) is plan:
             self._param_sync()                               # its deferred parameter-group updates must land first
             self._pipe_plan = None
@@ -410,6 +419,10 @@ class FlatParamsMixin:
         """Parameters were rewritten behind the optimizer's back (load_weights / load_state_dict): operands packed ahead of the next
         forward by a pipelined optimizer step are stale."""
         self._param_epoch = getattr(self, "_param_epoch", 0) + 1
+
+    def _param_versions(self):
+        """Sum of the parameters' autograd version counters: moves when user code edits any parameter in place (the HIP kernels do not)."""
+        return sum(p._version for p in self._plist)
 
     def _flat_ok(self):
         pl = getattr(self, "_plist", None)
@@ -443,6 +456,10 @@ class FlatParamsMixin:
 
     def _run_backward(self, plan, gout):
         self._last_train_plan = plan
+        # a label with cx / cy >= 1.0 (reference: IndexError inside build_targets, BEFORE any update, utils/utils.py:262): the flag copy
+        # recorded behind the forward has almost always landed by now, so raising here precedes optimizer.step()
+        if getattr(plan, "err_views", ()) and _CHECK_TARGETS:
+            plan.check_targets()
         pl = self._plist
         keep = None
         if pl[0].grad is not None:                       # gradients were not reset to None: accumulate semantics
@@ -468,7 +485,7 @@ class FlatParamsMixin:
                 p.grad = v
 
 
-class Darknet(nn.Module, FlatParamsMixin):
+class Darknet(FlatParamsMixin, nn.Module):
     """YOLOv3 object detection model (reference: CVC-YOLOv3/models.py:222-422)."""
 
     def __init__(self, config_path, xy_loss, wh_loss, no_object_loss, object_loss, vanilla_anchor, precision=None):

@@ -161,6 +161,8 @@ def test_bench_gpus_flag_is_honoured():
     y = line["workloads"]["yolo"]
     assert y["replicas_in_sync"] is True and y["comm"]["ranks"] == 2 and y["comm"]["buckets_per_step"] >= 4
     assert y["comm"]["allreduce_busy_ms"] > 0 and y["comm"]["exposed_comm_ms"] >= 0
+    assert y["comm"]["ms_per_step_reducer_detached"] > 0 and y["comm"]["step_stretch_with_reducer"] > 0      # same ranks, exchange off
+    assert len(out.stdout.splitlines()[-1]) < 3500
 
 
 def test_comm_c_abi_single_rank_rccl():

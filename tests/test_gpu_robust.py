@@ -147,6 +147,58 @@ def test_out_of_grid_target_raises_index_error_on_the_fused_path():
         yl(sample, bad[:2])
 
 
+def test_out_of_grid_target_raises_before_the_parameter_update():
+    """The reference raises inside build_targets BEFORE any update (utils/utils.py:262).  On the plan path the flag copy recorded behind
+    the forward is looked at again at the start of backward (so optimizer.step() is never reached) and when the plan is dropped (the last
+    batch of a run must not lose it)."""
+    from mdcv.optim import FusedAdam
+    z = np.load(os.path.join(G, "mini_darknet.npz"))
+    net = make_mini("fp32").train()
+    opt = FusedAdam(net, lr=1e-3)
+    x, tg = T(z["x"]).cuda(), T(z["targets"]).cuda().clone()
+    opt.zero_grad()
+    net(x, tg)[0].sum().backward()
+    opt.step()
+    before = net.flat_parameters()[0].clone()
+    bad = tg.clone()
+    bad[0, 0] = torch.tensor([0.0, 0.5, 1.0, 0.2, 0.2])             # cy == 1.0
+    opt.zero_grad()
+    loss = net(x, bad)[0].sum()
+    with pytest.raises(IndexError):
+        loss.backward()
+    assert torch.equal(net.flat_parameters()[0], before)            # no step was taken with the bad label
+    net(x, bad)                                                     # ... and a flag pending on a plan that is being dropped still surfaces
+    with pytest.raises(IndexError):
+        net.release_plans()
+
+
+def test_in_place_parameter_edit_after_a_pipelined_step_is_seen_by_the_next_forward():
+    """FusedAdam(pipeline=True) re-packs the conv operands ahead of the next forward; user code that edits a parameter in place between
+    step() and that forward (nn.init.*, clamp_ under no_grad, EMA copy-back) must force a re-pack: compare with the plain optimizer."""
+    from mdcv.optim import FusedAdam
+    z = np.load(os.path.join(G, "mini_darknet.npz"))
+    x, tg = T(z["x"]).cuda(), T(z["targets"]).cuda()
+    losses = []
+    for pipe in (False, True):
+        torch.manual_seed(5)
+        net = make_mini("bf16").train()
+        opt = FusedAdam(net, lr=1e-3, pipeline=pipe)
+        out = []
+        for it in range(3):
+            opt.zero_grad()
+            loss = net(x, tg)[0].sum()
+            loss.backward()
+            opt.step()
+            out.append(float(loss))
+            if it == 1:
+                opt.synchronize()
+                with torch.no_grad():
+                    net.module_list[0][0].weight.mul_(0.5)           # in-place edit of the first conv's weights
+        losses.append(out)
+    assert losses[0] == losses[1], losses
+    assert abs(losses[0][2] - losses[0][1]) > 1e-6                   # (the edit does change the loss)
+
+
 def test_route_with_unaligned_source_is_rejected(tmp_path):
     """A concat whose non-last source is not a multiple of 8 channels wide would put a pad hole in the middle of the consumer's input
     channels: refuse instead of computing with misaligned weights."""
@@ -266,3 +318,26 @@ def test_layer_batched_weight_gradients_in_the_plan(tmp_path, monkeypatch):
     a, b = grads[1].double(), grads[4].double()
     assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max())
     assert float((a @ b) / (a.norm() * b.norm())) > 0.999999
+
+
+def test_resnet_block_refuses_what_it_cannot_differentiate_or_would_break():
+    """Stand-alone ResNet block: eval mode with gradients enabled has no backward on the HIP path (refuse, do not return a graph-less
+    tensor); a block that lives inside a flattened KeypointNet must not re-flatten its parameters out of the parent."""
+    import copy
+    from mdcv.rektnet.keypoint_net import KeypointNet
+    from mdcv.rektnet.resnet import ResNet
+    blk = ResNet(16, 32, precision="fp32").cuda().eval()
+    x = torch.rand(2, 16, 20, 20, device="cuda")
+    with pytest.raises(NotImplementedError):
+        blk(x)
+    with torch.no_grad():
+        assert tuple(blk(x).shape) == (2, 32, 20, 20)
+    net = KeypointNet(7, (80, 80), precision="fp32").cuda().train()
+    img = torch.rand(2, 3, 80, 80, device="cuda")
+    net(img)
+    nplans = len(net._plans)
+    with pytest.raises(RuntimeError, match="flat buffer"):
+        net.res1(torch.rand(2, 16, 80, 80, device="cuda"))
+    assert len(net._plans) == nplans and net._flat_ok()
+    alone = copy.deepcopy(net.res1).train()                      # a copy owns its parameters and runs on its own
+    assert tuple(alone(torch.rand(2, 16, 80, 80, device="cuda")).shape) == (2, 16, 80, 80)
