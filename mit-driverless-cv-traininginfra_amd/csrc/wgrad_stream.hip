@@ -24,6 +24,8 @@
 #include "common.h"
 #include "wgrad_stream.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr unsigned OOB = 0x80000000u;
@@ -124,8 +126,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(xp), 0, x_bytes, 0x00020000);
 
   const int RS = a.RS, rmask = a.RS - 1;                    // ring rows: a power of two
-  unsigned char* const stages = smem + RS * RBX;
-  const unsigned ybase = (unsigned)(RS * RBX), bmask = (unsigned)(RS * RBX - 1);
+  // The ring carries a MIRROR of its first MIR rows behind its end (like the 7x7 kernel): a tap's fragments of one step -- NSUB sub-steps of
+  // 32 rows from one start row -- then never wrap, so a step computes ONE wrapped start address per tap and every read is that address +
+  // an immediate offset (the per-read add / and pairs were 104 VALU instructions per step in front of 72 MFMAs on a one-wave-per-SIMD kernel).
+  constexpr int MIR = NSUB * 32;
+  unsigned char* const stages = smem + (RS + MIR) * RBX;
+  const unsigned ybase = (unsigned)((RS + MIR) * RBX), bmask = (unsigned)(RS * RBX - 1);
   const int p_begin = split * a.pos_per_split;
   const int p_end = min(a.Mq, p_begin + a.pos_per_split);
   const int p_lo = p_begin - a.hpad;                        // stream position held by ring row 0
@@ -149,26 +155,74 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
     ok = ok && x < a.W && y < a.H;
     return ok ? __umul24((unsigned)((img * a.H + y) * a.W + x), ld2) : OOB;
   };
-  // one activation chunk: RPIX rows starting at stream position p (ring row rho, a multiple of RPIX)
+  // one activation chunk: RPIX rows starting at stream position p (ring row rho, a multiple of RPIX); rows below MIR also go to the mirror
   auto issue_x = [&](int p, int rho) {
     const unsigned off = pix_off(p + rrx, lx2, true);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + rho * RBX), 16, (int)(off == OOB ? OOB : off + lane_x), 0, 0, 0);
+    const int vo = (int)(off == OOB ? OOB : off + lane_x);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + rho * RBX), 16, vo, 0, 0, 0);
+    if (rho < MIR) {
+      asm volatile("" ::: "memory");                         // (two LDS-DMA calls that differ only in the destination must not be folded)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + (RS + rho) * RBX), 16, vo, 0, 0, 0);
+    }
   };
-  // step t: the BP new activation rows (p_begin + t*BP + hpad ..) and the BP dY rows of the step
+  // The steps are issued in order t = 0, 1, 2, ..., each exactly once, and every DMA lane's stream position advances by BP per step: the
+  // lane keeps (x, y, image) of its row per DMA instruction and steps them forward (add, compare, conditional subtract) instead of two
+  // float divisions per DMA per step.  That address code was ~180 VALU instructions per step IN FRONT of the step's MFMAs -- on the
+  // one-wave-per-SIMD forms nothing else issues meanwhile, which is why "fill" and "compute" added up instead of overlapping.
+  // Needs Hq > BP / Wq + 1 (one row wrap per step at most; the host only takes this kernel then).
+  const int adv_q = BP / a.Wq, adv_r = BP - adv_q * a.Wq, Hq = a.Sq / a.Wq;
+  int qx[XI], qy[XI], qi[XI], yx[DYI], yy[DYI], yi[DYI], yrem[DYI];
+  auto seed = [&](int p, int& x, int& y, int& img) {        // p >= 0
+    int rem;
+    fast_divmod(p < (1 << 24) - 1 ? p : (1 << 24) - 1, a.Sq, inv_sq, img, rem);
+    fast_divmod(rem, a.Wq, inv_wq, y, x);
+  };
+  const int nimg = a.Mq / a.Sq;
+#pragma unroll
+  for (int j = 0; j < XI; ++j) seed(p_begin + a.hpad + (wave + NW * j) * RPIX + rrx, qx[j], qy[j], qi[j]);
+#pragma unroll
+  for (int j = 0; j < DYI; ++j) {
+    const int p = p_begin + (wave + NW * j) * RPIY + rry;
+    seed(p, yx[j], yy[j], yi[j]);
+    yrem[j] = p_end - p;                                     // > 0 while the row belongs to this split
+  }
+  auto advance = [&](int& x, int& y, int& img) {
+    x += adv_r;
+    const int c1 = x >= a.Wq;
+    x -= c1 ? a.Wq : 0;
+    y += adv_q + c1;
+    const int c2 = y >= Hq;
+    y -= c2 ? Hq : 0;
+    img += c2;
+  };
+  auto row_off = [&](int x, int y, int img, unsigned ld2, bool ok) -> unsigned {
+    ok = ok && x < a.W && y < a.H && img < nimg;
+    const unsigned pix = __umul24(__umul24((unsigned)img, (unsigned)a.H) + (unsigned)y, (unsigned)a.W) + (unsigned)x;
+    return ok ? __umul24(pix, ld2) : OOB;
+  };
+  // step t (called for t = 0, 1, 2, ... in order): the BP new activation rows (p_begin + t*BP + hpad ..) and the BP dY rows of the step
   auto issue = [&](int t, int rho_new) {
-    const int p0 = p_begin + t * BP;
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
       const int chunk = wave + NW * j;
-      issue_x(p0 + a.hpad + chunk * RPIX, (rho_new + chunk * RPIX) & rmask);
+      const int rho = (rho_new + chunk * RPIX) & rmask;
+      const unsigned off = row_off(qx[j], qy[j], qi[j], lx2, true);
+      const int vo = (int)(off == OOB ? OOB : off + lane_x);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + rho * RBX), 16, vo, 0, 0, 0);
+      if (rho < MIR) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + (RS + rho) * RBX), 16, vo, 0, 0, 0);
+      }
+      advance(qx[j], qy[j], qi[j]);
     }
     unsigned char* sY = stages + (t % (D + 1)) * YSTAGE;
 #pragma unroll
     for (int j = 0; j < DYI; ++j) {
       const int chunk = wave + NW * j;
-      const int p = p0 + chunk * RPIY + rry;
-      const unsigned off = pix_off(p, ldy2, p < p_end);
+      const unsigned off = row_off(yx[j], yy[j], yi[j], ldy2, yrem[j] > 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t*)(sY + chunk * 1024), 16, (int)(off == OOB ? OOB : off + lane_y), 0, 0, 0);
+      advance(yx[j], yy[j], yi[j]);
+      yrem[j] -= BP;
     }
   };
 
@@ -192,18 +246,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
     const int g = (((dtap[tap] + prow) & 7) / RX) & (NCI - 1);
     laneX[tap] = (unsigned)((dtap[tap] + prow) * RBX + (xcol ^ (g << 5)));
   }
-  auto fragY = [&](unsigned sbase, int i) -> bf16x8_t {        // sbase: byte offset of the sub-step's first row in its stage
-    const unsigned ad = sbase + laneY[i];
-    const s16x4_t lo = lds_tr16<0>(ad);
-    const s16x4_t hi = lds_tr16<16 * RBY>(ad);
+  // per step: xa[tap] = wrapped byte address of this lane's row of the step's first sub-step at tap `tap` (rows up to MIR - 1 further on are
+  // contiguous thanks to the mirror); ya[i] = the same in the step's dY stage (linear, no wrap)
+  unsigned xa[9], ya[A];
+  auto step_addrs = [&](int t, int rho0) {
+    const unsigned ystage = (unsigned)((t % (D + 1)) * YSTAGE + pg * NSUB * 32 * RBY);
+    const unsigned xs = (unsigned)((rho0 + pg * NSUB * 32) * RBX);
+#pragma unroll
+    for (int i = 0; i < A; ++i) ya[i] = ystage + laneY[i];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) xa[tap] = (xs + laneX[tap]) & bmask;
+  };
+  auto fragY = [&](auto N, int i) -> bf16x8_t {                // N: sub-step of the step (integral_constant)
+    constexpr int o = decltype(N)::value * 32 * RBY;
+    const s16x4_t lo = lds_tr16<o>(ya[i]);
+    const s16x4_t hi = lds_tr16<o + 16 * RBY>(ya[i]);
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
-  auto fragX = [&](unsigned sbase, int tap) -> bf16x8_t {      // sbase: byte offset of the sub-step's first ring row (< ring bytes)
-    const unsigned a1 = (sbase + laneX[tap]) & bmask;          // the AND wraps the row, the column bits pass through
-    const unsigned a2 = (a1 + 16 * RBX) & bmask;               // 16 rows on: same row & 7, same swizzle
-    const s16x4_t lo = lds_tr16<0>(a1);
-    const s16x4_t hi = lds_tr16<0>(a2);
+  auto fragX = [&](auto N, int tap) -> bf16x8_t {
+    constexpr int o = decltype(N)::value * 32 * RBX;
+    const s16x4_t lo = lds_tr16<o>(xa[tap]);
+    const s16x4_t hi = lds_tr16<o + 16 * RBX>(xa[tap]);      // 16 rows on: same row & 7, same swizzle
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
@@ -232,14 +296,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
 #else
   constexpr bool kMfma = true;
 #endif
-  auto reads = [&](int t, int rho0, int s) {
-    const unsigned ystage = (unsigned)((t % (D + 1)) * YSTAGE);
-    const int ks = pg * NSUB + s;
-    const unsigned xs = (unsigned)((rho0 + ks * 32) * RBX);
+  auto reads = [&](auto N) {                                   // sub-step N of the step whose addresses step_addrs() prepared
 #pragma unroll
-    for (int i = 0; i < A; ++i) fa[i] = fragY(ystage + (unsigned)(ks * 32 * RBY), i);
+    for (int i = 0; i < A; ++i) fa[i] = fragY(N, i);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) fb[tap] = fragX(xs, tap);
+    for (int tap = 0; tap < 9; ++tap) fb[tap] = fragX(N, tap);
   };
   auto mfmas = [&]() {
     // reads return in issue order (fa..., fb[0], fb[1], ...): tap k starts as soon as its fragment is in, the rest keeps streaming
@@ -279,21 +340,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
 #ifndef MDCV_WST_NODMA
     if (more) issue(t_new, rho_new);
 #endif
+    step_addrs(t, rho0);
     if constexpr (kPipe) {
-      const unsigned ystage = (unsigned)((t % (D + 1)) * YSTAGE);
-      const unsigned xs0 = (unsigned)(rho0 * RBX);
+      using N0 = std::integral_constant<int, 0>;
+      using N1 = std::integral_constant<int, 1>;
       if constexpr (A == 4) {
 #include "wgrad_stream_pipe.inc"
       } else {
 #include "wgrad_stream_pipe8.inc"
       }
     } else {
-#pragma unroll
-      for (int s = 0; s < NSUB; ++s) {
-        if (late && s > 0) mfmas();
-        reads(t, rho0, s);
-        if (!late) mfmas();
-      }
+      static_assert(NSUB <= 4, "sub-steps are unrolled by hand below");
+      reads(std::integral_constant<int, 0>{});
+      if (!late) mfmas();
+      if constexpr (NSUB > 1) { if (late) mfmas(); reads(std::integral_constant<int, 1>{}); if (!late) mfmas(); }
+      if constexpr (NSUB > 2) { if (late) mfmas(); reads(std::integral_constant<int, 2>{}); if (!late) mfmas(); }
+      if constexpr (NSUB > 3) { if (late) mfmas(); reads(std::integral_constant<int, 3>{}); if (!late) mfmas(); }
     }
   };
 
@@ -541,7 +603,7 @@ inline int stream_ring_rows(const StreamCfg& c, int W, int dil) {       // >= (D
 }
 inline int stream_lds(const StreamCfg& c, int W, int dil) {
   const int rs = stream_ring_rows(c, W, dil);
-  const int ring = (c.d + 1) * c.bp * c.nco * 32 + rs * c.nci * 32;
+  const int ring = (c.d + 1) * c.bp * c.nco * 32 + (rs + c.bp / c.pg) * c.nci * 32;     // dY stages + ring + its mirror (one wave's sub-steps of a step)
   const int stage_out = c.nco * 16 * (c.tgrp * c.nci * 16 + 4) * 4;
   return ring > stage_out ? ring : stage_out;
 }
@@ -577,6 +639,7 @@ bool mdcv_wgrad_stream_eligible(int dtype, int B, int H, int W, int Cin, int Cou
   if (H < 4 || W < 4) return false;
   const long long Mq = (long long)B * (H + dil) * (W + dil);
   if (!stream_cfg_geom(Cin, Cout, W, dil, c, Mq)) return false;
+  if (c.bp / (W + dil) + 1 >= H + dil) return false;         // the DMA lanes step (x, y, image) forward by BP positions per step: one image wrap at most
   if (Mq + 4096 >= (1LL << 24) || (long long)B * H * W >= (1LL << 24)) return false;          // 24-bit multiplies / float divmod
   if ((long long)B * H * W * dy_ldc * 2 >= (1LL << 31) || (long long)B * H * W * x_ldc * 2 >= (1LL << 31)) return false;
   if (dy_ldc >= (1 << 23) || x_ldc >= (1 << 23)) return false;
@@ -626,6 +689,7 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   const bool batch = table || nlayers != 1;                  // batches keep the 8-wave form (mdcv_wgrad_stream_batch_splits)
   if (!stream_cfg_geom(Cin, Cout, W, dil, c, batch ? 0 : (long long)B * (H + dil) * (W + dil))) return MDCV_EARG;
   if (batch && !c.tiled) return MDCV_EARG;
+  if (c.bp / (W + dil) + 1 >= H + dil) return MDCV_EARG;
   WgradStreamArgs a;
   a.dy = dy; a.x = x; a.ws = ws; a.dy_ldc = dy_ldc; a.x_ldc = x_ldc;
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Ktot = 9 * Cin; a.dil = dil;
