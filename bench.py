@@ -136,7 +136,7 @@ def call_work(name, args):
 
 def _is_main_kernel(sym):
     """the kernel of a multi-kernel call that does the call's algorithmic work (not a slab / partial-row reduction or finalize)"""
-    return not any(t in sym for t in ("reduce", "colfinal", "finalize"))
+    return not any(t in sym for t in ("wgrad_reduce", "colfinal", "finalize", "rows_fold", "partial_reduce"))
 
 
 def short_symbol(sym):
