@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3        # MI355X fp32 MFMA (v_mfma_f32_16x16x4_f32: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz), the parity-mode kernels
-OPT_PIPELINE = os.environ.get("MDCV_OPT_PIPELINE", "0") == "1"   # FusedAdam(pipeline=True), see mdcv/optim.py: bit-identical, measured neutral -> off
+OPT_PIPELINE = False           # FusedAdam(pipeline=True), see mdcv/optim.py: bit-identical, measured neutral -> off
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 YOLO_TRAIN_GFLOP_PER_IMG = 197.59   # SURVEY.md §8d (conv only, fwd+dgrad+wgrad, classes=80, 416^2; classes=1: 195.87)
 REKT_TRAIN_GFLOP_PER_IMG = 11.872   # head conv counted once
@@ -483,8 +483,6 @@ def build_line(a, world, primary, result, extra, cpu_baseline):
     env = live_env_overrides()
     if env:
         line["env_overrides"] = env
-    if os.environ.get("MDCV_LIB"):
-        line["lib_path"] = _lib.LIB_PATH
     return line
 
 
@@ -558,11 +556,6 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     os.environ["MDCV_GRAPH"] = str(a.graph)
-    if os.environ.get("MDCV_MAIN_PRIO", "0") == "1":            # run the step on a high-priority stream (the wgrad side stream stays normal)
-        hp = torch.cuda.Stream(device=device, priority=-1)
-        hp.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(hp)
-
     from mdcv.yolo.models import Darknet
     from mdcv.rektnet.keypoint_net import KeypointNet
     from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss

@@ -68,18 +68,6 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
                       float* dw_oihw, int accumulate, int B, int Hin, int Win, int Cin, int Cin_real,
                       int Hout, int Wout, int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream);
 
-/* Weight gradients of `nlayers` convolutions of IDENTICAL geometry (the repeated residual blocks of a Darknet stage) in one launch pair.
- * Alone, a layer's dW needs ~256 / tiles pixel splits to fill the chip: short runs per block and splits x |dW| bytes of fp32 slabs.
- * A batch of L layers runs L times longer per block and writes L times fewer slabs per layer (YOLOv3 52x52 128->256 at batch 32:
- * 79 us alone, 55 us per layer in a batch of four).  table: nlayers device-resident 24-byte records { const void* dy; const void* x;
- * float* dw_oihw; }; ws: nlayers * splits * Cout * KH*KW*Cin floats.  _splits() = pixel splits per layer for such a batch, 0 when this
- * geometry has no batched kernel (3x3 / stride 1 / "same", bf16, Cin % 64 == 0, Cout % 128 == 0 do). */
-int mdcv_conv2d_wgrad_batched_splits(int dtype, int nlayers, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW,
-                                     int stride, int pad, int dil, int dy_ldc, int x_ldc);
-int mdcv_conv2d_wgrad_batched(int dtype, const void* table, int nlayers, int dy_ldc, int x_ldc, float* ws, int splits, int accumulate,
-                              int B, int Hin, int Win, int Cin, int Cin_real, int Hout, int Wout, int Cout, int Cout_real,
-                              int KH, int KW, int stride, int pad, int dil, void* stream);
-
 /* OIHW fp32 parameters -> GEMM operand layouts (w_dgrad may be NULL) */
 int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,
                       int Cout_pad, int Cin_pad, void* stream);

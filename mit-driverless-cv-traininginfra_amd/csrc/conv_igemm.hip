@@ -21,8 +21,11 @@
 #include "wgrad_shift.h"
 #include "wgrad_stream.h"
 
-namespace {
-
+// The file is compiled four times (Makefile: -DMDCV_CONV_PART=0..3) so that its template instantiations build in parallel:
+//   0  host entry points, weight-gradient and pack kernels, tuning globals      1  bf16 forward      2  bf16 data gradients      3  fp32 (parity mode)
+#ifndef MDCV_CONV_PART
+#define MDCV_CONV_PART 0
+#endif
 
 struct ConvArgs {
   const void* in; const void* w; void* out; const float* bias; const void* addsrc; float* stats;
@@ -34,6 +37,44 @@ struct ConvArgs {
   BnFuseArgs fuse;                            // BatchNorm-backward sums folded into the store loop of a data gradient (fuse.y == NULL: off)
   EpiArgs epi;                                // inference epilogue act(acc * oscale + bias) (oscale == NULL and act == 0: off)
 };
+
+#if MDCV_CONV_PART == 0
+int g_conv_no_ut = 0;    // tuning/A-B: 1 disables the uniform-tap address path
+int g_conv_tall_narrow = 256; // 256-row tiles for Nout <= 64 from this many Ki output positions (set_variant 2000 + M_min/1024; 2000 = off): half as
+                              // many workgroup prologues / epilogues on the 80^2 x 256 and 208^2..416^2 x 32 tensors.  Same-box A/B: RektNet +0.65 %, YOLOv3 +0.2 %
+int g_conv_deep_narrow = 1;  // 128x64 tiles of the 33..64-channel layers take the 3-stage ring from this many K steps (set_variant 30 + nk_min;
+                             // 30 = never).  Same-box A/B: RektNet 29.93k -> 30.17k img/s, YOLOv3 +0.3 %
+int g_conv_deep_small = 8;   // 128x128 and 128x64 tiles take the 3-stage DMA ring from this many K steps (set_variant 60 + nk_min; 60 = never).
+                             // Same-box A/B of the YOLOv3 step: never 2031, from 4 steps 2045, from 8 2050, from 16 2045, from 32 2034 img/s
+int g_conv_fuse_narrow = 1;  // (set_variant 92 = off) 1x1 data gradients with fused BatchNorm sums take 128x64 tiles on the 3-stage ring: their store loop (loads of
+                             // the shortcut gradient and y, sums, partial-row flush) is serial per workgroup, and three or four narrow workgroups per CU overlap it
+                             // better than one or two wide ones.  Alone (scripts/pw_ab_dgrad.py): 52^2 60 -> 47 us, 104^2 103 -> 78, 26^2 35 -> 32, 13^2 21.5 -> 20
+int g_conv_variant = -1;   // -1: heuristic ; >= 0: forced tile configuration for wide layers (tuning / A-B benchmarking)
+int g_conv_tall_s2 = 1;      // (set_variant 18 = off; +0.3 % on the YOLOv3 step) the tall narrow tiles for the parity-class launches too
+int g_conv_deep_s2 = 1;      // (set_variant 20 = off; +0.6 % on the YOLOv3 step, same-box A/B) 3-stage ring for the parity-class launches of the stride-2 data gradients
+int g_conv_s2_allcls = 1;    // (set_variant 16 = off) one launch for the four parity classes of a stride-2 data gradient (conv_glds_kernel ALLCLS)
+#else
+extern int g_conv_no_ut;
+extern int g_conv_tall_narrow;
+extern int g_conv_deep_narrow;
+extern int g_conv_deep_small;
+extern int g_conv_fuse_narrow;
+extern int g_conv_variant;
+extern int g_conv_tall_s2;
+extern int g_conv_deep_s2;
+extern int g_conv_s2_allcls;
+#endif
+// the per-part dispatch entry points (each defined by exactly one part)
+int mdcv_cd_bf16_fwd(const ConvArgs& a, hipStream_t st, int B);
+int mdcv_cd_bf16_dgrad(const ConvArgs& a, hipStream_t st, int B);
+int mdcv_cd_bf16_s2(const ConvArgs& a, hipStream_t st, int B);
+int mdcv_cd_bf16_s2_all(const ConvArgs& a, hipStream_t st, int B);
+int mdcv_cd_f32_fwd(const ConvArgs& a, hipStream_t st, int B);
+int mdcv_cd_f32_dgrad(const ConvArgs& a, hipStream_t st, int B);
+int mdcv_cd_f32_s2(const ConvArgs& a, hipStream_t st, int B);
+
+namespace {
+
 
 // One K tile of MFMAs for a wave: FM x FN fragments of 16x16, KT k-steps of 64 bytes per LDS row (row pitch RB bytes).
 template <typename T> struct Frag;
@@ -360,7 +401,6 @@ template <> struct FragSwz<float> {
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
-int g_conv_no_ut = 0;    // tuning/A-B: 1 disables the uniform-tap address path
 
 // ALLCLS (MODE 2 only): the workgroup computes ALL FOUR output-parity classes of its tile of dY positions, one after the other (classes
 // have 1, 2, 2 and 4 taps: every workgroup gets the same 9 taps of work, and the dY rows a tile reads come from HBM once instead of
@@ -829,21 +869,6 @@ int launch_conv_glds(const ConvArgs& a, hipStream_t st, int B) {
   return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, false>(a, st, B);
 }
 
-int g_conv_tall_mask = 7;     // (set_variant 24 + mask) 1: Nout <= 16, 2: <= 32, 4: <= 64
-int g_conv_tall_narrow = 256; // 256-row tiles for Nout <= 64 from this many Ki output positions (set_variant 2000 + M_min/1024; 2000 = off): half as
-                              // many workgroup prologues / epilogues on the 80^2 x 256 and 208^2..416^2 x 32 tensors.  Same-box A/B: RektNet +0.65 %, YOLOv3 +0.2 %
-int g_conv_deep_narrow32 = 0; // tuning (set_variant 22 / 23): also the 128x32 and 128x16 tiles (surplus waves DMA zeros into a sink)
-int g_conv_deep_narrow = 1;  // 128x64 tiles of the 33..64-channel layers take the 3-stage ring from this many K steps (set_variant 30 + nk_min;
-                             // 30 = never).  Same-box A/B: RektNet 29.93k -> 30.17k img/s, YOLOv3 +0.3 %
-int g_conv_deep4 = 0;        // tuning (set_variant 9000 + nk_min; 9000 = off): 4-stage ring for grids of at most 512 tiles of 128x128
-int g_conv_deep_small = 8;   // 128x128 and 128x64 tiles take the 3-stage DMA ring from this many K steps (set_variant 60 + nk_min; 60 = never).
-                             // Same-box A/B of the YOLOv3 step: never 2031, from 4 steps 2045, from 8 2050, from 16 2045, from 32 2034 img/s
-int g_conv_fuse_small = 0;   // tuning (set_variant 95 / 94): fused-sum data gradients with a short K loop take 128x128 two-stage tiles (4 workgroups per CU)
-int g_conv_fuse_narrow = 1;  // (set_variant 92 = off) 1x1 data gradients with fused BatchNorm sums take 128x64 tiles on the 3-stage ring: their store loop (loads of
-                             // the shortcut gradient and y, sums, partial-row flush) is serial per workgroup, and three or four narrow workgroups per CU overlap it
-                             // better than one or two wide ones.  Alone (scripts/pw_ab_dgrad.py): 52^2 60 -> 47 us, 104^2 103 -> 78, 26^2 35 -> 32, 13^2 21.5 -> 20
-int g_conv_midgrid = 0;    // tuning (set_variant 97 / 96): 256x128 tiles already from 300 tiles of 128x128 (1x1 layers at 52x52)
-int g_conv_variant = -1;   // -1: heuristic ; >= 0: forced tile configuration for wide layers (tuning / A-B benchmarking)
 
 template <typename T, int MODE>
 int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
@@ -856,25 +881,20 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
     if (v < 0) {   // measured on MI355X (scripts/conv_ab.py): tall tiles once the grid is >= 4 waves of CUs, half-width tiles
       const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);   // when 128x128 would leave CUs idle
       const int nk = a.Ktot / (4 * ET<T>::VEC);      // long K loops profit from the 3-stage DMA ring (scripts/conv_ab.py)
-      v = t128 >= (g_conv_midgrid ? g_conv_midgrid : 1024) ? 11 : (nk >= 100 ? 9 : (t128 >= 300 ? 6 : 7));
-      if (g_conv_fuse_small && MODE != 0 && a.fuse.y && nk <= 8 && v == 11) v = 6;
+      v = t128 >= 1024 ? 11 : (nk >= 100 ? 9 : (t128 >= 300 ? 6 : 7));
       if (g_conv_fuse_narrow && MODE == 1 && a.fuse.y && a.KH == 1 && a.KW == 1) v = 10;
       if (g_conv_deep_small && nk >= g_conv_deep_small && (v == 6 || v == 7)) v += 3;   // 3-stage ring for the mid / sparse grids too
-      if (g_conv_deep4 && nk >= g_conv_deep4 && t128 <= 512 && (v == 9 || v == 10)) v = v == 9 ? 12 : 14;   // sparse grids: 4 stages
     }
-    if (!BF && small) v = v == 8 ? 6 : (v == 11 ? 9 : (v == 13 ? 12 : v));   // the 8-wave 256-row tiles exist in bf16 only: fp32 takes the 128x128 LDS-DMA tiles
+    if (!BF && small) v = v == 8 ? 6 : (v == 11 ? 9 : v);   // the 8-wave 256-row tiles exist in bf16 only: fp32 takes the 128x128 LDS-DMA tiles
                                                                            // (the register-staged fallback has no inference epilogue and is slower)
-    if (v >= 6 && !small) v = (v == 8 || v == 11 || v == 13) ? 2 : ((v == 7 || v == 10) ? 4 : 0);
+    if (v >= 6 && !small) v = (v == 8 || v == 11) ? 2 : ((v == 7 || v == 10) ? 4 : 0);
     if (v == 6) return launch_conv_glds<T, MODE, 128, 128, 2, 2>(a, st, B);
     if (v == 7) return launch_conv_glds<T, MODE, 128, 64, 2, 2>(a, st, B);
     if (v == 9) return launch_conv_glds<T, MODE, 128, 128, 2, 2, 3>(a, st, B);
     if (v == 10) return launch_conv_glds<T, MODE, 128, 64, 2, 2, 3>(a, st, B);
-    if (v == 12) return launch_conv_glds<T, MODE, 128, 128, 2, 2, 4>(a, st, B);
-    if (v == 14) return launch_conv_glds<T, MODE, 128, 64, 2, 2, 4>(a, st, B);
     if (BF) {   // 8-wave / deep-K tiles only exist in the production dtype
       if (v == 8) return launch_conv_glds<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2>(a, st, B);
       if (v == 11) return launch_conv_glds<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, 3>(a, st, B);
-      if (v == 13) return launch_conv_glds<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, 4>(a, st, B);
       if (v == 1) return launch_conv<T, MODE, 128, 128, 2, 2, (BF ? 2 : 1)>(a, st);
       if (v == 2) return launch_conv<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, 1>(a, st);
       if (v == 3) return launch_conv<T, MODE, (BF ? 256 : 128), 128, (BF ? 4 : 2), 2, (BF ? 2 : 1)>(a, st);
@@ -888,27 +908,20 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
   const bool dma = small && g_conv_variant != 0;      // variant 0 forces the register-staged kernels everywhere (A/B)
   if constexpr (BF) {
     if (dma && g_conv_tall_narrow && a.M >= g_conv_tall_narrow * 1024) {   // tall tiles for the narrow layers of large images
-      if (a.Nout > 32) { if (g_conv_tall_mask & 4) return launch_conv_glds<T, MODE, 256, 64, 4, 2, 3>(a, st, B); }
-      else if (a.Nout > 16) { if (g_conv_tall_mask & 2) return launch_conv_glds<T, MODE, 256, 32, 4, 1>(a, st, B); }
-      else if (g_conv_tall_mask & 1) return launch_conv_glds<T, MODE, 256, 16, 4, 1>(a, st, B);
+      if (a.Nout > 32) return launch_conv_glds<T, MODE, 256, 64, 4, 2, 3>(a, st, B);
+      if (a.Nout > 16) return launch_conv_glds<T, MODE, 256, 32, 4, 1>(a, st, B);
+      return launch_conv_glds<T, MODE, 256, 16, 4, 1>(a, st, B);
     }
   }
   if (dma && g_conv_deep_narrow && a.Ktot / (4 * ET<T>::VEC) >= g_conv_deep_narrow) {
     if (a.Nout > 32) return launch_conv_glds<T, MODE, 128, 64, 2, 2, 3>(a, st, B);
-    if (g_conv_deep_narrow32) {
-      if (a.Nout > 16) return launch_conv_glds<T, MODE, 128, 32, 4, 1, 3>(a, st, B);
-      return launch_conv_glds<T, MODE, 128, 16, 4, 1, 3>(a, st, B);
-    }
   }
   if (a.Nout > 32) return dma ? launch_conv_glds<T, MODE, 128, 64, 2, 2>(a, st, B) : launch_conv<T, MODE, 128, 64, 2, 2, (BF ? 2 : 1)>(a, st);
   if (a.Nout > 16) return dma ? launch_conv_glds<T, MODE, 128, 32, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 32, 4, 1, (BF ? 2 : 1)>(a, st);
   return dma ? launch_conv_glds<T, MODE, 128, 16, 4, 1>(a, st, B) : launch_conv<T, MODE, 128, 16, 4, 1, (BF ? 2 : 1)>(a, st);
 }
 
-int g_conv_tall_s2 = 1;      // (set_variant 18 = off; +0.3 % on the YOLOv3 step) the tall narrow tiles for the parity-class launches too
-int g_conv_deep_s2 = 1;      // (set_variant 20 = off; +0.6 % on the YOLOv3 step, same-box A/B) 3-stage ring for the parity-class launches of the stride-2 data gradients
 
-int g_conv_s2_allcls = 1;    // (set_variant 16 = off) one launch for the four parity classes of a stride-2 data gradient (conv_glds_kernel ALLCLS)
 
 // all four classes in one launch: same tile choice as the per-class dispatch below (a.M = positions of ONE class)
 static int dispatch_dgrad_s2_all(const ConvArgs& a, hipStream_t st, int B) {
@@ -954,6 +967,7 @@ int dispatch_dgrad_s2(const ConvArgs& a, hipStream_t st, int B) {
   return launch_conv_glds<T, 2, 128, 16, 4, 1>(a, st, B);
 }
 
+#if MDCV_CONV_PART == 0
 // ------------------------------------------------------------------------------------------------
 // weight gradient: dW[co, k] = sum_m dY[m, co] * Xcol[m, k]; pixels (the reduction) are split across the grid and each
 // split writes an fp32 partial slab ws[split][Cout][Ktot]; mdcv_wgrad_reduce sums the slabs into the OIHW fp32 grad.
@@ -1358,16 +1372,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // input channel c (KK independent loads per split, several splits unrolled), so a block has ~4*KK*unroll loads in flight per
 // thread group instead of four dependent chains; the four partial sums meet in LDS.  (The chained version was latency-bound:
 // 25 us per layer, 1.9 ms per YOLOv3 step.)
-// `table` (layer batch, mdcv_conv2d_wgrad_batched): blockIdx.z is the layer; its slabs follow each other in ws, its gradient is table[z].dw.
 template <int KK>
 __global__ __launch_bounds__(256) void wgrad_reduce_kk_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int Cout_pad,
-                                                              int Cin_real, int Cin_pad, int Ktot, int accumulate, const WgradBatchRec* __restrict__ table) {
+                                                              int Cin_real, int Cin_pad, int Ktot, int accumulate) {
   __shared__ float tile[4][KK][65];
   const int co = blockIdx.x, ci0 = blockIdx.y * 64;
   const int nci = min(64, Cin_real - ci0);
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
   const size_t slab = (size_t)Cout_pad * Ktot;
-  if (table) { ws += (size_t)blockIdx.z * splits * slab; dw = table[blockIdx.z].dw; }
   float acc[KK];
 #pragma unroll
   for (int t = 0; t < KK; ++t) acc[t] = 0.f;
@@ -1433,23 +1445,15 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_flat_kernel(const float* __
 
 // sums the fp32 slabs ws[splits][Cout_pad][KK*Cin_pad] into the OIHW gradient
 static int launch_wgrad_reduce(const float* ws, float* dw_oihw, int splits, int Cout_pad, int Cout_real, int Cin_pad, int Cin_real, int KK,
-                               int accumulate, hipStream_t st, const WgradBatchRec* table = nullptr, int nlayers = 1) {
+                               int accumulate, hipStream_t st) {
   const int Ktot = KK * Cin_pad;
-  if (table) {                                       // layer batch: only the wide-layer kernel carries the table
-    if (KK != 9 && KK != 1) return MDCV_EARG;
-    const dim3 rgrid((unsigned)Cout_real, (unsigned)cdiv(Cin_real, 64), (unsigned)nlayers);
-    if (KK == 9) MDCV_LAUNCH(wgrad_reduce_kk_kernel<9>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate, table);
-    else MDCV_LAUNCH(wgrad_reduce_kk_kernel<1>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate, table);
-    MDCV_CHECK_LAUNCH();
-    return MDCV_OK;
-  }
   if (Cout_real * cdiv(Cin_real, 64) < 128) {
     MDCV_LAUNCH(wgrad_reduce_flat_kernel, dim3((unsigned)cdiv(Ktot, 64), (unsigned)Cout_real), dim3(1024), 0, st, ws, dw_oihw, splits,
                        Cout_pad, Cin_real, Cin_pad, KK, Ktot, accumulate);
   } else {
     const dim3 rgrid((unsigned)Cout_real, (unsigned)cdiv(Cin_real, 64));
-    if (KK == 9) MDCV_LAUNCH(wgrad_reduce_kk_kernel<9>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate, (const WgradBatchRec*)nullptr);
-    else if (KK == 1) MDCV_LAUNCH(wgrad_reduce_kk_kernel<1>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate, (const WgradBatchRec*)nullptr);
+    if (KK == 9) MDCV_LAUNCH(wgrad_reduce_kk_kernel<9>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate);
+    else if (KK == 1) MDCV_LAUNCH(wgrad_reduce_kk_kernel<1>, rgrid, dim3(256), 0, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, Ktot, accumulate);
     else MDCV_LAUNCH(wgrad_reduce_kernel, rgrid, dim3(256), KK * 65 * 4, st, ws, dw_oihw, splits, Cout_pad, Cin_real, Cin_pad, KK, Ktot, accumulate);
   }
   MDCV_CHECK_LAUNCH();
@@ -1652,7 +1656,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
 }
 
 int g_wgrad_slots = 512;   // target block count of the generic weight-gradient kernel (tuning hook 20000 + n)
-int g_wgrad_variant = 0;    // 0: 64-pixel steps x 2 stages ; 1: 32 x 3 ; 2: 32 x 4 ; 3: 64 x 3 (one block per CU)
+int g_wgrad_variant = 0;    // 0: default dispatch ; 4: generic address path ; 5: wide tile everywhere ; 8 / 9 / 10 / 11: kernel-family choices (use_wgrad_*)
 
 template <int BP, int STAGES, bool SAME>
 static int launch_wgrad_dma_t(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
@@ -1685,17 +1689,10 @@ static int launch_wgrad_narrow_t(const WgradArgs& a, unsigned grid, hipStream_t 
 }
 static int launch_wgrad_dma(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
   const bool same = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout;
-  if (a.Cout <= 32 && g_wgrad_variant != 5) {
-    if (g_wgrad_variant == 6) return same ? launch_wgrad_narrow_t<true, 2>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 2>(a, grid, st, dyb, xb);
-    if (g_wgrad_variant == 7) return same ? launch_wgrad_narrow_t<true, 5>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 5>(a, grid, st, dyb, xb);
+  if (a.Cout <= 32 && g_wgrad_variant != 5)                       // (variant 5: the wide tile for narrow layers too, A/B)
     return same ? launch_wgrad_narrow_t<true, 4>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 4>(a, grid, st, dyb, xb);
-  }
-  switch (g_wgrad_variant) {
-    case 1: return launch_wgrad_dma_t<32, 3, false>(a, grid, st, dyb, xb);
-    case 3: return launch_wgrad_dma_t<64, 3, false>(a, grid, st, dyb, xb);
-    case 4: return launch_wgrad_dma_t<64, 2, false>(a, grid, st, dyb, xb);        // generic address path (A/B)
-    default: return same ? launch_wgrad_dma_t<64, 2, true>(a, grid, st, dyb, xb) : launch_wgrad_dma_t<64, 2, false>(a, grid, st, dyb, xb);
-  }
+  if (g_wgrad_variant == 4) return launch_wgrad_dma_t<64, 2, false>(a, grid, st, dyb, xb);        // generic address path (A/B)
+  return same ? launch_wgrad_dma_t<64, 2, true>(a, grid, st, dyb, xb) : launch_wgrad_dma_t<64, 2, false>(a, grid, st, dyb, xb);
 }
 
 // all layers in one launch: blockIdx.y selects the layer descriptor, blockIdx.x grid-strides inside it
@@ -1777,7 +1774,20 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
   }
 }
 
+#endif   // MDCV_CONV_PART == 0 (weight gradients, pack)
 }  // namespace
+
+#if MDCV_CONV_PART == 1
+int mdcv_cd_bf16_fwd(const ConvArgs& a, hipStream_t st, int B) { return dispatch_conv<bf16_t, 0>(a, st, B); }
+#elif MDCV_CONV_PART == 2
+int mdcv_cd_bf16_dgrad(const ConvArgs& a, hipStream_t st, int B) { return dispatch_conv<bf16_t, 1>(a, st, B); }
+int mdcv_cd_bf16_s2(const ConvArgs& a, hipStream_t st, int B) { return dispatch_dgrad_s2<bf16_t>(a, st, B); }
+int mdcv_cd_bf16_s2_all(const ConvArgs& a, hipStream_t st, int B) { return dispatch_dgrad_s2_all(a, st, B); }
+#elif MDCV_CONV_PART == 3
+int mdcv_cd_f32_fwd(const ConvArgs& a, hipStream_t st, int B) { return dispatch_conv<float, 0>(a, st, B); }
+int mdcv_cd_f32_dgrad(const ConvArgs& a, hipStream_t st, int B) { return dispatch_conv<float, 1>(a, st, B); }
+int mdcv_cd_f32_s2(const ConvArgs& a, hipStream_t st, int B) { return dispatch_dgrad_s2<float>(a, st, B); }
+#else
 
 // =================================================================================================
 // C ABI
@@ -1814,7 +1824,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
       c.Hs = Hout / 2; c.Ws = Wout / 2;
       c.M = B * c.Hs * c.Ws;
       c.fuse.row_base = 0;
-      const int rc = dispatch_dgrad_s2_all(c, st, B);
+      const int rc = mdcv_cd_bf16_s2_all(c, st, B);
       if (rc != MDCV_EARG) return rc;              // (geometries without an all-class instantiation fall through to the four launches)
     }
     int row_base = 0;
@@ -1831,8 +1841,8 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
       row_base += cdiv(c.M, 128);
       int rc;
       if (c.nkh <= 0 || c.nkw <= 0) { c.nkh = c.nkh > 0 ? c.nkh : 0; c.nkw = c.nkw > 0 ? c.nkw : 0; c.Ktot = 0; }
-      if (dtype == MDCV_BF16) rc = dispatch_dgrad_s2<bf16_t>(c, st, B);
-      else if (dtype == MDCV_F32) rc = dispatch_dgrad_s2<float>(c, st, B);
+      if (dtype == MDCV_BF16) rc = mdcv_cd_bf16_s2(c, st, B);
+      else if (dtype == MDCV_F32) rc = mdcv_cd_f32_s2(c, st, B);
       else return MDCV_EARG;
       if (rc) return rc;
     }
@@ -1846,7 +1856,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
     if (!small) return MDCV_EARG;
     const int keep = g_conv_variant;
     if (keep >= 0 && keep < 6) g_conv_variant = -1;
-    const int rc = dtype == MDCV_BF16 ? dispatch_conv<bf16_t, 1>(a, st, B) : (dtype == MDCV_F32 ? dispatch_conv<float, 1>(a, st, B) : MDCV_EARG);
+    const int rc = dtype == MDCV_BF16 ? mdcv_cd_bf16_dgrad(a, st, B) : (dtype == MDCV_F32 ? mdcv_cd_f32_dgrad(a, st, B) : MDCV_EARG);
     g_conv_variant = keep;
     return rc;
   }
@@ -1857,8 +1867,8 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
       if (e != hipSuccess) return (int)e;
     }
   }
-  if (dtype == MDCV_BF16) return mode == 0 ? dispatch_conv<bf16_t, 0>(a, st, B) : dispatch_conv<bf16_t, 1>(a, st, B);
-  if (dtype == MDCV_F32) return mode == 0 ? dispatch_conv<float, 0>(a, st, B) : dispatch_conv<float, 1>(a, st, B);
+  if (dtype == MDCV_BF16) return mode == 0 ? mdcv_cd_bf16_fwd(a, st, B) : mdcv_cd_bf16_dgrad(a, st, B);
+  if (dtype == MDCV_F32) return mode == 0 ? mdcv_cd_f32_fwd(a, st, B) : mdcv_cd_f32_dgrad(a, st, B);
   return MDCV_EARG;
 }
 
@@ -1936,20 +1946,20 @@ int mdcv_conv2d_wgrad_set_variant(int v) {   /* tuning hook; 1000 + 100*d + bloc
   return MDCV_OK;
 }
 int mdcv_conv2d_set_variant(int v) {
-  if (v <= -3 && v >= -26) { mdcv_shift_set_ring(-v); v = -1; }   // shift kernel tuning: -7 default plan, -8 256-row, -9 128-row, -10 mixed, -11 16-wave workgroups, -12 192-row tiles where they save a round
-  if (v == 97 || v == 96) { g_conv_midgrid = v == 97 ? 300 : 0; return MDCV_OK; }
-  if (v >= 9000 && v < 9999) { g_conv_deep4 = v - 9000; return MDCV_OK; }
-  if (v >= 3000 && v < 9000) { g_conv_midgrid = v - 3000; return MDCV_OK; }   // 3000 + first t128 that takes 256x128 tiles
-  if (v == 95 || v == 94) { g_conv_fuse_small = v == 95; return MDCV_OK; }
+  // tuning / A-B hook of the conv family (tests walk the tile variants; scripts/ab_env.sh runs whole steps under a setting).  -1: heuristics.
+  //   0..11  forced tile configuration of wide layers (0-5 register-staged kernels, 6-11 LDS-DMA: 128x128 / 128x64 / 256x128 x 2 / 3 stages); 100 + v: generic address path
+  //   16/17  stride-2 data gradient as four parity-class launches / one launch        18/19, 20/21  its tall tiles, its 3-stage ring off / on
+  //   30+n   3-stage ring for 33..64-channel layers from n K steps (30 never)           60+n  the same for 128x128 / 128x64 tiles (60 never)
+  //   92/93  128x64 tiles for fused 1x1 data gradients off / on                         2000+n  256-row tiles for Nout <= 64 from n Ki positions (2000 off)
+  //   -3..-26  shift-kernel hooks (conv_shift.hip: mdcv_shift_set_ring)
+  if (v <= -3 && v >= -26) { mdcv_shift_set_ring(-v); v = -1; }
   if (v == 93 || v == 92) { g_conv_fuse_narrow = v == 93; return MDCV_OK; }
   if (v >= 60 && v < 92) { g_conv_deep_small = v - 60; return MDCV_OK; }
   if (v >= 30 && v < 60) { g_conv_deep_narrow = v - 30; return MDCV_OK; }
   if (v == 20 || v == 21) { g_conv_deep_s2 = v - 20; return MDCV_OK; }
   if (v == 16 || v == 17) { g_conv_s2_allcls = v - 16; return MDCV_OK; }
   if (v == 18 || v == 19) { g_conv_tall_s2 = v - 18; return MDCV_OK; }
-  if (v == 22 || v == 23) { g_conv_deep_narrow32 = v - 22; return MDCV_OK; }
   if (v >= 2000 && v < 3000) { g_conv_tall_narrow = v - 2000; return MDCV_OK; }
-  if (v >= 24 && v < 30) { g_conv_tall_mask = v - 24; return MDCV_OK; }
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
   g_conv_variant = v == 99 ? -1 : v;
   return MDCV_OK;
@@ -2068,28 +2078,6 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, KH * KW, accumulate, st);
 }
 
-// Weight gradients of `nlayers` convolutions of identical geometry in ONE launch pair (see include/mdcv_hip.h).
-int mdcv_conv2d_wgrad_batched_splits(int dtype, int nlayers, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW,
-                                     int stride, int pad, int dil, int dy_ldc, int x_ldc) {
-  if (nlayers < 1 || g_wgrad_variant == 9 || g_wgrad_variant == 10 || Hin != Hout || Win != Wout) return 0;
-  if (!mdcv_wgrad_stream_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc)) return 0;
-  return mdcv_wgrad_stream_batch_splits(nlayers, B, Hout, Wout, Cin, Cout, dil);
-}
-
-int mdcv_conv2d_wgrad_batched(int dtype, const void* table, int nlayers, int dy_ldc, int x_ldc, float* ws, int splits, int accumulate,
-                              int B, int Hin, int Win, int Cin, int Cin_real, int Hout, int Wout, int Cout, int Cout_real,
-                              int KH, int KW, int stride, int pad, int dil, void* stream) {
-  if (!table || !ws || nlayers < 1 || splits < 1) return MDCV_EARG;
-  if ((Cin & 7) || (Cout & 7) || (dy_ldc & 7) || (x_ldc & 7)) return MDCV_EARG;
-  if (mdcv_conv2d_wgrad_batched_splits(dtype, nlayers, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc) <= 0 ||
-      !mdcv_wgrad_stream_splits_ok(splits, B, Hout, Wout, Cin, Cout, dil))
-    return MDCV_EARG;
-  const int rc = mdcv_wgrad_stream(nullptr, dy_ldc, nullptr, x_ldc, ws, splits, B, Hout, Wout, Cin, Cout, dil, (hipStream_t)stream, table, nlayers);
-  if (rc) return rc;
-  return launch_wgrad_reduce(ws, nullptr, splits, Cout, Cout_real, Cin, Cin_real, 9, accumulate, (hipStream_t)stream,
-                             reinterpret_cast<const WgradBatchRec*>(table), nlayers);
-}
-
 int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,
                       int Cout_pad, int Cin_pad, void* stream) {
   if (!w_oihw || !w_fwd) return MDCV_EARG;
@@ -2129,3 +2117,5 @@ int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, int max
 }
 
 }  // extern "C"
+
+#endif   // MDCV_CONV_PART == 0 (host entry points)

@@ -27,9 +27,39 @@
 #include "conv_shift.h"
 #include "bn_fuse.h"
 
+// The file is compiled twice (Makefile: conv_shift_fwd.o with -DMDCV_SHIFT_PART=0, conv_shift_dgrad.o with -DMDCV_SHIFT_PART=1) so that the
+// forward and the data-gradient instantiations build in parallel; part 0 also holds the host entry points and the tuning globals.
+#ifndef MDCV_SHIFT_PART
+#define MDCV_SHIFT_PART 0
+#endif
+#if MDCV_SHIFT_PART == 0
+int g_shift_ring = 4;   // weight-ring depth of sparse grids (<= 256 tiles); 3: off (tuning hook: mdcv_conv2d_set_variant(-3 / -4))
+int g_shift_wmax_narrow = 104; // rows up to 104 pixels for the 64- / 32-wide tiles (their smaller weight ring keeps two workgroups on a CU): the data gradients of
+                               // YOLOv3's 104x104 64->128 layers, +0.3 % on its step (set_variant(-24) off, (-23) on)
+int g_shift_wmax_n32 = 0;   // tuning (set_variant(-25) -> 208, (-26) -> off): 32-wide tiles on rows up to 208 pixels (128-row tiles)
+int g_shift_dil2 = 1;   // dilation-2 layers (stream padded with two shared zero columns / rows): 1 = where it pays (below), 2 = every eligible
+                        // layer (set_variant(-20)), 0 = never (set_variant(-21)), set_variant(-22) restores 1
+int g_shift_n64 = 2;    // 64- and 32-channel layers run one narrow tile column (set_variant(-18) off / (-17) 64 only / (-19) 64 and 32): RektNet's
+                        // 64->64 layers 210 -> 168 us forward, 211 -> 153 us data gradient, +0.5 % on its step; the 32->32 layers another +0.35 %
+int g_shift_wmax = 80;  // widest image row the shift kernel takes (set_variant(-15) -> 62, (-14) -> 80).  Up to 62 the chunk is 384 rows (3 DMAs per
+                        // wave); 63..80 take a fourth and still fit two workgroups on a CU: RektNet's 128->128 layers at 80x80 +3.1 % on its step,
+                        // the 76x76 layers of the 608^2 detector +1 % on the joint pipeline (same-box A/B)
+int g_shift_plan = 0;   // 0 / 5: default plan (192-row tiles where they save a round) ; 1: 256-row tiles only ; 2: 128-row only ; 6: never 192-row
+#else
+extern int g_shift_ring;
+extern int g_shift_wmax_narrow;
+extern int g_shift_wmax_n32;
+extern int g_shift_dil2;
+extern int g_shift_n64;
+extern int g_shift_wmax;
+extern int g_shift_plan;
+#endif
+int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes);   // defined by part 1
+
 namespace {
 
-constexpr int BN = 128, WM = 4;     // default tile width ; waves: 4 (M) x WN (N), WN = 2 (8 waves, wave tile (BM/4) x 64) or 4 (16 waves, (BM/4) x 32)
+[[maybe_unused]] constexpr int BN = 128;
+constexpr int WM = 4;     // default tile width (BN) ; waves: 4 (M) x WN (N), WN = 2 (8 waves, wave tile (BM/4) x 64)
 // (per instantiation: BTILE = BN * 64 bytes per weight tile of the ring, SROW = BN * 2 + 16 bytes epilogue staging pitch)
 constexpr unsigned OOB = 0x80000000u;
 
@@ -50,19 +80,6 @@ __device__ long long g_shift_ts[4 * 512];
 #else
 #define STS(k)
 #endif
-
-int g_shift_ring = 4;   // weight-ring depth of sparse grids (<= 256 tiles); 3: off, 6: six slots, 5: four slots on every grid (tuning hook: mdcv_conv2d_set_variant(-3 .. -6))
-int g_shift_wmax_narrow = 104; // rows up to 104 pixels for the 64- / 32-wide tiles (their smaller weight ring keeps two workgroups on a CU): the data gradients of
-                               // YOLOv3's 104x104 64->128 layers, +0.3 % on its step (set_variant(-24) off, (-23) on)
-int g_shift_wmax_n32 = 0;   // tuning (set_variant(-25) -> 208, (-26) -> off): 32-wide tiles on rows up to 208 pixels (128-row tiles)
-int g_shift_dil2 = 1;   // dilation-2 layers (stream padded with two shared zero columns / rows): 1 = where it pays (below), 2 = every eligible
-                        // layer (set_variant(-20)), 0 = never (set_variant(-21)), set_variant(-22) restores 1
-int g_shift_n64 = 2;    // 64- and 32-channel layers run one narrow tile column (set_variant(-18) off / (-17) 64 only / (-19) 64 and 32): RektNet's
-                        // 64->64 layers 210 -> 168 us forward, 211 -> 153 us data gradient, +0.5 % on its step; the 32->32 layers another +0.35 %
-int g_shift_wmax = 80;  // widest image row the shift kernel takes (set_variant(-15) -> 62, (-14) -> 80).  Up to 62 the chunk is 384 rows (3 DMAs per
-                        // wave); 63..80 take a fourth and still fit two workgroups on a CU: RektNet's 128->128 layers at 80x80 +3.1 % on its step,
-                        // the 76x76 layers of the 608^2 detector +1 % on the joint pipeline (same-box A/B)
-int g_shift_plan = 0;   // 0: default plan ; 1: 256-row tiles only ; 2: 128-row only ; 3: mixed rounds ; 4: 16 waves ; 5: 192-row tiles where they save a round (= default) ; 6: never 192-row
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -421,9 +438,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   // such launches (batch 32: the 13x13 and 26x26 data gradients) take a 4-slot weight ring.  Same-box A/B of the YOLOv3 step:
   // +0.45 .. 0.6 % (6 slots +0.35 %; 4 slots on EVERY grid -2.8 %: the 36-step unrolled period and the third workgroup's worth of LDS).
   if constexpr (BRING == 3 && WN == 2 && !EPI) {
-    if (g_shift_ring == 6 && tiles_m * a.tiles_n <= 256)
-      return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 6, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-    if ((g_shift_ring == 4 && tiles_m * a.tiles_n <= 256) || g_shift_ring == 5)
+    if (g_shift_ring == 4 && tiles_m * a.tiles_n <= 256)
       return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 4, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
   a.p_base = p_base;
@@ -457,21 +472,11 @@ int launch_shift(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, un
   return launch_shift_f<MODE, BM, NPA, false, WN, false, 3, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
 }
 
-// 16-wave workgroups (4 x 4 waves of (BM/4) x 32) were tried for grids that put at most one workgroup on a CU (idea: 4 waves per
-// SIMD from one workgroup hide the K-step latencies like two co-resident 8-wave workgroups).  Measured slower everywhere
-// (26x26 dgrad 54.4 vs 50.4 us, 13x13 forward 56.1 vs 52.2 us: the 16-wave barrier and the extra fragment reads cost more than
-// the latency hiding gains), so the variant is only reachable through the tuning hook (plan 4).
+// (16-wave workgroups -- 4 x 4 waves of (BM/4) x 32 -- were tried for grids that put at most one workgroup on a CU and measured slower
+// everywhere: 26x26 dgrad 54.4 vs 50.4 us, 13x13 forward 56.1 vs 52.2 us; removed in round 3.)
 template <int MODE, int BM, int BN_>
 int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   const int nca = (BM + 2 * a.dil * (a.Wq + 1) + 15) / 16;
-  if constexpr (BN_ == 128) {
-    const bool wide = g_shift_plan == 4 && !a.fuse.y;
-    if (wide) {
-      const int npa = (nca + 15) / 16;
-      if (npa <= 1) return launch_shift<MODE, BM, 1, 4, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-      return launch_shift<MODE, BM, 2, 4, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-    }
-  }
   const int npa = (nca + 7) / 8;
   if (npa <= 2) return launch_shift<MODE, BM, 2, 2, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   if (npa == 3) return launch_shift<MODE, BM, 3, 2, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
@@ -508,16 +513,10 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128) {
 
 template <int MODE, int BN_>
 int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
-  const int SLOTS = 512;
   const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr, 2 * a.dil * (a.Wq + 1), BN_);
   if (bm == 192) return launch_shift_bm<MODE, 192, BN_>(a, 0, (a.Mq + 191) / 192, st, in_bytes, w_bytes);
   const int big_m = (a.Mq + 255) / 256;
-  const int t_big = big_m * a.tiles_n;
-  int nbig_m = bm == 128 ? 0 : big_m;
-  if (g_shift_plan == 3 && bm == 256) {              // tuning: full rounds as 256-row tiles, a short remainder as 128-row tiles
-    const int full = t_big / SLOTS * SLOTS, rem = t_big - full;
-    nbig_m = (rem > 0 && rem <= SLOTS / 2) ? full / a.tiles_n : big_m;
-  }
+  const int nbig_m = bm == 128 ? 0 : big_m;
   if (nbig_m > 0) {
     const int rc = launch_shift_bm<MODE, 256, BN_>(a, 0, nbig_m, st, in_bytes, w_bytes);
     if (rc) return rc;
@@ -529,6 +528,13 @@ int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, uns
 
 }  // namespace
 
+#if MDCV_SHIFT_PART == 1
+int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
+  if (a.Nout == 32) return launch_shift_mode<1, 32>(a, st, in_bytes, w_bytes);
+  if (a.Nout == 64) return launch_shift_mode<1, 64>(a, st, in_bytes, w_bytes);
+  return launch_shift_mode<1, 128>(a, st, in_bytes, w_bytes);
+}
+#else
 // ---- host side (internal linkage across the library's objects: declared in conv_shift.h)
 bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc) {
   if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != dil || (dil != 1 && !(dil == 2 && g_shift_dil2))) return false;
@@ -566,12 +572,13 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   a.wrow = 9 * Cin;
   const unsigned in_bytes = (unsigned)((long long)B * H * W * in_ldc * 2);
   const unsigned w_bytes = (unsigned)((long long)Nout * 9 * Cin * 2);
-  if (Nout == 32) return mode == 0 ? launch_shift_mode<0, 32>(a, st, in_bytes, w_bytes) : launch_shift_mode<1, 32>(a, st, in_bytes, w_bytes);
-  if (Nout == 64) return mode == 0 ? launch_shift_mode<0, 64>(a, st, in_bytes, w_bytes) : launch_shift_mode<1, 64>(a, st, in_bytes, w_bytes);
-  return mode == 0 ? launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes) : launch_shift_mode<1, 128>(a, st, in_bytes, w_bytes);
+  if (mode != 0) return mdcv_shift_launch_dgrad(a, st, in_bytes, w_bytes);
+  if (Nout == 32) return launch_shift_mode<0, 32>(a, st, in_bytes, w_bytes);
+  if (Nout == 64) return launch_shift_mode<0, 64>(a, st, in_bytes, w_bytes);
+  return launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring == 3 || ring == 4) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);
@@ -592,3 +599,5 @@ extern "C" int mdcv_debug_shift_wg(long long* host3x4096) {
   return (int)hipMemcpyFromSymbol(host3x4096, HIP_SYMBOL(g_shift_wg), sizeof(long long) * 3 * 4096);
 }
 #endif
+
+#endif   // MDCV_SHIFT_PART

@@ -10,21 +10,15 @@ struct WgradStreamArgs {
   int Wq, Sq, Mq;                       // W+dil, (H+dil)(W+dil), B*Sq: padded position stream with `dil` shared zero columns / rows
   int hpad, RS;                         // halo rows on each side (multiple of 32) and rows of the activation ring
   int pos_per_split, splits, xcd_chunk;
-  int tiles, tiles_ci;                  // TILED instantiation: (Cout/128) x (Cin/64) channel tiles per split, blocks = nlayers * splits * tiles
-  const void* table; int nlayers;       // layer batch: nlayers records WgradBatchRec (device memory) replace dy / x (NULL: one layer, dy / x above)
+  int tiles, tiles_ci;                  // TILED instantiation: (Cout/128 or /64) x (Cin/64) channel tiles per split, blocks = splits * tiles
 };
-
-// one layer of a batched weight-gradient launch (mdcv_conv2d_wgrad_batched): 24-byte device-resident record
-struct WgradBatchRec { const void* dy; const void* x; float* dw; };
 
 bool mdcv_wgrad_stream_eligible(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
                                 long long dy_ldc, long long x_ldc);
 int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil);
 bool mdcv_wgrad_stream_splits_ok(int splits, int B, int H, int W, int Cin, int Cout, int dil);
 int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, int Cin, int Cout,
-                      int dil, hipStream_t st, const void* table = nullptr, int nlayers = 1);
-// the channel-tiled instantiation takes a batch of same-geometry layers; splits for a batch of nlayers (0: geometry not tiled)
-int mdcv_wgrad_stream_batch_splits(int nlayers, int B, int H, int W, int Cin, int Cout, int dil);
+                      int dil, hipStream_t st);
 void mdcv_wgrad_stream_tiled_blocks(int blocks);   // tuning hook: target block count of the channel-tiled instantiation (default 128)
 void mdcv_wgrad_stream_tune(int d, int blocks);   // tuning hook: prefetch depth (0 = default), target block count (0 = default)
 // 7x7 / stride 1 / pad 3 stem, 16 (padded) -> 16 channels

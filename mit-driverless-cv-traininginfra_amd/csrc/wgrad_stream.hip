@@ -75,8 +75,7 @@ template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[4], bf1
 // TILED: the block owns a 16*NCO x 9 x 16*NCI slice of a LARGER dW (Cout = tiles_co * 16*NCO, Cin = tiles_ci * 16*NCI): the 128..1024-channel
 // layers of YOLOv3 at 52x52 / 26x26 / 13x13.  Same ring, same fragments; the DMA columns and the slab rows / columns carry the tile offset.
 // 128 co x 64 ci x 9 taps per block fills 24 KiB per 64 positions = 393 FLOP per filled byte (generic 128 x 128 im2col tile: 64).
-// NW: waves per block (8, or 4 for the one-wave-per-SIMD instantiation whose waves own all 128 output channels: A = 8, 288 accumulator
-// registers, 17 fragment reads per 72 MFMAs instead of 13 per 36).
+// NW: waves per block (8, or 4 for the light form: 64 co x 64 ci per block, one wave per SIMD).
 template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3x3_stream_kernel(WgradStreamArgs a, unsigned dy_bytes, unsigned x_bytes) {
   constexpr int RBX = NCI * 32, RBY = NCO * 32;            // row bytes
@@ -100,24 +99,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
   int split = logical, tile_co = 0, tile_ci = 0;
   if constexpr (TILED) {
     static_assert(TGRP == 1, "tiled slabs are written one tap at a time");
-    if (logical >= a.nlayers * a.splits * a.tiles) return;
-    split = logical / a.tiles;                               // = layer * splits + split: the tiles of one split are neighbours on an XCD
+    if (logical >= a.splits * a.tiles) return;
+    split = logical / a.tiles;                               // the tiles of one split are neighbours on an XCD
     const int tl = logical - split * a.tiles;                //   (they read the same pixel rows)
     tile_co = tl / a.tiles_ci; tile_ci = tl - tile_co * a.tiles_ci;
   } else {
     if (logical >= a.splits) return;
   }
-  const int slab_index = split;                              // [layer][split] slab of the workspace
+  const int slab_index = split;
   const void* dyp = a.dy;
   const void* xp = a.x;
-  if constexpr (TILED) {
-    const int layer = split / a.splits;
-    split -= layer * a.splits;
-    if (a.table) {                                           // batch of same-geometry layers: this block's operands
-      const WgradBatchRec* rec = reinterpret_cast<const WgradBatchRec*>(a.table) + layer;
-      dyp = rec->dy; xp = rec->x;
-    }
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pg = wave % PG, tg = wave / PG;
@@ -321,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
   const bool late = NSUB == 1 && wave >= NW / 2;             // (two sub-steps per step: the skewed schedule spills)
 #endif
   // channel-tiled instantiation: the reads run a few fragments ahead of the multiplies (wgrad_stream_pipe.inc, scripts/gen_wgrad_pipeline.py)
-  constexpr bool kPipe = TILED && NSUB == 2 && PG == 1 && (A == 4 || A == 8) && g_pipe_enabled;
+  constexpr bool kPipe = TILED && NSUB == 2 && PG == 1 && A == 4 && g_pipe_enabled;
   bf16x8_t fa2[2][A];
   if constexpr (kPipe) {
 #pragma unroll
@@ -344,11 +335,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
     if constexpr (kPipe) {
       using N0 = std::integral_constant<int, 0>;
       using N1 = std::integral_constant<int, 1>;
-      if constexpr (A == 4) {
 #include "wgrad_stream_pipe.inc"
-      } else {
-#include "wgrad_stream_pipe8.inc"
-      }
     } else {
       static_assert(NSUB <= 4, "sub-steps are unrolled by hand below");
       reads(std::integral_constant<int, 0>{});
@@ -546,34 +533,20 @@ __global__ __launch_bounds__(512) void wgrad7x7_stream_kernel(WgradStreamArgs a,
 }
 
 struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; bool tiled = false; int nw = 8; };
-int g_stream_d = 0;        // tuning hook: force the prefetch depth (1..3); 0 = per-configuration default
-int g_stream_blocks = 0;   // tuning hook: force the target block count; 0 = default
-int g_stream_alt = 0;      // tuning hook: alternative wave grids (A = 2, two blocks per CU) for 32->64 and 64->64
-int g_stream_tiled = 1;    // 128 co x 64 ci tiles for the wide layers (Cin % 64 == 0, Cout % 128 == 0); tuning hook: 0 = off
-int g_stream_w4 = 0;       // tuning hook (MDCV_WGRAD_VARIANT=30001): tiled instantiation with 4 waves per block, each owning all 128 output channels
-                           // (A = 8: 17 transpose reads per 72 MFMAs instead of 13 per 36, 456 registers, one wave per SIMD).  Measured SLOWER: 52^2 128->256
-                           // 99 vs 80 us on 256 blocks, 149 vs 97 us on 128; YOLOv3 step 2044 vs 2142 img/s -- one wave per SIMD cannot cover the read latency
-// Light form of the tiled instantiation: 64 co x 64 ci per block, FOUR waves (one per SIMD, 216 VGPRs), prefetch depth 1, 48 KiB of LDS -- about
-// half a CU, on 256 blocks.  The 8-wave form owns its CU outright (2 x 232 VGPRs per SIMD, 112 KiB) and runs on 128 blocks so that the main
-// stream keeps the other half of the chip; the light form leaves room for main-stream workgroups on EVERY CU instead (296 registers per lane,
-// 112 KiB), and their waves fill the issue slots its single wave per SIMD leaves open.  Same-box A/B of the YOLOv3 step: 14.45 -> 14.32 ms
-// (256 blocks; 192: 14.62, 224: 14.35, 288: 14.39, 320: 14.54, 384: 14.77; depth 2: 14.60).  Layers with long position streams stay on the
-// 8-wave form: RektNet's 80^2 x 256-image layers (1.68 M positions) lose 1.3 % with the light form.
-int g_stream_light_maxpos = 600000;   // light form up to this many padded stream positions (tuning: 30003 / 30004 force it with depth 1 / 2, 30005 = never)
-int g_stream_light_blocks = 256;      // its block target (tuning: 33000 + n)
-int g_stream_light_d = 1;
-int g_stream_tiled_wmask = 15;   // tuning (39000 + mask): image widths that take the tiled instantiation, 1: <= 16, 2: <= 32, 4: <= 64, 8: wider
-int g_stream_tiled_blocks_13 = 0, g_stream_tiled_blocks_26 = 0;   // tuning: block targets for images of at most 16 / 32 rows (0: the common target)
-int g_stream_tiled_blocks = 128;   // target block count of the tiled instantiation.  A block fills its CU (8 waves x 224 VGPRs, 112 KiB LDS), and the
-                           // weight gradients run on a side stream BESIDE the main stream's kernels: with one block on every CU the main stream's
-                           // workgroups wait for whole weight-gradient blocks to retire; 128 blocks leave half the CUs to the main stream
-                           // (YOLOv3 step, same-box A/B: 256 blocks 2033, 192: 2080, 128: 2103, 64: 2033 img/s)
-static int tiled_blocks_for(int H) {
-  if (H <= 16 && g_stream_tiled_blocks_13 > 0) return g_stream_tiled_blocks_13;
-  if (H <= 32 && g_stream_tiled_blocks_26 > 0) return g_stream_tiled_blocks_26;
-  return g_stream_tiled_blocks;
-}
-
+// Tuning hooks (mdcv_conv2d_wgrad_set_variant): ONE per decision that was measured on the training step.
+int g_stream_blocks = 0;   // force the target block count of every form; 0 = defaults below (1000 + blocks/64)
+int g_stream_tiled = 1;    // channel-tiled instantiation for the wide layers (Cin % 64 == 0, Cout % 128 == 0); 0 = off (1800)
+// Light form of the tiled instantiation: 64 co x 64 ci per block, FOUR waves (one per SIMD, 237 VGPRs), prefetch depth 1, 56 KiB of LDS -- about
+// half a CU, on 256 blocks.  The 8-wave form owns its CU outright (2 x 234 VGPRs per SIMD, 120 KiB) and runs on 128 blocks so that the main
+// stream keeps the other half of the chip; the light form leaves room for main-stream workgroups on EVERY CU instead, and their waves fill
+// the issue slots its single wave per SIMD leaves open.  Same-box A/B of the YOLOv3 step: 14.45 -> 14.32 ms (256 blocks; 192: 14.62, 224:
+// 14.35, 288: 14.39, 320: 14.54, 384: 14.77; depth 2: 14.60).  Layers with long position streams stay on the 8-wave form (RektNet's 80^2 x
+// 256-image layers, 1.68 M positions: -1.3 % with the light form in round 2, neutral since the round-3 address rework).
+int g_stream_light_maxpos = 600000;   // light form up to this many padded stream positions (30003: everywhere, 30005: never, 30002: default)
+int g_stream_light_blocks = 256;      // its block target (33000 + n)
+int g_stream_tiled_blocks = 128;      // block target of the 8-wave tiled form (30000 + n).  A block fills its CU, and the weight gradients run BESIDE
+                                      // the main stream: with one block on every CU the main stream's workgroups wait for whole weight-gradient blocks to
+                                      // retire (YOLOv3 step, same-box A/B: 256 blocks 2033, 192: 2080, 128: 2103, 64: 2033 img/s)
 
 // (Cin, Cout) -> instantiation; false if unsupported
 inline bool stream_cfg(int Cin, int Cout, StreamCfg& c, long long Mq = 0) {     // Mq: padded stream positions (0: unknown -> the 8-wave form)
@@ -585,13 +558,9 @@ inline bool stream_cfg(int Cin, int Cout, StreamCfg& c, long long Mq = 0) {     
   else if (Cin == 64 && Cout == 128 && !g_stream_tiled) c = {4, 8, 4, 1, 64, 2, 1};
   else if (g_stream_tiled && Cin % 64 == 0 && Cout % 128 == 0 && Cin <= 4096 && Cout <= 4096) {
     c = {4, 8, 4, 1, 64, 2, 1}; c.tiled = true;
-    if (g_stream_w4 == 1) { c.a = 8; c.nw = 4; }
-    if (g_stream_w4 == 2 || (g_stream_w4 == 0 && Mq > 0 && Mq <= g_stream_light_maxpos)) { c.nco = 4; c.nw = 4; c.d = g_stream_light_d; }   // light form
+    if (Mq > 0 && Mq <= g_stream_light_maxpos) { c.nco = 4; c.nw = 4; c.d = 1; }   // light form
   }
   else return false;
-  if (g_stream_alt && Cin == 32 && Cout == 64) c = {2, 4, 2, 2, 128, 2, 3};
-  if (g_stream_alt && Cin == 64 && Cout == 64) c = {4, 4, 2, 1, 64, 2, 3};
-  if (g_stream_d >= 1 && g_stream_d <= 3) c.d = g_stream_d;
   return true;
 }
 
@@ -611,7 +580,6 @@ inline int stream_lds(const StreamCfg& c, int W, int dil) {
 // configuration for a layer geometry: the prefetch depth shrinks until ring + stages fit the 160 KiB of a CU
 inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c, long long Mq = 0) {
   if (!stream_cfg(Cin, Cout, c, Mq)) return false;
-  if (c.tiled && !(g_stream_tiled_wmask & (W <= 16 ? 1 : (W <= 32 ? 2 : (W <= 64 ? 4 : 8))))) return false;   // tuning: the generic kernel for this image size
   while (c.d > 1 && stream_lds(c, W, dil) > 160 * 1024) --c.d;
   return stream_lds(c, W, dil) <= 160 * 1024;
 }
@@ -652,7 +620,7 @@ int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil) {
   const int Mq = B * (H + dil) * (W + dil);
   if (!stream_cfg(Cin, Cout, c, Mq)) return 1;
   int s = g_stream_blocks > 0 ? g_stream_blocks : (c.a <= 2 ? 512 : 256);
-  if (c.tiled) s = ((g_stream_blocks > 0 ? g_stream_blocks : (c.nco == 4 ? g_stream_light_blocks : tiled_blocks_for(H))) + (Cout / (16 * c.nco)) * (Cin / 64) - 1) / ((Cout / (16 * c.nco)) * (Cin / 64));   // blocks = splits x channel tiles
+  if (c.tiled) s = ((g_stream_blocks > 0 ? g_stream_blocks : (c.nco == 4 ? g_stream_light_blocks : g_stream_tiled_blocks)) + (Cout / (16 * c.nco)) * (Cin / 64) - 1) / ((Cout / (16 * c.nco)) * (Cin / 64));   // blocks = splits x channel tiles
   const int max_s = (Mq + c.bp * 4 - 1) / (c.bp * 4);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -668,27 +636,10 @@ bool mdcv_wgrad_stream_splits_ok(int splits, int B, int H, int W, int Cin, int C
   return (Mq + pps - 1) / pps == splits;
 }
 
-// splits per layer for a batch of `nlayers` same-geometry layers through the channel-tiled kernel: blocks = nlayers x splits x tiles ~ one per CU,
-// never less than 4 steps per split; 0 when the geometry does not take the tiled instantiation
-int mdcv_wgrad_stream_batch_splits(int nlayers, int B, int H, int W, int Cin, int Cout, int dil) {
-  StreamCfg c;
-  if (nlayers < 1 || !stream_cfg_geom(Cin, Cout, W, dil, c) || !c.tiled) return 0;
-  const int Mq = B * (H + dil) * (W + dil);
-  const int tiles = (Cout / (16 * c.nco)) * (Cin / 64) * nlayers;
-  int s = ((g_stream_blocks > 0 ? g_stream_blocks : g_stream_tiled_blocks) + tiles - 1) / tiles;
-  const int max_s = (Mq + c.bp * 4 - 1) / (c.bp * 4);
-  if (s > max_s) s = max_s;
-  if (s < 1) s = 1;
-  const int pps = ((Mq + s - 1) / s + c.bp - 1) / c.bp * c.bp;
-  return (Mq + pps - 1) / pps;
-}
-
 int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, int Cin, int Cout,
-                      int dil, hipStream_t st, const void* table, int nlayers) {
+                      int dil, hipStream_t st) {
   StreamCfg c;
-  const bool batch = table || nlayers != 1;                  // batches keep the 8-wave form (mdcv_wgrad_stream_batch_splits)
-  if (!stream_cfg_geom(Cin, Cout, W, dil, c, batch ? 0 : (long long)B * (H + dil) * (W + dil))) return MDCV_EARG;
-  if (batch && !c.tiled) return MDCV_EARG;
+  if (!stream_cfg_geom(Cin, Cout, W, dil, c, (long long)B * (H + dil) * (W + dil))) return MDCV_EARG;
   if (c.bp / (W + dil) + 1 >= H + dil) return MDCV_EARG;
   WgradStreamArgs a;
   a.dy = dy; a.x = x; a.ws = ws; a.dy_ldc = dy_ldc; a.x_ldc = x_ldc;
@@ -701,33 +652,18 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   a.splits = splits;
   a.tiles_ci = c.tiled ? Cin / 64 : 1;
   a.tiles = c.tiled ? (Cout / (16 * c.nco)) * a.tiles_ci : 1;
-  a.table = table; a.nlayers = nlayers;
-  a.xcd_chunk = (nlayers * splits * a.tiles + 7) / 8;
+  a.xcd_chunk = (splits * a.tiles + 7) / 8;
   const int lds = stream_lds(c, W, dil);
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
-  if (c.tiled && c.nw == 4 && c.nco == 4) {
-    if (c.d == 1) return launch_stream<4, 4, 4, 1, 64, 1, 1, true, 4>(a, lds, dyb, xb, st);
-    return launch_stream<4, 4, 4, 1, 64, 2, 1, true, 4>(a, lds, dyb, xb, st);
-  }
-  if (c.tiled && c.nw == 4) {
-    if (c.d == 1) return launch_stream<4, 8, 8, 1, 64, 1, 1, true, 4>(a, lds, dyb, xb, st);
-    if (c.d == 2) return launch_stream<4, 8, 8, 1, 64, 2, 1, true, 4>(a, lds, dyb, xb, st);
-    return launch_stream<4, 8, 8, 1, 64, 3, 1, true, 4>(a, lds, dyb, xb, st);
-  }
+  if (c.tiled && c.nw == 4) return launch_stream<4, 4, 4, 1, 64, 1, 1, true, 4>(a, lds, dyb, xb, st);
   if (c.tiled) {
     if (c.d == 1) return launch_stream<4, 8, 4, 1, 64, 1, 1, true>(a, lds, dyb, xb, st);
-    if (c.d == 2) return launch_stream<4, 8, 4, 1, 64, 2, 1, true>(a, lds, dyb, xb, st);
-    return launch_stream<4, 8, 4, 1, 64, 3, 1, true>(a, lds, dyb, xb, st);
+    return launch_stream<4, 8, 4, 1, 64, 2, 1, true>(a, lds, dyb, xb, st);
   }
 #define STREAM_CASE(CI, CO, NCI, NCO, A, PG, BP, TGRP)                                            \
   if (Cin == CI && Cout == CO) {                                                                  \
     if (c.d == 1) return launch_stream<NCI, NCO, A, PG, BP, 1, TGRP>(a, lds, dyb, xb, st);        \
-    if (c.d == 2) return launch_stream<NCI, NCO, A, PG, BP, 2, TGRP>(a, lds, dyb, xb, st);        \
-    return launch_stream<NCI, NCO, A, PG, BP, 3, TGRP>(a, lds, dyb, xb, st);                      \
-  }
-  if (g_stream_alt) {
-    STREAM_CASE(32, 64, 2, 4, 2, 2, 128, 3)
-    STREAM_CASE(64, 64, 4, 4, 2, 1, 64, 3)
+    return launch_stream<NCI, NCO, A, PG, BP, 2, TGRP>(a, lds, dyb, xb, st);                      \
   }
   STREAM_CASE(16, 16, 1, 1, 1, 8, 256, 9)
   STREAM_CASE(16, 32, 1, 2, 2, 8, 256, 9)
@@ -739,19 +675,15 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   return MDCV_EARG;
 }
 
-void mdcv_wgrad_stream_tiled_blocks(int blocks) {      // 30000 + n: block target of the 8-wave form ; 30001: 4 waves x 128 co ; 30002: default choice ; 30003 / 30004: light form everywhere
-                                                       // (depth 1 / 2) ; 30005: never ; 33000 + n: its block target ; 35000 + n: images of at most 16 rows ; 37000 + n: at most 32 rows
-  if (blocks == 1) { g_stream_w4 = 1; return; }
-  if (blocks == 2) { g_stream_w4 = 0; g_stream_light_maxpos = 600000; g_stream_light_d = 1; return; }   // the default: light form for short streams
-  if (blocks == 3 || blocks == 4) { g_stream_w4 = 2; g_stream_light_d = blocks - 2; return; }   // light form everywhere (64 co x 64 ci, 4 waves)
-  if (blocks == 5) { g_stream_w4 = 0; g_stream_light_maxpos = 0; return; }                        // light form never
+void mdcv_wgrad_stream_tiled_blocks(int blocks) {      // 30000 + n: block target of the 8-wave form ; 30002: default form choice ; 30003: light form everywhere ;
+                                                       // 30005: never ; 33000 + n: the light form's block target
+  if (blocks == 2) { g_stream_light_maxpos = 600000; return; }
+  if (blocks == 3) { g_stream_light_maxpos = 1 << 30; return; }
+  if (blocks == 5) { g_stream_light_maxpos = 0; return; }
   if (blocks >= 3000 && blocks < 5000) { g_stream_light_blocks = blocks - 3000; return; }
-  if (blocks >= 9000 && blocks < 9016) { g_stream_tiled_wmask = blocks - 9000; return; }
-  if (blocks >= 7000 && blocks < 9000) { g_stream_tiled_blocks_26 = blocks - 7000; return; }
-  if (blocks >= 5000 && blocks < 7000) { g_stream_tiled_blocks_13 = blocks - 5000; return; }
   g_stream_tiled_blocks = blocks > 0 ? blocks : 128;
 }
-void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_tiled = !(d & 8); g_stream_alt = (d & 4) != 0; g_stream_d = d & 3; g_stream_blocks = blocks; }
+void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_tiled = !(d & 8); g_stream_blocks = blocks; }
 
 // ---- 7x7 stem (see wgrad7x7_stream_kernel)
 static int stem_hpad(int W) { return (3 * (W + 3 + 1) + 31) / 32 * 32; }
@@ -794,7 +726,7 @@ int mdcv_wgrad_stem(const void* dy, int dy_ldc, const void* x, int x_ldc, float*
   a.pos_per_split = ((a.Mq + splits - 1) / splits + 255) / 256 * 256;
   if ((a.Mq + a.pos_per_split - 1) / a.pos_per_split != splits) return MDCV_EARG;
   a.splits = splits;
-  a.tiles = a.tiles_ci = 1; a.table = nullptr; a.nlayers = 1;
+  a.tiles = a.tiles_ci = 1;
   a.xcd_chunk = (splits + 7) / 8;
   const int lds = stem_lds(W);
   static int attr_lds = 0;

@@ -147,9 +147,6 @@ class Plan:
         self.on_ready = None               # set per backward by the data-parallel reducer
         self.dgrad_entries = {}            # grad buffer ptr -> backward-list entry of the data gradient that wrote it last
         self.fused_bn = 0                  # BatchNorm backward reductions folded into data-gradient store loops
-        self._wb_groups = {}               # geometry key -> open batch of deferred weight gradients (emit_conv_bwd / flush_wgrad_batches)
-        self._wb_clock = 0                 # conv layers emitted into the backward list so far (age of an open batch)
-        self.wgrad_batches = []            # sizes of the batches that were launched (tests / bench)
 
     # ------------------------------------------------------------------ buffers
     def new_act(self, B, H, W, C, zero=False):
@@ -178,12 +175,8 @@ class Plan:
     def mark_ready(self):
         """Backward-list marker: every gradient at flat offset >= low_water has been ENQUEUED at this point (layers are
         processed last-to-first and the flat buffer is in parameter order).  The data-parallel reducer uses it to start
-        all-reducing finished buckets while the rest of backward still runs.  Weight gradients that wait in an open layer batch
-        are not enqueued yet: the mark stays above the highest of them."""
+        all-reducing finished buckets while the rest of backward still runs."""
         lw = self.low_water
-        for g in self._wb_groups.values():
-            for it in g["items"]:
-                lw = max(lw, it["hi"])
         if lw >= self._last_mark:
             return
         self._last_mark = lw
@@ -284,51 +277,6 @@ class Plan:
                   stats_partial.data_ptr() if stats_partial is not None else None,
                   x.B, x.H, x.W, cs.cin_pad, y.H, y.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
 
-    # Layer-batched weight gradients (mdcv_conv2d_wgrad_batched): consecutive layers of one geometry -- the repeated residual blocks of a
-    # Darknet stage -- are launched together, up to `wgrad_batch` at a time.  Their dY and X buffers are plan-owned and stay valid, the
-    # weight gradients are leaves of the backward dependency chain, so deferring them changes no value; it lengthens every block's run
-    # and divides the slab traffic per layer by the batch size.  A batch is launched when it is full, when it has been open for more
-    # than `wgrad_batch_age` later conv layers (the data-parallel reducer waits for its gradients), or at the end of the list.
-    # Measured on the YOLOv3 step (MI355X, same-box A/B): the batches cut the weight-gradient kernel + reduce time from 5.25 to 4.66 ms per
-    # step, but the step itself does not move (2103 vs 2101 img/s): the side stream's long batched kernels hold their CUs for 225..350 us
-    # at a time and the main stream's workgroups queue behind them.  Default 1 = one launch per layer; the mechanism stays for hosts that
-    # run the weight gradients on the main stream (MDCV_WGRAD_STREAM=0: 17.5 -> 16.3 ms per step with batches of four on 256 blocks).
-    wgrad_batch = int(os.environ.get("MDCV_WGRAD_BATCH", "1"))
-    wgrad_batch_age = int(os.environ.get("MDCV_WGRAD_BATCH_AGE", "12"))
-
-    def _flush_wgrad_batch(self, key):
-        g = self._wb_groups.pop(key)
-        items = g["items"]
-        L, dt = self.L, self.dtype
-        n = len(items)
-        geom = g["geom"]                       # (B, Hin, Win, cin_w, cin_real, Hout, Wout, cout_pad, cout_real, kh, kw, stride, pad, dil, dy_ldc, x_ldc)
-        B, Hin, Win, cin_w, cin_real, Hout, Wout, cout_pad, cout_real, kh, kw, stride, pad, dil, dy_ldc, x_ldc = geom
-        splits = int(L.conv2d_wgrad_batched_splits(dt, n, B, Hin, Win, cin_w, Hout, Wout, cout_pad, kh, kw, stride, pad, dil, dy_ldc, x_ldc))
-        assert splits > 0
-        self.ws_floats = max(self.ws_floats, n * splits * cout_pad * kh * kw * cin_w)
-        import struct
-        rec = b"".join(struct.pack("<QQQ", it["dy"].ptr, it["x"].ptr, it["gw"].data_ptr()) for it in items)
-        table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(self.device)
-        self.keep.append(table)
-        self.keep.append([it["gw"] for it in items])
-        plan = self
-
-        def wgrad(stream, table=table, n=n, splits=splits):
-            return L.conv2d_wgrad_batched(dt, table.data_ptr(), n, dy_ldc, x_ldc, plan.wgrad_ws().data_ptr(), splits, 0, B, Hin, Win, cin_w, cin_real,
-                                          Hout, Wout, cout_pad, cout_real, kh, kw, stride, pad, dil, stream)
-        wgrad.__name__ = "conv2d_wgrad"
-        wgrad.info = (B * n, Hin, Win, cin_w, Hout, Wout, cout_pad, kh, stride, splits)      # (batch slot = images x layers: FLOPs of the whole batch)
-        self.bwd.append((wgrad, ()))
-        for it in items:
-            self.low_water = min(self.low_water, it["lo"])
-        self.wgrad_batches.append(n)
-
-    def flush_wgrad_batches(self, older_than=None):
-        """Launch open weight-gradient batches: all of them (end of the backward list), or those opened more than `older_than` conv layers ago."""
-        for key in list(self._wb_groups):
-            if older_than is None or self._wb_clock - self._wb_groups[key]["opened"] > older_than:
-                self._flush_wgrad_batch(key)
-
     def emit_conv_bwd(self, cs, xnode, y_shape_act, dy, x_wgrad=None):
         """dy: Act gradient of the raw conv output.  Emits wgrad (+bias grad) and, if the input needs it, dgrad.
         x_wgrad: a copy of the conv's input with a wider channel padding for the weight gradient only (the 7x7 stem's LDS-ring
@@ -337,26 +285,7 @@ class Plan:
         x = xnode.act
         xw = x_wgrad if x_wgrad is not None else x
         cin_w = xw.C if x_wgrad is not None else cs.cin_pad
-        self._wb_clock += 1
-        self.flush_wgrad_batches(older_than=self.wgrad_batch_age)
-        geom = (xw.B, xw.H, xw.W, cin_w, cs.cin, dy.H, dy.W, cs.cout_pad, cs.cout, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil, dy.ldc, xw.ldc)
-        batched = (self.wgrad_batch > 1 and self.grad_offset is not None and
-                   int(L.conv2d_wgrad_batched_splits(dt, 2, xw.B, xw.H, xw.W, cin_w, dy.H, dy.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad,
-                                                     cs.dil, dy.ldc, xw.ldc)) > 0)
-        if batched:
-            # deferred: the gradient buffer is bound now, but it counts as "enqueued" (low_water) only when its batch is launched
-            lw = self.low_water
-            gw = self.param_grad(cs.weight)
-            self.low_water = lw
-            lo = self.grad_offset(cs.weight)
-            g = self._wb_groups.get(geom)
-            if g is None:
-                g = self._wb_groups[geom] = dict(geom=geom, items=[], opened=self._wb_clock)
-            g["items"].append(dict(dy=dy, x=xw, gw=gw, lo=lo, hi=lo + cs.weight.numel()))
-            if len(g["items"]) >= self.wgrad_batch:
-                self._flush_wgrad_batch(geom)
-        else:
-            self._emit_wgrad_single(cs, xw, dy, cin_w)
+        self._emit_wgrad_single(cs, xw, dy, cin_w)
         self._emit_dgrad(cs, xnode, dy)
 
     def _emit_wgrad_single(self, cs, xw, dy, cin_w):
@@ -464,21 +393,21 @@ class Plan:
                   dy2.ptr if dy2 is not None else None, dy2.ldc if dy2 is not None else 0, y1.M, y1.C, act, float(slope))
         return (dy1, dy2) if y2 is not None else dy1
 
-    # On by default (MDCV_BN_FUSE=0 restores the two-pass form).  YOLOv3 416^2 B=32: it removes 0.95 ms of stand-alone reduce kernels
+    # On by default (Plan.fuse_bn = False restores the two-pass form).  YOLOv3 416^2 B=32: it removes 0.95 ms of stand-alone reduce kernels
     # per step and adds ~1.1 ms to the 66 data gradients' store loops (the y loads are HBM misses whose latency is exposed once per
     # 128-row group at the end of each tile) -- neutral while everything ran on one stream, +0.9 % (2039 -> 2058 img/s, same-box A/B)
     # now that the weight gradients fill the MFMA pipe from the side stream and the main stream is what bounds the step.
-    fuse_bn = os.environ.get("MDCV_BN_FUSE", "1") == "1"
+    fuse_bn = True                     # (tests flip the class attribute; no environment knob)
 
-    fuse_skip = int(os.environ.get("MDCV_BN_FUSE_SKIP", "13"))
+    fuse_skip = 13                     # bit mask of the geometry classes of _fuse_pays that keep the stand-alone reduce pass (0: fuse all)
     # Data gradients whose fused sums would take more than this many partial rows (RektNet's 80^2 x 256 tensors: 12 800; YOLOv3's 208^2 / 416^2
     # layers) keep the stand-alone reduce pass.  The finalize can take them since round 2 (rows beyond 4096 are folded in place first,
     # csrc/elementwise.hip), but the fused store loops still lose on these HBM-bound layers: RektNet 31.99k -> 31.34k img/s, YOLOv3 2136 -> 2118
     # with the limit lifted (same-box A/B).
-    fuse_max_rows = int(os.environ.get("MDCV_BN_FUSE_MAXROWS", "4096"))
+    fuse_max_rows = 4096
 
     def _fuse_pays(self, geom):
-        """Per-geometry choice between the fused sums and the stand-alone reduce pass (MDCV_BN_FUSE_SKIP = bit mask of the classes
+        """Per-geometry choice between the fused sums and the stand-alone reduce pass (Plan.fuse_skip = bit mask of the classes
         that keep the stand-alone pass; 0: fuse every eligible data gradient).  The fused store loop runs at the END of every tile;
         when the launch is a single round of workgroups over a large dx tensor nothing hides it and the stand-alone pass (full HBM
         rate) wins.  Classes by pixels of dx (yolo_baseline 416^2 at batch 32 in brackets), chosen by same-box A/B of the whole

@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..engine import TNode, ConvSpec, BnSpec, parse_precision, ACT_RELU, BF16
-from ..yolo.models import _NetPlan, FlatParamsMixin, _bump_counters, _sync_before_state_dict
+from ..yolo.models import _NetPlan, FlatParamsMixin, _bump_counters, _sync_before_state_dict, _EVAL_FUSE
 from .resnet import ResNet, lower_conv_bn, lower_block, lower_block_bwd
 
 
@@ -146,7 +146,7 @@ class KeypointNet(FlatParamsMixin, nn.Module):
         plan.pre.append(plan.fwd.pop())
         plan.in_holder = holder
         plan.x16 = None
-        if os.environ.get("MDCV_STEM16", "1") == "1" and bn_train and not logits_only and plan.dtype == BF16 and self.conv.kernel_size == (7, 7) and self.conv.padding == (3, 3) \
+        if bn_train and not logits_only and plan.dtype == BF16 and self.conv.kernel_size == (7, 7) and self.conv.padding == (3, 3) \
                 and self.conv.out_channels == 16:
             # second copy of the input with 16-channel rows: the stem's weight gradient runs the LDS-ring kernel on it (csrc/wgrad_stream.hip)
             x16 = plan.new_act(B, H, W, 16)
@@ -160,7 +160,7 @@ class KeypointNet(FlatParamsMixin, nn.Module):
         nbt = []
         recs = []
 
-        one_launch = infer and os.environ.get("MDCV_EVAL_FUSE", "1") == "1"
+        one_launch = infer and _EVAL_FUSE
 
         def conv_bn(conv, bn, xnode, relu_into=None):
             return lower_conv_bn(plan, conv, bn, xnode, B, H, W, bn_train, nbt, one_launch, relu_into=relu_into)
@@ -214,6 +214,5 @@ class KeypointNet(FlatParamsMixin, nn.Module):
                 dy0 = plan.emit_bn_act_bwd(a0.grad, y0, bs0, ACT_RELU, 0.0)
                 plan.emit_conv_bwd(cs0, xin_, y0, dy0, x_wgrad=plan.x16)
                 plan.emit_bias_grad(cs0, None, zero_only=True)
-        plan.flush_wgrad_batches()
         plan.mark_ready()
         return plan

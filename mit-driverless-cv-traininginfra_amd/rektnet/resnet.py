@@ -169,7 +169,6 @@ class ResNet(FlatParamsMixin, nn.Module):
         dout_in.__name__ = "nchw_to_nhwc"
         plan.bwd.append((dout_in, ()))
         lower_block_bwd(plan, rec)
-        plan.flush_wgrad_batches()
         plan.mark_ready()
         if need_dx:
             plan.dx_nchw = torch.empty(B, self.in_channels, H, W, dtype=torch.float32, device=device)

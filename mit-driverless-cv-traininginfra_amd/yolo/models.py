@@ -205,8 +205,7 @@ class _DarknetTrainFn(torch.autograd.Function):
         return (None, None, None, None) + (None,) * len(model._plist)
 
 
-_TAIL_PROBE = os.environ.get("MDCV_TAIL_PROBE", "0") == "1"
-_CHECK_TARGETS = os.environ.get("MDCV_CHECK_TARGETS", "1") == "1"
+_CHECK_TARGETS = True       # (module attribute: tests may switch the one-step-late label check off)
 _BAD_TARGET_MSG = ("index out of range in build_targets: a target has cx >= 1.0 or cy >= 1.0 (grid cell == grid size), where the reference "
                    "raises IndexError at utils/utils.py:262")
 
@@ -216,7 +215,7 @@ def _head_err_view(ws, B, A, Gh, Gw):
     return ws.view(torch.int32)[B * A * Gh * Gw + Gh * Gw:B * A * Gh * Gw + Gh * Gw + 1]
 
 
-_EVAL_FUSE = os.environ.get("MDCV_EVAL_FUSE", "1") == "1"     # inference: conv + BatchNorm(running stats) + activation in one launch
+_EVAL_FUSE = True           # inference: conv + BatchNorm(running stats) + activation in one launch (module attribute; False: two-pass plans)
 
 
 class _NetPlan(Plan):
@@ -287,13 +286,7 @@ class _NetPlan(Plan):
 
     def side(self):
         if getattr(self, "_side", None) is None:
-            prio = int(os.environ.get("MDCV_WGRAD_PRIO", "0"))       # 0 = same as the main stream ; 1 = lowest the device offers
-            if prio:
-                with torch.cuda.device(self.device):
-                    lo = torch.cuda.Stream.priority_range()[0]        # (least, greatest): the least priority is the larger number
-                self._side = torch.cuda.Stream(device=self.device, priority=lo)
-            else:
-                self._side = torch.cuda.Stream(device=self.device)
+            self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
     def run_bwd_list(self):
@@ -315,10 +308,6 @@ class _NetPlan(Plan):
             if rc:
                 raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
         if used:
-            if _TAIL_PROBE:                                  # how long the side stream runs on after the main stream's last backward kernel
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(cur); e1.record(side)
-                self.__dict__.setdefault("tail_events", []).append((e0, e1))
             cur.wait_stream(side)
 
     def run_backward(self, gout):
@@ -869,7 +858,6 @@ class Darknet(FlatParamsMixin, nn.Module):
                         continue
                     for sn, off in parts:
                         plan.grad_identity(sn, z.grad.slice(off, sn.act.C))
-            plan.flush_wgrad_batches()
             plan.mark_ready()
         plan.outs = outs
         return plan

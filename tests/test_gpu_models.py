@@ -617,7 +617,7 @@ def test_hipgraph_replay_matches_eager():
 
 def test_mini_darknet_with_fused_bn_backward_sums(monkeypatch):
     """BatchNorm-backward sums folded into the data-gradient store loops (bf16 only, default on) vs the two-pass form
-    (MDCV_BN_FUSE=0): same losses, gradients equal up to the order of the fp32 partial sums."""
+    (engine.Plan.fuse_bn = False): same losses, gradients equal up to the order of the fp32 partial sums."""
     from mdcv import engine
     z = load("mini_darknet.npz")
     outs = {}

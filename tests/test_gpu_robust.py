@@ -276,50 +276,6 @@ def test_standalone_resnet_block_vs_torch_fp32(cin, cout):
         check(ev, _ref_block(x, {k: v.detach() for k, v in blk.cpu().state_dict().items()}, False), "eval out")
 
 
-def test_layer_batched_weight_gradients_in_the_plan(tmp_path, monkeypatch):
-    """MDCV_WGRAD_BATCH > 1: consecutive same-geometry 3x3 layers of a Darknet stage launch their weight gradients as one batch.  The
-    gradients equal the one-launch-per-layer plan's (other pixel splits: fp32 sums in another order), the data-parallel markers never
-    announce a gradient that still waits in an open batch, and every parameter gradient is written exactly once."""
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
-    from mdcv import engine
-    from mdcv.yolo.models import Darknet
-    from mdcv.parallel import GradAllReducer
-    cfg = bench.write_yolo_cfg(str(tmp_path), classes=1)
-    g = torch.Generator().manual_seed(3)
-    x = torch.rand(4, 3, 416, 416, generator=g).cuda()
-    tg = bench.synth_targets(4, 8, g).cuda()
-    grads, sizes = {}, {}
-    for batch in (1, 4):
-        monkeypatch.setattr(engine.Plan, "wgrad_batch", batch)
-        cwd = os.getcwd()
-        os.chdir(tmp_path)
-        try:
-            torch.manual_seed(0)
-            net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
-        finally:
-            os.chdir(cwd)
-        calls = []
-        red = GradAllReducer.attach(net, bucket_mb=8.0, allreduce_fn=lambda t: calls.append((t.data_ptr(), t.numel())))
-        out = net(x, tg)
-        out[0].sum().backward()
-        red.finish()
-        torch.cuda.synchronize()
-        plan = [p for p in net._plans.values() if p.has_bwd][0]
-        sizes[batch] = list(plan.wgrad_batches)
-        grads[batch] = net.flat_parameters()[1].clone()
-        base = net.flat_parameters()[1].data_ptr()
-        segs = sorted(((p - base) // 4, (p - base) // 4 + n) for p, n in calls)
-        assert segs[0][0] == 0 and segs[-1][1] == grads[batch].numel() and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
-        del net
-        torch.cuda.empty_cache()
-    assert sizes[1] == [] and len(sizes[4]) >= 6 and max(sizes[4]) == 4 and sum(sizes[4]) == 31      # the 31 wide 3x3 stride-1 layers (52^2, 26^2, 13^2 and the two 104^2 64->128)
-    a, b = grads[1].double(), grads[4].double()
-    assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max())
-    assert float((a @ b) / (a.norm() * b.norm())) > 0.999999
-
-
 def test_resnet_block_refuses_what_it_cannot_differentiate_or_would_break():
     """Stand-alone ResNet block: eval mode with gradients enabled has no backward on the HIP path (refuse, do not return a graph-less
     tensor); a block that lives inside a flattened KeypointNet must not re-flatten its parameters out of the parent."""
