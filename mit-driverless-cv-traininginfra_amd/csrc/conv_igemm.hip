@@ -34,6 +34,7 @@ struct ConvArgs {
   int KH, KW, stride, pad, dil;
   int M, Ktot, tiles_n, sshift, tiles_total, xcd_chunk;
   int ph, pw, Hs, Ws, kh0, kw0, nkh, nkw;     // MODE 2 (stride-2 data gradient, one output-parity class per launch)
+  int cls_split;                              // ALLCLS: 1 = two workgroups per tile, the 4-tap class and the 1+2+2-tap classes (sparse grids)
   BnFuseArgs fuse;                            // BatchNorm-backward sums folded into the store loop of a data gradient (fuse.y == NULL: off)
   EpiArgs epi;                                // inference epilogue act(acc * oscale + bias) (oscale == NULL and act == 0: off)
 };
@@ -53,6 +54,8 @@ int g_conv_variant = -1;   // -1: heuristic ; >= 0: forced tile configuration fo
 int g_conv_tall_s2 = 1;      // (set_variant 18 = off; +0.3 % on the YOLOv3 step) the tall narrow tiles for the parity-class launches too
 int g_conv_deep_s2 = 1;      // (set_variant 20 = off; +0.6 % on the YOLOv3 step, same-box A/B) 3-stage ring for the parity-class launches of the stride-2 data gradients
 int g_conv_s2_allcls = 1;    // (set_variant 16 = off) one launch for the four parity classes of a stride-2 data gradient (conv_glds_kernel ALLCLS)
+int g_conv_s2_split = 512;   // ALLCLS grids below this many 128 x 128 tiles run two workgroups per tile (set_variant 4000 + n; 26->52 and 13->26 at batch 32)
+int g_conv_s2_split_on = 1;  // (set_variant 14 = off: those layers go back to four class launches; 15 = on)
 #else
 extern int g_conv_no_ut;
 extern int g_conv_tall_narrow;
@@ -63,6 +66,8 @@ extern int g_conv_variant;
 extern int g_conv_tall_s2;
 extern int g_conv_deep_s2;
 extern int g_conv_s2_allcls;
+extern int g_conv_s2_split;
+extern int g_conv_s2_split_on;
 #endif
 // the per-part dispatch entry points (each defined by exactly one part)
 int mdcv_cd_bf16_fwd(const ConvArgs& a, hipStream_t st, int B);
@@ -431,14 +436,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a0, un
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = logical / a0.tiles_n, tile_n = logical % a0.tiles_n;
+  // ALLCLS with cls_split: the tile's work is cut into two workgroups of 4 and 5 tap-GEMMs -- class (1,1) alone and classes (0,0), (0,1),
+  // (1,0) -- that sit next to each other in the launch order (same XCD: the dY rows they both read meet in its L2).  The 26->52 and
+  // 13->26 layers at batch 32 give only 338 / 172 tiles of 128 x 128: one workgroup per tile walked its nine tap-GEMMs on a
+  // half-empty chip, four class launches did the same one class at a time.
+  int tile_id = logical, cls_lo = 0, cls_hi = ALLCLS ? 4 : 1;
+  if constexpr (ALLCLS) {
+    if (a0.cls_split) { tile_id = logical >> 1; if (logical & 1) cls_hi = 3; else cls_lo = 3; }
+  }
+  const int tile_m = tile_id / a0.tiles_n, tile_n = tile_id % a0.tiles_n;
   const int lrow = lane >> 2;                              // row inside a chunk this lane fills
   const int kv = (lane & 3) ^ swz(lrow);                   // logical k-vector it fetches for that slot
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a0.in), 0, in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a0.w), 0, w_bytes, 0x00020000);
-  constexpr int NCLS = ALLCLS ? 4 : 1;
 #pragma unroll 1
-  for (int cls = 0; cls < NCLS; ++cls) {
+  for (int cls = cls_lo; cls < cls_hi; ++cls) {
   ConvArgs a = a0;
   if constexpr (ALLCLS) {                                  // class (ph, pw): its live taps kh = kh0 + 2i, kw = kw0 + 2j (see conv2d_impl)
     a.ph = cls >> 1; a.pw = cls & 1;
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a0, un
     a.nkh = (a.KH - a.kh0 + 1) / 2; a.nkw = (a.KW - a.kw0 + 1) / 2;
     a.Ktot = a.nkh * a.nkw * a.Cin;
     a.fuse.row_base = cls * ((a.M + 127) >> 7);
-    if (cls) __syncthreads();                              // the previous class's epilogue is done with the LDS
+    if (cls != cls_lo) __syncthreads();                    // the previous class's epilogue is done with the LDS
   }
 
   int bh[NPA], bw[NPA], ib[NPA];
@@ -830,7 +842,7 @@ int launch_conv_glds_f(const ConvArgs& a0, hipStream_t st, int B) {
     attr_set = true;
   }
   a.tiles_n = cdiv(a.Nout, BN);
-  a.tiles_total = cdiv(a.M, BM) * a.tiles_n;
+  a.tiles_total = cdiv(a.M, BM) * a.tiles_n * ((ALLCLS && a.cls_split) ? 2 : 1);
   a.xcd_chunk = cdiv(a.tiles_total, 8);
   const unsigned in_bytes = (unsigned)((long long)B * a.Hin * a.Win * a.in_ldc * (long long)sizeof(T));
   const unsigned w_bytes = (unsigned)((long long)a.Nout * a.KH * a.KW * a.Cin * (long long)sizeof(T));
@@ -934,7 +946,13 @@ static int dispatch_dgrad_s2_all(const ConvArgs& a, hipStream_t st, int B) {
   // Measured per layer of yolo_baseline at batch 32 (one launch vs four): 208->416 279 -> 204 us, 104->208 139 -> 125, 52->104 98 -> 86, but
   // 26->52 (338 tiles of 128 x 128: one sparse round of long workgroups) 136 -> 183 and 13->26 140 -> 139: only grids of >= 512 tiles take it.
   const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
-  if (a.Nout <= 64 || t128 < 512) return MDCV_EARG;
+  if (a.Nout <= 64) return MDCV_EARG;
+  if (t128 < g_conv_s2_split) {                    // sparse grids: two workgroups per tile (4 + 5 tap-GEMMs), see conv_glds_kernel
+    if (!g_conv_s2_split_on) return MDCV_EARG;
+    ConvArgs c = a;
+    c.cls_split = 1;
+    return launch_conv_glds<T, 2, 128, 128, 2, 2, 3, true>(c, st, B);
+  }
   if (t128 >= 1024) return launch_conv_glds<T, 2, 256, 128, 4, 2, 3, true>(a, st, B);
   return launch_conv_glds<T, 2, 128, 128, 2, 2, 3, true>(a, st, B);
 }
@@ -1809,7 +1827,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Nout = Nout;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin; a.tiles_n = 0; a.sshift = stride == 2 ? 1 : 0; a.tiles_total = 0; a.xcd_chunk = 0;
-  a.ph = a.pw = a.kh0 = a.kw0 = 0; a.Hs = Hout; a.Ws = Wout; a.nkh = KH; a.nkw = KW;
+  a.ph = a.pw = a.kh0 = a.kw0 = 0; a.Hs = Hout; a.Ws = Wout; a.nkh = KH; a.nkw = KW; a.cls_split = 0;
   a.fuse = fuse ? *fuse : BnFuseArgs{};
   a.epi = epi ? *epi : EpiArgs{nullptr, 0, 0.f};
   if (a.M <= 0) return MDCV_OK;
@@ -1948,6 +1966,7 @@ int mdcv_conv2d_wgrad_set_variant(int v) {   /* tuning hook; 1000 + 100*d + bloc
 int mdcv_conv2d_set_variant(int v) {
   // tuning / A-B hook of the conv family (tests walk the tile variants; scripts/ab_env.sh runs whole steps under a setting).  -1: heuristics.
   //   0..11  forced tile configuration of wide layers (0-5 register-staged kernels, 6-11 LDS-DMA: 128x128 / 128x64 / 256x128 x 2 / 3 stages); 100 + v: generic address path
+  //   14/15  sparse stride-2 data gradients: four class launches / one launch with two workgroups per tile     4000+n  'sparse' = below n tiles
   //   16/17  stride-2 data gradient as four parity-class launches / one launch        18/19, 20/21  its tall tiles, its 3-stage ring off / on
   //   30+n   3-stage ring for 33..64-channel layers from n K steps (30 never)           60+n  the same for 128x128 / 128x64 tiles (60 never)
   //   92/93  128x64 tiles for fused 1x1 data gradients off / on                         2000+n  256-row tiles for Nout <= 64 from n Ki positions (2000 off)
@@ -1958,6 +1977,8 @@ int mdcv_conv2d_set_variant(int v) {
   if (v >= 30 && v < 60) { g_conv_deep_narrow = v - 30; return MDCV_OK; }
   if (v == 20 || v == 21) { g_conv_deep_s2 = v - 20; return MDCV_OK; }
   if (v == 16 || v == 17) { g_conv_s2_allcls = v - 16; return MDCV_OK; }
+  if (v == 14 || v == 15) { g_conv_s2_split_on = v - 14; return MDCV_OK; }
+  if (v >= 4000 && v < 6000) { g_conv_s2_split = v - 4000; return MDCV_OK; }
   if (v == 18 || v == 19) { g_conv_tall_s2 = v - 18; return MDCV_OK; }
   if (v >= 2000 && v < 3000) { g_conv_tall_narrow = v - 2000; return MDCV_OK; }
   if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path

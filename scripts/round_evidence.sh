@@ -13,7 +13,8 @@ bash scripts/profile_round.sh $TAG rektnet > /dev/null 2>&1
 cd $R
 cp $OUT/${TAG}_*.csv $OUT/${TAG}_pmc_*.json $OUT/${TAG}_*_under_rocprof.json $R/profiles/ 2>/dev/null   # bench.py quotes traffic / *_in_step from profiles/ when the fingerprint matches
 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
-python bench.py --workload joint --no-cpu-baseline > $OUT/${TAG}_joint_bench.json 2> $OUT/joint.err
+cp $R/gpurun_out/bench_detail.json $OUT/${TAG}_bench_detail.json 2>/dev/null    # per-kernel tables of that run (the stdout line stays < 3.5 KB)
+python bench.py --workload joint > $OUT/${TAG}_joint_bench.json 2> $OUT/joint.err
 python bench.py --workload yolo --no-cpu-baseline --no-fp32 --dump-launches $OUT/yolo_launches.json > /dev/null 2>&1 && python scripts/layer_table.py $OUT/yolo_launches.json > $OUT/${TAG}_yolo_conv_launch_table.txt
 python bench.py --workload rektnet --no-cpu-baseline --no-fp32 --dump-launches $OUT/rektnet_launches.json > /dev/null 2>&1 && python scripts/layer_table.py $OUT/rektnet_launches.json > $OUT/${TAG}_rektnet_conv_launch_table.txt
 rm -f $OUT/*_launches.json
