@@ -8,7 +8,7 @@ L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 B = 32
 e0 = ctypes.c_void_p(); e1 = ctypes.c_void_p(); L.event_create(ctypes.byref(e0)); L.event_create(ctypes.byref(e1))
-NAMES = {-1: "auto", 6: "128x128/2", 9: "128x128/3", 12: "128x128/4", 7: "128x64/2", 10: "128x64/3", 14: "128x64/4", 8: "256x128/2", 11: "256x128/3", 13: "256x128/4"}
+NAMES = {-1: "auto", 6: "128x128/2", 9: "128x128/3", 7: "128x64/2", 10: "128x64/3", 8: "256x128/2", 11: "256x128/3"}
 for (H, Ci, Co) in [(52, 256, 128), (52, 128, 256), (26, 512, 256), (26, 256, 512), (13, 1024, 512), (13, 512, 1024), (104, 128, 64)]:
     xs = [torch.randn(B * H * H * Ci, device="cuda").to(torch.bfloat16) for _ in range(4)]
     ys = [torch.randn(B * H * H * Co, device="cuda").to(torch.bfloat16) for _ in range(4)]
