@@ -399,7 +399,9 @@ class Plan:
     # now that the weight gradients fill the MFMA pipe from the side stream and the main stream is what bounds the step.
     fuse_bn = True                     # (tests flip the class attribute; no environment knob)
 
-    fuse_skip = 13                     # bit mask of the geometry classes of _fuse_pays that keep the stand-alone reduce pass (0: fuse all)
+    fuse_skip = 141                    # bit mask of the geometry classes of _fuse_pays that keep the stand-alone reduce pass (0: fuse all);
+                                       # 128 (round 3): the sparse stride-2 data gradients 13->26 / 26->52, whose fused store loops ran once per parity
+                                       # class and cost 100 us against 20-28 us for the stand-alone pass (same-box A/B scripts/ab_fuse.py: -0.07 ms per step)
     # Data gradients whose fused sums would take more than this many partial rows (RektNet's 80^2 x 256 tensors: 12 800; YOLOv3's 208^2 / 416^2
     # layers) keep the stand-alone reduce pass.  The finalize can take them since round 2 (rows beyond 4096 are folded in place first,
     # csrc/elementwise.hip), but the fused store loops still lose on these HBM-bound layers: RektNet 31.99k -> 31.34k img/s, YOLOv3 2136 -> 2118
@@ -431,6 +433,8 @@ class Plan:
                 return not (k & 64)
         if stride == 2 and 300000 <= px < 1000000:   # [52^2 -> 104^2]
             return not (k & 8)
+        if stride == 2 and px < 300000:              # [13^2 -> 26^2, 26^2 -> 52^2]
+            return not (k & 128)
         return True
 
     def _fuse_bn_sums(self, dout, y, bs, act, slope, dgamma, dbeta):
