@@ -43,6 +43,57 @@ def pad8(c):
     return (c + 7) // 8 * 8
 
 
+# One side stream per device, shared by every plan of every model, and CHECKED to run beside the stream it is used next to.  HIP multiplexes
+# its streams onto a few hardware queues (4 by default): a pool stream that lands on the queue of the current stream never overlaps with it.
+# Found in round 3 (scripts/bimodal_probe.py): identical models built one after another in one process took 14.5 ms per step -- or 17.0 ms, with
+# the per-kernel times of a SERIAL step, whenever their plan's fresh torch.cuda.Stream() shared the main stream's queue (about one model in
+# eight).  The check: two 1-block spin kernels of ~0.5 ms, one per stream; side by side they take one kernel's time, on one queue two.
+_SIDE_STREAMS = {}
+
+
+def _runs_beside(others, cand):
+    """True if a kernel on `cand` runs concurrently with a kernel on each stream of `others` (one at a time)."""
+    cycles = 1 << 20
+    for cur in others:
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(cur):
+            torch.cuda._sleep(cycles)                  # warm the kernel
+            cur.synchronize()
+            e0.record(cur)
+            torch.cuda._sleep(cycles)
+            e1.record(cur)                             # e0..e1: one spin kernel alone
+            cand.wait_stream(cur)
+            with torch.cuda.stream(cand):
+                torch.cuda._sleep(cycles)
+            torch.cuda._sleep(cycles)
+            cur.wait_stream(cand)
+            e2.record(cur)                             # e1..e2: one on each stream
+        e2.synchronize()
+        if not e1.elapsed_time(e2) < 1.5 * e0.elapsed_time(e1):
+            return False
+    return True
+
+
+def checked_stream(device, beside, key):
+    """A stream of `device` that was CHECKED to run beside every stream in `beside`; cached per (device, key, those streams)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    k = (idx, key) + tuple(s.cuda_stream for s in beside)
+    s = _SIDE_STREAMS.get(k)
+    if s is None:
+        with torch.cuda.device(device):
+            for _ in range(16):                        # torch hands out its pool streams round-robin: a few tries walk the hardware queues
+                s = torch.cuda.Stream(device=device)
+                if _runs_beside(beside, s):
+                    break
+        _SIDE_STREAMS[k] = s
+    return s
+
+
+def side_stream(device):
+    """The device's side stream for work that runs BESIDE the current stream (weight gradients of a backward pass)."""
+    return checked_stream(device, [torch.cuda.current_stream(device)], "side")
+
+
 def parse_precision(p):
     if p in (BF16, "bf16", torch.bfloat16):
         return BF16
@@ -424,6 +475,8 @@ class Plan:
                 return not (k & 2)
             if px >= 300000:               # [104^2 3x3, 2 layers]
                 return not (k & 32)
+            if px < 20000:                 # [13^2 3x3, 8 layers]
+                return not (k & 256)
         if kh == 1:
             if px >= 300000:               # [104^2 1x1, 2 layers]
                 return not (k & 4)
@@ -431,6 +484,8 @@ class Plan:
                 return not (k & 16)
             if 20000 <= px < 50000:        # [26^2 1x1, 11 layers]
                 return not (k & 64)
+            if px < 20000:                 # [13^2 1x1, 8 layers]
+                return not (k & 512)
         if stride == 2 and 300000 <= px < 1000000:   # [52^2 -> 104^2]
             return not (k & 8)
         if stride == 2 and px < 300000:              # [13^2 -> 26^2, 26^2 -> 52^2]

@@ -70,7 +70,8 @@ class FusedAdam(_FlatOptimizer):
         model = self.model
         cur = torch.cuda.current_stream()
         if self._pstream is None:
-            self._pstream = torch.cuda.Stream(device=pflat.device)
+            from .engine import checked_stream
+            self._pstream = checked_stream(pflat.device, [cur], "param")      # (checked to run beside the current stream)
         ps = self._pstream
         ps.wait_stream(cur)                                  # gradients final (backward, side stream, all-reduce all joined `cur`)
         for pl in model._plans.values():

@@ -62,7 +62,8 @@ class GradAllReducer:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if flat.is_cuda:
             if self._stream is None:
-                self._stream = torch.cuda.Stream(device=flat.device)
+                from .engine import checked_stream
+                self._stream = checked_stream(flat.device, [torch.cuda.current_stream(flat.device)], "comm")
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
                 for b in self.buckets(flat):
@@ -90,7 +91,10 @@ class GradAllReducer:
         self.log = []
         self._ev_cur = [] if (self.timing and flat.is_cuda and self._active()) else None
         if self._active() and flat.is_cuda and self._stream is None:
-            self._stream = torch.cuda.Stream(device=flat.device)
+            # a stream that was checked to run beside the compute streams (HIP multiplexes streams onto a few hardware queues: a stream that
+            # shares the main stream's queue would serialise the exchange with backward; engine.checked_stream)
+            from .engine import checked_stream
+            self._stream = checked_stream(flat.device, [torch.cuda.current_stream(flat.device)] + list(self.extra_streams), "comm")
 
     def _fire(self, lo):
         """all-reduce [lo, pending_hi) on the comm stream, ordered after everything enqueued so far on the compute stream"""

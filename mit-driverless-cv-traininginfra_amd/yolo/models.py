@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from ..engine import Plan, TNode, ConvSpec, BnSpec, pad8, parse_precision, ACT_NONE, ACT_LEAKY, ACT_RELU
+from ..engine import Plan, TNode, ConvSpec, BnSpec, pad8, parse_precision, side_stream, ACT_NONE, ACT_LEAKY, ACT_RELU
 from .utils.parse_config import parse_model_config
 
 vanilla_anchor_list = [[10, 13], [16, 30], [33, 23], [30, 61], [62, 45], [59, 119], [116, 90], [156, 198], [373, 326]]
@@ -286,7 +286,7 @@ class _NetPlan(Plan):
 
     def side(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = side_stream(self.device)           # one per device, checked to overlap with the current stream (engine.side_stream)
         return self._side
 
     def run_bwd_list(self):
@@ -457,8 +457,8 @@ class FlatParamsMixin:
         overlap = red is not None and keep is None and not plan.use_graph
         plan.on_ready = red.on_ready if overlap else None
         if red is not None:
-            red.begin(self._gflat, overlap)
             red.extra_streams = [plan.side()] if (plan.overlap_wgrad and not plan.use_graph and self._gflat.is_cuda) else []
+            red.begin(self._gflat, overlap)
         plan.run_backward(gout)
         plan.on_ready = None
         if keep is not None:
