@@ -17,6 +17,12 @@ import sys
 import tempfile
 import time
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # Multi-rank runs add RCCL's stream (torch's ProcessGroupNCCL picks it) to the main, weight-gradient and comm streams.  HIP multiplexes
+    # streams onto 4 hardware queues by default and two streams on one queue run serially: give the runtime more queues
+    # BEFORE it initialises.  Stamped into the line (env_overrides).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -453,7 +459,7 @@ ROOFLINE_KEYS = ("kernel", "bound", "launches", "avg_us", "achieved", "peak", "u
 
 def live_env_overrides():
     """MDCV_* variables that change what the timed step launches; stamped into the line."""
-    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("MDCV_") and k not in ("MDCV_GRAPH", "MDCV_DIST_BACKEND")}
+    return {k: v for k, v in sorted(os.environ.items()) if (k.startswith("MDCV_") and k not in ("MDCV_GRAPH", "MDCV_DIST_BACKEND")) or k == "GPU_MAX_HW_QUEUES"}
 
 
 def build_line(a, world, primary, result, extra, cpu_baseline):
