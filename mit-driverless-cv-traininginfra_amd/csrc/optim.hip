@@ -2,6 +2,7 @@
 // Replaces torch.optim.Adam / SGD.step() as called from CVC-YOLOv3/train.py:180-187,72 and RektNet/train_eval.py:263,72
 // (222 / 54 small tensors per step in the reference -> one launch over the flat parameter buffer).
 // Update rules are torch's (Adam: bias-corrected, eps added after sqrt(v_hat); SGD: momentum buffer, dampening 0).
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -91,6 +92,33 @@ int mdcv_event_record(void* ev, void* stream) { return (int)hipEventRecord((hipE
 int mdcv_event_sync(void* ev) { return (int)hipEventSynchronize((hipEvent_t)ev); }
 int mdcv_event_elapsed_ms(void* start, void* stop, float* ms) { return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop); }
 int mdcv_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+
+// Cross-stream ordering inside one device: everything enqueued on `from` so far happens before what is enqueued on `to` afterwards.
+// One event record + one stream wait, on events of a per-device ring created WITHOUT timing and (device_scope != 0) with
+// hipEventReleaseToDevice: the default event releases to SYSTEM scope, which a consumer kernel on the same GPU does not need.
+// Re-recording a ring event is legal once its wait is enqueued (the wait captured the record it saw).
+int mdcv_stream_fork(void* from, void* to, int device_scope) {
+  constexpr int RING = 64, MAXDEV = 16;
+  static hipEvent_t ring[MAXDEV][2][RING];
+  static unsigned head[MAXDEV][2];
+  static std::mutex mu;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= MAXDEV) return MDCV_EARG;
+  const int sc = device_scope ? 1 : 0;
+  hipEvent_t ev;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    const unsigned i = head[dev][sc]++ % RING;
+    if (!ring[dev][sc][i]) {
+      e = hipEventCreateWithFlags(&ring[dev][sc][i], hipEventDisableTiming | (sc ? hipEventReleaseToDevice : 0u));
+      if (e != hipSuccess) { ring[dev][sc][i] = nullptr; return (int)e; }
+    }
+    ev = ring[dev][sc][i];
+  }
+  e = hipEventRecord(ev, (hipStream_t)from); if (e != hipSuccess) return (int)e;
+  return (int)hipStreamWaitEvent((hipStream_t)to, ev, 0);
+}
 
 // hipGraph capture of a launch sequence issued through this library on `stream`
 int mdcv_graph_begin(void* stream) { return (int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal); }

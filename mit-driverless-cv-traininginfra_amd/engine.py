@@ -240,10 +240,14 @@ class Plan:
         ready.__name__ = "grad_ready"
         self.bwd.append((ready, ()))
 
-    def wgrad_ws(self):
-        if self._ws is None or self._ws.numel() < self.ws_floats:
-            self._ws = _alloc(max(self.ws_floats, 1), torch.float32, self.device, False, self)
-        return self._ws
+    def wgrad_ws(self, stream=0):
+        """The split-K slab scratch of the weight gradients launched on `stream` (kernels of one stream run in order and may share it)."""
+        if self._ws is None:
+            self._ws = {}
+        w = self._ws.get(stream)
+        if w is None or w.numel() < self.ws_floats:
+            w = self._ws[stream] = _alloc(max(self.ws_floats, 1), torch.float32, self.device, False, self)
+        return w
 
     # ------------------------------------------------------------------ launch lists
     def call(self, lst, fn, *args):
@@ -348,7 +352,7 @@ class Plan:
         plan = self
 
         def wgrad(stream, cs=cs, x=xw, dy=dy, gw=gw, splits=splits, cin_w=cin_w):
-            return L.conv2d_wgrad(dt, dy.ptr, dy.ldc, x.ptr, x.ldc, plan.wgrad_ws().data_ptr(), splits, gw.data_ptr(), 0,
+            return L.conv2d_wgrad(dt, dy.ptr, dy.ldc, x.ptr, x.ldc, plan.wgrad_ws(stream).data_ptr(), splits, gw.data_ptr(), 0,
                                   x.B, x.H, x.W, cin_w, cs.cin, dy.H, dy.W, cs.cout_pad, cs.cout, cs.kh, cs.kw,
                                   cs.stride, cs.pad, cs.dil, stream)
         wgrad.__name__ = "conv2d_wgrad"

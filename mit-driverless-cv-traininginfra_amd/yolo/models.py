@@ -297,10 +297,10 @@ class _NetPlan(Plan):
             return
         side = self.side()
         st, ss = cur.cuda_stream, side.cuda_stream
-        used = False
+        fork, used = self.L.stream_fork, False                 # (one ring event, device-scope release; torch's wait_stream builds an Event per call)
         for fn, args in self.bwd:
             if getattr(fn, "__name__", "") == "conv2d_wgrad":
-                side.wait_stream(cur)
+                self.L.check(fork(st, ss, 1), "stream_fork")     # side waits for "dY(L), X(L) ready"
                 rc = fn(*args, ss)
                 used = True
             else:
@@ -308,7 +308,7 @@ class _NetPlan(Plan):
             if rc:
                 raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
         if used:
-            cur.wait_stream(side)
+            self.L.check(fork(ss, st, 1), "stream_fork")         # main waits for "all gradients done"
 
     def run_backward(self, gout):
         self.gscale.copy_(gout.reshape(-1)[:self.gscale.numel()], non_blocking=True)

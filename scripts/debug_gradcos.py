@@ -1,5 +1,6 @@
-"""Debug: per-layer cosine between the HIP path's weight gradients and the CPU oracle's, full YOLOv3 (batch from argv), bf16 and fp32."""
-import os, sys, tempfile, torch
+"""Per-layer cosine between the HIP path's weight gradients and the CPU oracle's (fp32), full YOLOv3 (batch from argv), bf16 and fp32, next to
+the same cosine of the reference arithmetic under torch.autocast(bfloat16) (tests/golden/yolo_autocast_bf16_cos.json, batch 32)."""
+import json, os, sys, tempfile, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
@@ -16,6 +17,7 @@ x = torch.rand(B, 3, 416, 416, generator=g); tg = bench.synth_targets(B, 16, g)
 torch.set_num_threads(min(os.cpu_count() or 1, 32))
 for k in orc.trainable(): orc.params[k].requires_grad_(True)
 ref = orc.forward(x, tg); ref[0].sum().backward()
+golden = json.load(open(os.path.join(ROOT, "tests", "golden", "yolo_autocast_bf16_cos.json")))["cos"]
 for prec in precs:
     os.chdir(tmp); net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision=prec); os.chdir(cwd)
     sd = net.state_dict()
@@ -32,4 +34,4 @@ for prec in precs:
             i = n.split(".")[1]
             a = p.grad.detach().cpu().double().reshape(-1); b = orc.params[f"conv{i}.weight"].grad.double().reshape(-1)
             cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
-            print("  layer %3s %-22s cos %.4f  |g| %.3e ref %.3e" % (i, tuple(p.shape), cos, float(a.norm()), float(b.norm())))
+            print("  layer %3s %-22s cos %.4f  (reference under autocast: %.4f)  |g| %.3e ref %.3e" % (i, tuple(p.shape), cos, golden.get(f"conv{i}.weight", float("nan")), float(a.norm()), float(b.norm())))

@@ -707,8 +707,9 @@ def test_pipelined_adam_is_bit_identical_mini_darknet():
 @pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 5e-3)])
 def test_full_yolov3_batch32_train_forward_backward_vs_oracle(precision, tol, tmp_path):
     """BASELINE config 3 at its real size (yolo_baseline 416x416, classes=80, batch 32) against the CPU oracle on the same seeded
-    weights, inputs and targets: total loss within the SURVEY 8d tolerance, the six parts within 10 %, the gradients of the first,
-    a middle and the last conv aligned (cosine), BatchNorm running statistics of the first layer equal."""
+    weights, inputs and targets: total loss within the SURVEY 8d tolerance, the six parts within 10 %, EVERY conv weight gradient aligned
+    (fp32: cosine > 0.999; bf16: at least as well as the reference's own ops under torch.autocast(bfloat16) are, layer by layer, and
+    > 0.999 at the head convs), gradient norms within 10 %, BatchNorm running statistics of the first layer equal."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -748,19 +749,29 @@ def test_full_yolov3_batch32_train_forward_backward_vs_oracle(precision, tol, tm
     assert abs(got[0] - exp[0]) <= tol * abs(exp[0]), (got, exp)
     np.testing.assert_allclose(got[1:], exp[1:], rtol=0.1 if precision == "bf16" else 1e-3)
     named = dict(net.named_parameters())
-    # fp32 kernels: every gradient aligned.  bf16: the no-object term pushes every confidence logit the same way, BatchNorm backward
-    # projects that (large) uniform component out again, so the rounding of the stored activation gradients (2^-9 of the large part)
-    # is a growing share of what is left: cosine 0.9999 at the heads decays layer by layer (scripts/debug_gradcos.py: 0.96 one block
-    # below a head, ~0.5 at layer 0) while the gradient NORMS stay within a few percent -- checked here.
-    for i in (0, 37, 105):
+    # fp32 kernels: every gradient aligned.  bf16: bf16 activations through 75 layers move the deep feature maps by a few percent, and the
+    # gradient of a random-init YOLOv3 is that sensitive: the REFERENCE's own torch ops under torch.autocast(bfloat16) lose the same
+    # direction layer by layer (0.9995 at the head convs, 0.88 one block below, ~0.5 at conv 0 -- tests/golden/yolo_autocast_bf16_cos.json,
+    # generated by scripts/ref_autocast_cos.py on these very weights / batch / targets).  The bar for the bf16 mode is that curve: no conv
+    # layer may be more than 0.02 worse aligned with the fp32 gradient than the reference under autocast is; norms within 10 %.
+    import json
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yolo_autocast_bf16_cos.json")))
+    assert golden["batch"] == B and golden["size"] == 416
+    worst = (0.0, None)
+    for name, gcos in golden["cos"].items():
+        i = int(name[4:].split(".")[0])
         a = named[f"module_list.{i}.conv_{i}.weight"].grad.detach().cpu().double().reshape(-1)
         b = orc.params[f"conv{i}.weight"].grad.double().reshape(-1)
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
-        if precision == "fp32" or i == 105:
+        if precision == "fp32":
             assert cos > 0.999, (i, cos)
         else:
-            assert cos > 0.3, (i, cos)
+            if gcos - cos > worst[0]:
+                worst = (gcos - cos, (i, cos, gcos))
+            if i in (81, 93, 105):
+                assert cos > 0.999, (i, cos)
         assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.1, (i, float(a.norm()), float(b.norm()))
+    assert worst[0] <= 0.02, worst
     rm = net.state_dict()["module_list.0.batch_norm_0.running_mean"].cpu().numpy()
     np.testing.assert_allclose(rm, orc.params["bn0.running_mean"].detach().numpy(), rtol=0, atol=2e-3 if precision == "bf16" else 1e-5)
 
