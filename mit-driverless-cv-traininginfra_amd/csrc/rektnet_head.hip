@@ -234,12 +234,13 @@ int mdcv_softargmax_bwd(int dtype, const float* hm, const float* pts, const floa
 }
 
 // CrossRatioLoss forward + gradients in one call.  loss_type: 0 l2_softargmax, 1 l2_heatmap, 2 l1_softargmax.
-// out3 = (location, geo, total) ; dpts [B,7,2] ; dhm [B,7,H,W] (l2_heatmap only) ; acc_ws: one zero-initialised double.
+// out3 = (location, geo, total) ; dpts [B,7,2] ; dhm [B,7,H,W] (l2_heatmap only) ; acc_ws: one zero-initialised double (l2_heatmap only,
+// may be NULL otherwise).
 // gscale (device, 2 floats, may be NULL = ones): upstream gradients of the location part and of the geo part.
 int mdcv_cross_ratio_loss(const float* hm, const float* pts, const float* thm, const float* tpts, int B, int H, int W, int loss_type,
                           int include_geo, float gamma_horz, float gamma_vert, double* acc_ws, const float* gscale, float* out3,
                           float* dpts, float* dhm, void* stream) {
-  if (!pts || !tpts || !out3 || !acc_ws || loss_type < 0 || loss_type > 2) return MDCV_EARG;
+  if (!pts || !tpts || !out3 || loss_type < 0 || loss_type > 2 || (loss_type == 1 && !acc_ws)) return MDCV_EARG;
   hipStream_t st = (hipStream_t)stream;
   if (loss_type == 1) {
     if (!hm || !thm) return MDCV_EARG;

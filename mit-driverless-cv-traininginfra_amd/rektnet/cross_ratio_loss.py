@@ -30,29 +30,38 @@ class _CrossRatioFn(torch.autograd.Function):
             hm = heatmap.detach().float().contiguous()
             thm = target_hm.detach().to(device=dev, dtype=torch.float32).contiguous()
             H, W = hm.shape[2], hm.shape[3]
-        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        # (the double accumulator is only touched by the heat-map loss; three separate 0-dim outputs instead of one [3] tensor the caller
+        #  indexes: indexing costs a zeros + copy launch per use in autograd's select_backward, ~10 tiny launches per training step)
+        acc = torch.zeros(1, dtype=torch.float64, device=dev) if lt == 1 else None
         out3 = torch.empty(3, dtype=torch.float32, device=dev)
         L.check(L.cross_ratio_loss(hm.data_ptr() if hm is not None else None, pts.data_ptr(), thm.data_ptr() if thm is not None else None,
                                    tpts.data_ptr(), B, H, W, lt, int(bool(mod.include_geo)), float(mod.geo_loss_gamma_horz),
-                                   float(mod.geo_loss_gamma_vert), acc.data_ptr(), None, out3.data_ptr(), None, None, st), "cross_ratio_loss")
+                                   float(mod.geo_loss_gamma_vert), acc.data_ptr() if acc is not None else None, None, out3.data_ptr(), None, None,
+                                   st), "cross_ratio_loss")
         ctx.saved = (mod, hm, pts, thm, tpts, lt, acc, H, W)
-        return out3
+        ctx.set_materialize_grads(False)
+        return out3[0], out3[1], out3[2]
 
     @staticmethod
-    def backward(ctx, g3):
+    def backward(ctx, g_loc, g_geo, g_tot):
         L = _lib.lib()
         mod, hm, pts, thm, tpts, lt, acc, H, W = ctx.saved
         st = torch.cuda.current_stream().cuda_stream
         B = pts.shape[0]
-        g3 = g3.float()
-        gs = torch.stack((g3[0] + g3[2], g3[1] + g3[2])).contiguous()       # upstream grads of (location, geo)
+        # upstream gradients of the (location, geo) parts: total = location + geo
+        if g_loc is None and g_geo is None and g_tot is not None:
+            gs = g_tot.detach().float().reshape(1).expand(2).contiguous()       # the training loops backpropagate `total` only: one launch
+        else:
+            z = torch.zeros((), dtype=torch.float32, device=pts.device)
+            f = lambda g: z if g is None else g.detach().float().reshape(())    # noqa: E731
+            gs = torch.stack((f(g_loc) + f(g_tot), f(g_geo) + f(g_tot))).contiguous()
         dpts = torch.empty_like(pts)
         dhm = torch.empty_like(hm) if lt == 1 else None
         scratch = torch.empty(3, dtype=torch.float32, device=pts.device)
         L.check(L.cross_ratio_loss(hm.data_ptr() if hm is not None else None, pts.data_ptr(), thm.data_ptr() if thm is not None else None,
                                    tpts.data_ptr(), B, H, W, lt, int(bool(mod.include_geo)), float(mod.geo_loss_gamma_horz),
-                                   float(mod.geo_loss_gamma_vert), acc.data_ptr(), gs.data_ptr(), scratch.data_ptr(), dpts.data_ptr(),
-                                   dhm.data_ptr() if dhm is not None else None, st), "cross_ratio_loss(bwd)")
+                                   float(mod.geo_loss_gamma_vert), acc.data_ptr() if acc is not None else None, gs.data_ptr(), scratch.data_ptr(),
+                                   dpts.data_ptr(), dhm.data_ptr() if dhm is not None else None, st), "cross_ratio_loss(bwd)")
         return None, dhm, dpts, None, None
 
 
@@ -75,7 +84,6 @@ class CrossRatioLoss(nn.Module):
             raise ValueError(f"CrossRatioLoss (HIP) takes points / target_points of shape [B, 7, 2]; got {tuple(points.shape)} and "
                              f"{tuple(target_points.shape)}")
         _lib.require_gpu(points)
-        out3 = _CrossRatioFn.apply(self, heatmap, points, target_hm, target_points)
-        location_loss, total = out3[0], out3[2]
-        geo_loss = out3[1] if self.include_geo else torch.tensor(0)     # int64 CPU zero, like the reference (:59)
+        location_loss, geo, total = _CrossRatioFn.apply(self, heatmap, points, target_hm, target_points)
+        geo_loss = geo if self.include_geo else torch.tensor(0)         # int64 CPU zero, like the reference (:59)
         return location_loss, geo_loss, total

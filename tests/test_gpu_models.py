@@ -318,6 +318,27 @@ def test_cross_ratio_loss_all_variants():
         CrossRatioLoss("nonsense", True, 0.0, 0.0)(hm, T(z["pts"]).cuda(), thm, tpts)
 
 
+def test_cross_ratio_loss_parts_backpropagate_separately():
+    """The three returned losses are separate autograd outputs: a caller may backpropagate any mix of them (the reference's are three
+    tensors of one graph).  2*location + 3*geo + 0.5*total against the oracle's autograd on the same inputs, and location alone."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+    from oracle import rektnet_oracle as ro
+    z = load("cross_ratio.npz")
+    hm, thm, tpts = T(z["hm"]), T(z["thm"]), T(z["tpts"])
+    for lt in ("l2_softargmax", "l1_softargmax"):
+        for mix in ((2.0, 3.0, 0.5), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0)):
+            pr = T(z["pts"]).clone().requires_grad_(True)
+            rl, rg, rt = ro.cross_ratio_loss(hm, pr, thm, tpts, lt, True, 0.05, 0.07)
+            (mix[0] * rl + mix[1] * rg + mix[2] * rt).backward()
+            p = T(z["pts"]).cuda().requires_grad_(True)
+            loc, gl, tot = CrossRatioLoss(lt, True, 0.05, 0.07)(hm.cuda(), p, thm.cuda(), tpts.cuda())
+            terms = [m * v for m, v in zip(mix, (loc, gl, tot)) if m != 0.0]
+            sum(terms[1:], terms[0]).backward()
+            close(p.grad.cpu(), pr.grad, rtol=1e-4, atol=1e-7)
+
+
 # ------------------------------------------------------------------------------------------------ full-size structure
 def write_baseline_cfg(tmp, size, classes):
     """yolo_baseline topology written from the structure table, not from the reference file."""
