@@ -620,7 +620,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a0, un
     // steady state: every iteration issues exactly one tile, so the wait count is a constant and the body is ONE basic
     // block (no branches): the DMA address arithmetic can be scheduled into the issue gaps between the MFMAs.
     for (const int nmain = nk - (STAGES - 1); kt < nmain; ++kt) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD * (STAGES - 2)) : "memory");
+      // (lgkmcnt(0): this wave's fragment reads of the previous tile are DONE before anyone may refill that slot -- the compiler sinks a
+      //  tile's last MFMAs and their LDS waits below this barrier, and an LDS-DMA write is not ordered against queued ds_reads; conv_shift.hip)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GD * (STAGES - 2)) : "memory");
       __builtin_amdgcn_s_barrier();
       const unsigned char* sA = smem + slot * (BM + BN) * 64 + wm * TM * 64;
       const unsigned char* sB = smem + slot * (BM + BN) * 64 + BM * 64 + wn * TN * 64;
@@ -640,9 +642,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a0, un
     }
     for (; kt < nk; ++kt) {                              // drain: no more tiles to issue
       const int newer = nk - 1 - kt;                     // tiles issued after tile kt (<= STAGES - 2)
-      if (newer >= 2 && STAGES > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD * 2) : "memory");
-      else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GD) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (newer >= 2 && STAGES > 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GD * 2) : "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(GD) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       const unsigned char* sA = smem + slot * (BM + BN) * 64 + wm * TM * 64;
       const unsigned char* sB = smem + slot * (BM + BN) * 64 + BM * 64 + wn * TN * 64;
@@ -1791,6 +1793,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
     __syncthreads();
   }
 }
+
 
 #endif   // MDCV_CONV_PART == 0 (weight gradients, pack)
 }  // namespace

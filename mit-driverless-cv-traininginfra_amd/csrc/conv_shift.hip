@@ -82,6 +82,13 @@ __device__ long long g_shift_ts[4 * 512];
 #endif
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// The wait in front of a ring barrier also drains THIS wave's LDS reads (lgkmcnt(0)).  The compiler schedules the last MFMAs of a step --
+// and the s_waitcnt lgkmcnt that guards their operands -- BELOW the next step's barrier (register-only instructions are not ordered by
+// s_barrier or by an asm memory clobber), so a wave could sit behind the barrier with its last fragment reads still queued while another
+// wave's LDS-DMA already refilled that ring slot: ds_read / ds_write of different waves are served in issue order, an LDS-DMA write is not
+// ordered against them.  Seen as one wrong 16-column fragment of one wave about once per 2000 YOLOv3 steps, only with the weight-gradient
+// stream running beside the kernel (scripts/repro_probe.py).
+template <int N> __device__ __forceinline__ void wait_vm_reads_done() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
 }  // namespace
 
@@ -203,7 +210,13 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
         for (int tap = 0; tap < 9; ++tap) {
           const int rslot = (cc * 9 + tap) % BRING, wslot = (cc * 9 + tap + LA) % BRING;
           STS(0);
-          if (tap >= 1 && tap <= LA) wait_vm<LA - 1 + NPA>(); else wait_vm<LA - 1>();
+          // Every MFMA of the previous step is ISSUED before this barrier -- hence each fragment read it consumes has RETURNED (see
+          // wait_vm_reads_done above for why that matters; pinning the accumulators costs nothing measurable, draining lgkmcnt here +0.4 %).
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(acc[i][j]));
+          if (tap >= 1 && tap <= LA) wait_vm_reads_done<LA - 1 + NPA>(); else wait_vm_reads_done<LA - 1>();
           STS(1);
           __builtin_amdgcn_s_barrier();
           STS(2);

@@ -359,6 +359,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
   }
   int rho0 = a.hpad;
   for (int t = 0; t < nt; ++t) {
+    // lgkmcnt(0): the waves that run half a sub-step late carry fragment READS across this barrier (they multiply them behind it), and the
+    // DMA issued behind the barrier refills the dY stage -- and, when the ring has less than one step of slack, activation rows -- those
+    // reads come from.  ds_reads are served in issue order against other waves' ds_writes, not against an LDS-DMA write: the reads must have
+    // RETURNED before any wave passes the barrier (same hazard as in conv_shift.hip; scripts/check_ring_barriers.py checks the built code).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (its own statement: on every path to the barrier, whichever vmcnt wait is taken)
     if (issued - 1 - t >= D - 1 && D > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

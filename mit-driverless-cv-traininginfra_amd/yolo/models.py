@@ -283,6 +283,7 @@ class _NetPlan(Plan):
     # pooling), so the only ordering needed is "dY(L), X(L) ready" (side waits on main) and "all gradients done" (main waits on
     # side at the end; the data-parallel reducer's comm stream waits on both).
     overlap_wgrad = os.environ.get("MDCV_WGRAD_STREAM", "1") == "1"
+    fork_device_scope = 1
 
     def side(self):
         if getattr(self, "_side", None) is None:
@@ -300,7 +301,7 @@ class _NetPlan(Plan):
         fork, used = self.L.stream_fork, False                 # (one ring event, device-scope release; torch's wait_stream builds an Event per call)
         for fn, args in self.bwd:
             if getattr(fn, "__name__", "") == "conv2d_wgrad":
-                self.L.check(fork(st, ss, 1), "stream_fork")     # side waits for "dY(L), X(L) ready"
+                self.L.check(fork(st, ss, self.fork_device_scope), "stream_fork")     # side waits for "dY(L), X(L) ready"
                 rc = fn(*args, ss)
                 used = True
             else:
@@ -308,7 +309,7 @@ class _NetPlan(Plan):
             if rc:
                 raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
         if used:
-            self.L.check(fork(ss, st, 1), "stream_fork")         # main waits for "all gradients done"
+            self.L.check(fork(ss, st, self.fork_device_scope), "stream_fork")         # main waits for "all gradients done"
 
     def run_backward(self, gout):
         self.gscale.copy_(gout.reshape(-1)[:self.gscale.numel()], non_blocking=True)

@@ -1029,3 +1029,45 @@ def test_yolo_head_grad_tile_kernel_equals_scalar_kernel(dt, C, G):
         live[an * attrs:an * attrs + 5] = True
     assert float(a[..., ~live].abs().max()) == 0.0
     assert float(a[..., live].abs().max()) > 0.0
+
+
+def test_batched_pack_equals_the_single_layer_pack():
+    """mdcv_pack_weights_batched (one table-driven launch for all layers of a plan: every training step starts with it) against
+    mdcv_pack_weights layer by layer, bit for bit: 1x1 / 3x3 / 7x7 kernels, channel counts that are not multiples of 8 or 64, tiles that
+    straddle the channel padding, layers without a data-gradient operand, a bias copy, and parameters that sit at ODD float offsets of
+    one flat buffer (the flat parameter buffer of a model has no padding between tensors)."""
+    import struct
+    L = _lib.lib()
+    shapes = [(32, 3, 3, True, False), (255, 1024, 1, True, True), (64, 32, 3, True, False), (1024, 512, 3, True, False), (16, 3, 7, False, False),
+              (128, 384, 1, True, False), (72, 40, 3, True, False), (7, 64, 1, True, True), (256, 128, 3, True, False), (512, 1024, 1, True, False)]
+    g = torch.Generator().manual_seed(5)
+    total = sum(co * ci * k * k + (co if b else 0) for co, ci, k, d, b in shapes) + 1
+    flat = torch.randn(total, generator=g).cuda()
+    off = 1                                                   # (odd offset for the first layer; the 255- and 7-element biases shift later ones)
+    recs, outs, eq = [], [], 1
+    for co, ci, k, need_d, has_b in shapes:
+        n = co * ci * k * k
+        w = flat[off:off + n]; off += n
+        b = None
+        if has_b:
+            b = flat[off:off + co]; off += co
+        cop, cip, kk = pad8(co), pad8(ci), k * k
+        wf = torch.full((cop * kk * cip,), 7.0, dtype=torch.bfloat16, device="cuda")
+        wd = torch.full((cip * kk * cop,), 7.0, dtype=torch.bfloat16, device="cuda") if need_d else None
+        bp = torch.full((cop,), 7.0, device="cuda") if has_b else None
+        wf0, wd0 = torch.zeros_like(wf), (torch.zeros_like(wd) if need_d else None)
+        wc = w.clone()                                        # the single-layer reference reads an aligned copy
+        L.check(L.pack_weights(BF16, wc.data_ptr(), wf0.data_ptr(), wd0.data_ptr() if need_d else None, co, ci, k, k, cop, cip, st()))
+        recs.append(struct.pack("<QQQiiiiiiiiQQ", w.data_ptr(), wf.data_ptr(), wd.data_ptr() if need_d else 0, co, ci, kk, cop, cip, 0, 0, 0,
+                                b.data_ptr() if has_b else 0, bp.data_ptr() if has_b else 0))
+        outs.append((wf, wd, bp, wf0, wd0, b))
+        eq = max(eq, (min(64, cip) * kk + 63) // 64)
+    table = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8).cuda()
+    L.check(L.pack_weights_batched(BF16, table.data_ptr(), len(shapes), eq, st()))
+    torch.cuda.synchronize()
+    for (wf, wd, bp, wf0, wd0, b), shp in zip(outs, shapes):
+        assert torch.equal(wf.view(torch.int16), wf0.view(torch.int16)), shp
+        if wd is not None:
+            assert torch.equal(wd.view(torch.int16), wd0.view(torch.int16)), shp
+        if bp is not None:
+            assert torch.equal(bp[:shp[0]], b), shp

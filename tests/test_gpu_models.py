@@ -798,9 +798,12 @@ def test_full_yolov3_batch32_train_forward_backward_vs_oracle(precision, tol, tm
 
 
 def test_full_yolov3_training_is_bit_reproducible(tmp_path):
-    """Two model instances in one process, same seeds, three train steps of the full yolo_baseline (batch 32, bf16, weight gradients on
+    """Two model instances in one process, same seeds, 150 train steps of the full yolo_baseline (batch 32, bf16, weight gradients on
     the side stream, fused BatchNorm sums): identical losses and bit-identical parameters.  (No atomics on any data path; this is also
-    what exposed the out-of-bounds partial row in round 1: results depended on what the allocator had placed behind a buffer.)"""
+    what exposed the out-of-bounds partial row in round 1: results depended on what the allocator had placed behind a buffer.  Round 3
+    found a ring-slot race that diverged once per ~2000 steps -- far too rare for this test, which is why the ISA check
+    tests/test_host_logic.py::test_ring_kernels_drain_their_lds_reads_before_every_barrier and scripts/repro_probe.py exist -- but 150
+    steps at 14 ms cost nothing and catch anything that is merely unlikely.)"""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -822,12 +825,12 @@ def test_full_yolov3_training_is_bit_reproducible(tmp_path):
         tg = bench.synth_targets(32, 16, g).cuda()
         junk = torch.rand(1 << 20, device="cuda")                 # perturbs the allocator between instances
         losses = []
-        for _ in range(3):
+        for _ in range(150):
             opt.zero_grad()
             out = net(x, tg)
             out[0].sum().backward()
             opt.step()
-            losses.append(out[0].detach().clone())
+            losses.append(out[0].detach().sum())
         torch.cuda.synchronize()
         del junk
         return [float(v) for v in losses], net.flat_parameters()[0].clone()

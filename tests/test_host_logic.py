@@ -329,3 +329,24 @@ def test_autocast_gradient_curve_fixture_is_what_the_gpu_test_expects():
     for head in ("conv81.weight", "conv93.weight", "conv105.weight"):
         assert d["cos"][head] > 0.999
     assert d["cos"]["conv0.weight"] < 0.6 and abs(d["loss"]["bf16"] / d["loss"]["fp32"] - 1) < 5e-3
+
+
+def test_ring_kernels_drain_their_lds_reads_before_every_barrier():
+    """ISA check of the library as built (scripts/check_ring_barriers.py): in every gfx950 kernel that refills LDS with LDS-DMA, no path
+    reaches an s_barrier with ds_reads of the wave still queued.  A queued read behind the barrier races with another wave's DMA into
+    the slot it reads (an LDS-DMA write is not ordered against queued ds_reads), and the compiler moves a step's last MFMAs -- with the
+    s_waitcnt that guards their fragments -- below the next barrier unless the kernel pins them: round 3 found that as one wrong
+    16-column fragment per ~2000 YOLOv3 steps.  Needs only the built .so and llvm-objdump (no GPU)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "mit-driverless-cv-traininginfra_amd", "libmdcv_hip.so")
+    if not os.path.exists(lib):
+        sys.path.insert(0, root)
+        import __graft_entry__
+        __graft_entry__.build()
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump in this image")
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import check_ring_barriers
+    seen, bad = check_ring_barriers.check(lib)
+    assert seen >= 100, seen                              # the conv / shift / weight-gradient families are all LDS-DMA kernels
+    assert not bad, bad[:10]
