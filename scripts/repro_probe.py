@@ -1,6 +1,6 @@
 """Run-to-run reproducibility over MANY steps: two YOLOv3 models from the same seed take the same batches step by step; after every step the
 flat parameter buffers must be bit-identical.  Reports the first step at which they differ (a race shows up as a rare divergence that
-training then amplifies).  usage: repro_probe.py [steps=200] [fork_scope=1] [batch=32]"""
+training then amplifies).  usage: repro_probe.py [steps=200] [fork_scope=1] [batch=32] [yolo|rektnet]"""
 import os, sys, tempfile, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,21 +27,46 @@ def _new_act(self, *a, **k):
 
 
 _eng.Plan.new_act = _new_act
+NET = sys.argv[4] if len(sys.argv) > 4 else "yolo"
 nets, opts = [], []
-for i in range(2):
-    torch.manual_seed(0)
-    n = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
-    nets.append(n); opts.append(FusedAdam(n, lr=1e-3))
 g = torch.Generator().manual_seed(21)
-xs = [torch.rand(B, 3, 416, 416, generator=g).cuda() for _ in range(4)]
-tg = [bench.synth_targets(B, 16, g).cuda() for _ in range(4)]
+if NET == "yolo":
+    for i in range(2):
+        torch.manual_seed(0)
+        n = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
+        nets.append(n); opts.append(FusedAdam(n, lr=1e-3))
+    xs = [torch.rand(B, 3, 416, 416, generator=g).cuda() for _ in range(4)]
+    tg = [bench.synth_targets(B, 16, g).cuda() for _ in range(4)]
+
+    def one(n, o, s):
+        o.zero_grad()
+        out = n(xs[s % 4], tg[s % 4]); out[0].sum().backward(); o.step()
+        return float(out[0].detach().sum())
+else:
+    import contextlib
+    from mdcv.rektnet.keypoint_net import KeypointNet
+    from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+    for i in range(2):
+        torch.manual_seed(0)
+        n = KeypointNet(7, (80, 80), precision="bf16").cuda().train()
+        nets.append(n); opts.append(FusedAdam(n, lr=1e-2))
+    with contextlib.redirect_stdout(sys.stderr):
+        crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
+    xs = [torch.rand(B, 3, 80, 80, generator=g).cuda() for _ in range(4)]
+    tg = [(torch.rand(B, 7, 2, generator=g) * (79 / 80)).cuda() for _ in range(4)]
+
+    def one(n, o, s):
+        o.zero_grad()
+        hm, pts = n(xs[s % 4])
+        loss = crit(hm, pts, None, tg[s % 4])[2]
+        loss.backward(); o.step()
+        return float(loss.detach())
 bad = 0
 for s in range(steps):
     losses = []
     for n, o in zip(nets, opts):
-        o.zero_grad()
-        out = n(xs[s % 4], tg[s % 4]); out[0].sum().backward(); o.step()
-        losses.append(float(out[0].detach().sum()))
+        losses.append(one(n, o, s))
     a, b = nets[0].flat_parameters()[0], nets[1].flat_parameters()[0]
     if not torch.equal(a, b):
         d = (a != b)
