@@ -33,7 +33,7 @@ g = torch.Generator().manual_seed(21)
 if NET == "yolo":
     for i in range(2):
         torch.manual_seed(0)
-        n = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
+        n = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision=os.environ.get("PROBE_PREC", "bf16")).cuda().train()
         nets.append(n); opts.append(FusedAdam(n, lr=1e-3))
     xs = [torch.rand(B, 3, 416, 416, generator=g).cuda() for _ in range(4)]
     tg = [bench.synth_targets(B, 16, g).cuda() for _ in range(4)]
@@ -49,7 +49,7 @@ else:
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
     for i in range(2):
         torch.manual_seed(0)
-        n = KeypointNet(7, (80, 80), precision="bf16").cuda().train()
+        n = KeypointNet(7, (80, 80), precision=os.environ.get("PROBE_PREC", "bf16")).cuda().train()
         nets.append(n); opts.append(FusedAdam(n, lr=1e-2))
     with contextlib.redirect_stdout(sys.stderr):
         crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
