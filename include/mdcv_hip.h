@@ -248,6 +248,24 @@ int mdcv_graph_end(void* stream, void** graph_exec);
 int mdcv_graph_launch(void* graph_exec, void* stream);
 int mdcv_graph_destroy(void* graph_exec);
 
+/* ---- 1x1 convolution blocks with the neighbouring BatchNorm pass folded into the operand load (csrc/pw_block.hip; bf16 only).
+ *      Replaces, for a 1x1 conv whose input is the output of a conv -> BatchNorm -> activation (-> shortcut add) block
+ *      (CVC-YOLOv3/models.py:48-72 + the shortcut of :322-327), the pair  mdcv_bn_act_fwd + mdcv_conv2d  (forward) and the pair
+ *      mdcv_bn_act_bwd_apply + mdcv_conv2d / mdcv_conv2d_dgrad_bnsums  (backward) by one launch each, with identical results.
+ *      K = channels of the transformed operand (multiple of 32, K/8 divides 512, <= 1024), N = output channels (multiple of 8). */
+int mdcv_pw_rows(long long M, int K);          /* rows of stats_partial / fpartial the two entry points below write: one per pixel tile */
+int mdcv_pw_set_variant(int v);                /* tuning hook: 64 / 32 / 16 pixels per tile, 0 = heuristic */
+/* forward: z = act(y * scale + shift) (+ resid) -> z_out ; out = z . W^T (+ bias) ; stats_partial (may be NULL): [mdcv_pw_rows][2][N] */
+int mdcv_pw_conv_fwd(int dtype, const void* y, int ldy, const float* scale, const float* shift, const void* resid, int ldr, int act,
+                     float slope, void* z_out, int ldz, const void* w_packed, const float* bias, void* out, int out_ldc,
+                     float* stats_partial, long long M, int K, int N, void* stream);
+/* backward: dy = cA*g + cB*y + cC with g = dz * act'(y*scale + shift) -> dy_out ; dx = dy . W (+ addsrc) ; fy != NULL: also the
+ * BatchNorm-backward partial sums of the layer that produced this conv's input, [mdcv_pw_rows][2][N] (as mdcv_conv2d_dgrad_bnsums). */
+int mdcv_pw_conv_bwd(int dtype, const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* cA,
+                     const float* cB, const float* cC, int act, float slope, void* dy_out, int lddy, const void* wd_packed, void* dx,
+                     int dx_ldc, const void* addsrc, int add_ldc, const void* fy, int ldfy, const float* fscale, const float* fshift,
+                     const float* fmean, int fact, float fslope, float* fpartial, long long M, int K, int N, void* stream);
+
 /* ---- the one exchange step of the data-parallel path, for hosts that do not go through torch.distributed:
  *      nn.DataParallel's gradient reduction (CVC-YOLOv3/train.py:193-195 with `losses[0].sum().backward()`, train.py:70) as an RCCL
  *      all-reduce(SUM) of the flat fp32 gradient buffer over xGMI, one process per GPU.  librccl is bound at run time (dlopen by

@@ -26,6 +26,7 @@
 #include "common.h"
 #include "conv_shift.h"
 #include "bn_fuse.h"
+#include <cstdlib>
 
 // The file is compiled twice (Makefile: conv_shift_fwd.o with -DMDCV_SHIFT_PART=0, conv_shift_dgrad.o with -DMDCV_SHIFT_PART=1) so that the
 // forward and the data-gradient instantiations build in parallel; part 0 also holds the host entry points and the tuning globals.
@@ -44,6 +45,10 @@ int g_shift_n64 = 2;    // 64- and 32-channel layers run one narrow tile column 
 int g_shift_wmax = 80;  // widest image row the shift kernel takes (set_variant(-15) -> 62, (-14) -> 80).  Up to 62 the chunk is 384 rows (3 DMAs per
                         // wave); 63..80 take a fourth and still fit two workgroups on a CU: RektNet's 128->128 layers at 80x80 +3.1 % on its step,
                         // the 76x76 layers of the 608^2 detector +1 % on the joint pipeline (same-box A/B)
+static int env_int(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }
+int g_shift_loop = env_int("MDCV_SHIFT_LOOP", 0);   // K-loop form: 0 lockstep, 1 ping-pong wave groups (set_variant(-30) / (-31))
+int g_shift_stagger = 0;
+int g_shift_big = env_int("MDCV_SHIFT_BIG", 0);   // 384 / 512: that tile height (one workgroup per CU, ping-pong loop) where the plan below takes it
 int g_shift_plan = 0;   // 0 / 5: default plan (192-row tiles where they save a round) ; 1: 256-row tiles only ; 2: 128-row only ; 6: never 192-row
 #else
 extern int g_shift_ring;
@@ -53,6 +58,9 @@ extern int g_shift_dil2;
 extern int g_shift_n64;
 extern int g_shift_wmax;
 extern int g_shift_plan;
+extern int g_shift_loop;
+extern int g_shift_stagger;
+extern int g_shift_big;
 #endif
 int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes);   // defined by part 1
 
@@ -92,7 +100,7 @@ template <int N> __device__ __forceinline__ void wait_vm_reads_done() { asm vola
 
 }  // namespace
 
-template <int MODE, int BM, int NPA, int BRING, bool FUSE, int WN, bool EPI = false, int BN_ = 128>
+template <int MODE, int BM, int NPA, int BRING, bool FUSE, int WN, bool EPI = false, int BN_ = 128, int LOOP = 0>
 __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftArgs a, unsigned in_bytes, unsigned w_bytes) {
   // output channels per tile: 128, or 64 for 64-channel layers (wave tile (BM/4) x 32; waves 4..7 send their weight DMA to the sink)
   constexpr int BN = BN_, BTILE = BN * 64, SROW = BN * 2 + 16;
@@ -111,6 +119,9 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 
   const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
   if (logical >= a.tiles_total) return;
+  if (a.stagger && ((blockIdx.x >> 8) & 1)) {               // experiment: the second workgroup of a CU starts late
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -180,6 +191,13 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   // outstanding, plus the chunk (NPA DMAs) while it is younger than tile s, i.e. at taps 1 .. LA.
   constexpr int LA = BRING - 1;
   const int nch = a.nchunks;
+  constexpr int ABL = LOOP >= 16 ? LOOP - 16 : 0;          // timing ablations of the lockstep loop (never shipped as a default): 1 no MFMA, 2 no reads, 4 no DMA
+  [[maybe_unused]] bf16x8_t abl_frag;
+  if constexpr (ABL & 2) {
+    const float fv = 0.37f + 0.01f * (float)lane;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) abl_frag[e] = (__bf16)(e & 1 ? -fv : fv);
+  }
 #ifdef MDCV_SHIFT_TS
   const bool ts_on = logical == 300 && tid == 64 * 3;
   int ts_i = 0;
@@ -199,6 +217,74 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   // constant of (cc, tap): 9 * PERIOD is a multiple of BRING, and PERIOD is even or the A buffer index is taken from c.
   constexpr int PERIOD = BRING == 4 ? 4 : 2;              // 3- and 6-slot rings: 18 steps ; 4 slots: 36
   static_assert((9 * PERIOD) % BRING == 0, "ring period");
+  if constexpr (LOOP == 1) {
+    // PING-PONG form (round 4).  The eight waves are two groups of four (one wave of each group per SIMD); a K step of a wave is a LOAD
+    // phase (fragment reads of step s, the DMA of weight tile s+LA, the counted wait for tile s+1) and an MFMA phase (16 MFMAs), each
+    // closed by a barrier, and group 1 runs ONE BARRIER behind group 0: in every barrier interval one wave of a SIMD multiplies while its
+    // partner reads and issues DMAs, instead of all eight waves reading, then all eight multiplying.
+    //   interval 2s   : group 0 LOAD(s)      group 1 MFMA(s-1)
+    //   interval 2s+1 : group 0 MFMA(s)      group 1 LOAD(s)
+    // RAW: tile s+1 is waited for (own DMAs, counted vmcnt) at the end of LOAD(s) by both groups, i.e. no later than interval 2s+1, and
+    // first read by group 0 in interval 2s+2 -- a barrier every wave has passed lies between.  WAR: tile s+LA goes into the slot of tile
+    // s-1 (LA = BRING-1), whose last reads (group 1, LOAD(s-1), interval 2s-1) are DONE (lgkmcnt(0)) before the barrier that opens
+    // interval 2s, where group 0 issues first.  The same count holds for the activation chunk (issued in LOAD(9c), its buffer last read in
+    // LOAD(9c-1)).
+    const int grp = wave >> 2;
+    wait_vm<LA - 1>();                                     // own share of chunk 0 and weight tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int c0 = 0; c0 < nch; c0 += PERIOD) {
+#pragma unroll
+      for (int cc = 0; cc < PERIOD; ++cc) {
+        const int c = c0 + cc;
+        if (c < nch) {
+          const bool lastc = c == nch - 1;
+          const int abase = (cc & 1) * ABYTES;
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const int rslot = (cc * 9 + tap) % BRING, wslot = (cc * 9 + tap + LA) % BRING;
+            // ---- LOAD phase
+            bf16x8_t fa[FM], fb[FN];
+            const unsigned char* pa = smem + abase + offA[tap];
+            const unsigned char* pb = smem + BBASE + rslot * BTILE + offB;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 1024);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(pa + i * 1024);
+            {
+              const int t2 = (tap + LA) % 9, c2 = c + (tap + LA) / 9;
+              if (tap + LA >= 9 && lastc) ISSUE_B(rw0, t2, c2, wslot);
+              else ISSUE_B(rw, t2, c2, wslot);
+            }
+            if (tap == 0) {
+              if (lastc) ISSUE_A(rin0, c + 1, (cc + 1) & 1);
+              else ISSUE_A(rin, c + 1, (cc + 1) & 1);
+            }
+            // tile s+1 landed: LA-1 newer weight tiles may be outstanding, and the chunk while it is younger than tile s+1 (taps 0 .. LA-1)
+            if (tap <= LA - 1) wait_vm_reads_done<LA - 1 + NPA>(); else wait_vm_reads_done<LA - 1>();
+#pragma unroll
+            for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(fb[j]));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA phase
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+              for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else {
   for (int c0 = 0; c0 < nch; c0 += PERIOD) {
 #pragma unroll
     for (int cc = 0; cc < PERIOD; ++cc) {
@@ -223,10 +309,18 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
           bf16x8_t fa[FM], fb[FN];
           const unsigned char* pa = smem + abase + offA[tap];
           const unsigned char* pb = smem + BBASE + rslot * BTILE + offB;
+          if constexpr (ABL & 2) {                           // timing ablation: no fragment reads (operands = a lane pattern)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = abl_frag;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = abl_frag;
+          } else {
 #pragma unroll
           for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(pa + i * 1024);
 #pragma unroll
           for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 1024);
+          }
+          if constexpr (!(ABL & 4)) {
           {
             const int t2 = (tap + LA) % 9, c2 = c + (tap + LA) / 9;
             if (tap + LA >= 9 && lastc) ISSUE_B(rw0, t2, c2, wslot);   // past the last K step: zero fill, same DMA count
@@ -236,13 +330,21 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
             if (lastc) ISSUE_A(rin0, c + 1, (cc + 1) & 1);
             else ISSUE_A(rin, c + 1, (cc + 1) & 1);
           }
+          }
 #ifdef MDCV_SHIFT_PRIO
           __builtin_amdgcn_s_setprio(MDCV_SHIFT_PRIO);
 #endif
+          if constexpr (ABL & 1) {                           // timing ablation: no MFMAs (the fragments stay live)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) asm volatile("" :: "v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(fb[j]));
+          } else {
 #pragma unroll
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          }
 #ifdef MDCV_SHIFT_PRIO
           __builtin_amdgcn_s_setprio(0);
 #endif
@@ -253,6 +355,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
         }
       }
     }
+  }
   }
   wait_vm<0>();
   __syncthreads();                                         // the epilogue reuses the pipeline LDS
@@ -334,7 +437,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
         reinterpret_cast<bf16_t*>(smem + (row + 1) * SROW)[col] = (bf16_t)(pk >> 16);
       }
   __syncthreads();
-  constexpr int GR = BM % 128 == 0 ? 128 : BM;             // stream positions per partial-statistics row (192-row tiles: one row per tile)
+  constexpr int GR = (BM == 128 || BM == 256 || BM == 512) ? 128 : BM;   // stream positions per partial-statistics row (192- / 384-row tiles: one row per tile)
   constexpr int G = BM / GR, WPG = WM / G;                 // rows per tile; waves (in M) per row
   if (a.stats && tid < BN * G) {
     const int g = tid / BN, col = tid - g * BN;
@@ -367,6 +470,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
           for (int e = 0; e < 8; ++e) x[e] += y[e];
           d = ET<bf16_t>::pack(x);
         }
+        if constexpr (ABL & 8) asm volatile("" :: "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w)); else
         *reinterpret_cast<uint4*>(out + ((size_t)pix * a.out_ldc + n)) = d;
       }
     }
@@ -443,18 +547,36 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 
 namespace {
 
-template <int MODE, int BM, int NPA, bool FUSE, int WN, bool EPI = false, int BRING = 3, int BN_ = 128>
+template <int MODE, int BM, int NPA, bool FUSE, int WN, bool EPI = false, int BRING = 3, int BN_ = 128, int LOOP = 0>
 int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   constexpr int NW = WM * WN;
+  if constexpr (LOOP == 0 && WN == 2 && !EPI) {
+    if (g_shift_loop == 1 || BM > 256) return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 1>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  }
+  if constexpr (LOOP == 0 && WN == 2 && !EPI && MODE == 0 && BM == 256 && BN_ == 128 && !FUSE && BRING == 3 && NPA == 3) {   // timing ablations
+    switch (g_shift_loop) {
+      case 17: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 17>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      case 18: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 18>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      case 19: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 19>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      case 20: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 20>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      case 21: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 21>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      case 22: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 22>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      case 23: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 23>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      case 24: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 24>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      case 31: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 31>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+      default: break;
+    }
+  }
   constexpr int BN = BN_, BTILE = BN * 64, SROW = BN * 2 + 16;
   // A grid that puts one workgroup on a CU has only the ring's lookahead in flight on that CU's L2 -> LDS path (latency-bound fill):
   // such launches (batch 32: the 13x13 and 26x26 data gradients) take a 4-slot weight ring.  Same-box A/B of the YOLOv3 step:
   // +0.45 .. 0.6 % (6 slots +0.35 %; 4 slots on EVERY grid -2.8 %: the 36-step unrolled period and the third workgroup's worth of LDS).
-  if constexpr (BRING == 3 && WN == 2 && !EPI) {
-    if (g_shift_ring == 4 && tiles_m * a.tiles_n <= 256)
-      return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 4, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  if constexpr (BRING == 3 && WN == 2 && !EPI && BM <= 384) {
+    if ((g_shift_ring == 4 && tiles_m * a.tiles_n <= 256) || g_shift_ring == 5)
+      return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 4, BN_, LOOP>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
   a.p_base = p_base;
+  a.stagger = g_shift_stagger;
   a.tiles_total = tiles_m * a.tiles_n;
   a.xcd_chunk = (a.tiles_total + 7) / 8;
   a.nca = (BM + 2 * a.dil * (a.Wq + 1) + 15) / 16;         // KiB-chunks (16 stream rows each) of one activation chunk
@@ -462,7 +584,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics (the fused sums fold inside dead staging rows)
   const int lds = pipe > epi ? pipe : epi;
   static int attr_lds = 0;
-  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE, WN, EPI, BN_>;
+  auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE, WN, EPI, BN_, LOOP>;
   if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
@@ -514,6 +636,7 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128) {
     }
     return 256;
   }
+  if (g_shift_big && bn == 128 && !fused && halo <= 110) return g_shift_big;
   if (g_shift_plan == 1) return 256;
   if (g_shift_plan == 2) return 128;
   const int t256 = ((Mq + 255) / 256) * tiles_n;
@@ -527,6 +650,10 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128) {
 template <int MODE, int BN_>
 int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr, 2 * a.dil * (a.Wq + 1), BN_);
+  if constexpr (BN_ == 128 && MODE == 0) {
+    if (bm == 384) return launch_shift_bm<MODE, 384, BN_>(a, 0, (a.Mq + 383) / 384, st, in_bytes, w_bytes);
+    if (bm == 512) return launch_shift_bm<MODE, 512, BN_>(a, 0, (a.Mq + 511) / 512, st, in_bytes, w_bytes);
+  }
   if (bm == 192) return launch_shift_bm<MODE, 192, BN_>(a, 0, (a.Mq + 191) / 192, st, in_bytes, w_bytes);
   const int big_m = (a.Mq + 255) / 256;
   const int nbig_m = bm == 128 ? 0 : big_m;
@@ -566,7 +693,8 @@ int mdcv_shift_stats_rows(int B, int H, int W, int dil) { return (int)(((long lo
 int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil) {
   const int Mq = B * (H + dil) * (W + dil);
   const int bn = Nout <= 64 ? Nout : BN;
-  return shift_plan_bm(Mq, Nout <= 64 ? 1 : Nout / BN, false, 2 * dil * (W + dil + 1), bn) == 192 ? (Mq + 191) / 192 : (Mq + 127) / 128;
+  const int bm = shift_plan_bm(Mq, Nout <= 64 ? 1 : Nout / BN, false, 2 * dil * (W + dil + 1), bn);
+  return (bm == 192 || bm == 384) ? (Mq + bm - 1) / bm : (Mq + 127) / 128;
 }
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
@@ -591,7 +719,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   return launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring == 3 || ring == 4) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring >= 200 && ring < 300) { g_shift_big = ring == 200 ? 0 : (ring == 201 ? 384 : 512); return; } if (ring >= 100 && ring < 200) { g_shift_stagger = ring - 100; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

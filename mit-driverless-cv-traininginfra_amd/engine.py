@@ -414,13 +414,90 @@ class Plan:
                   x.B, x.H, x.W, cs.cin_pad, out.H, out.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
 
     def emit_bn_act_fwd(self, y1, bs1, out, act, slope, y2=None, bs2=None, resid=None):
+        # (remembered so that a 1x1 conv emitted right behind it can take the pass into its operand load: emit_pw_fwd)
+        self.last_bnact = None if y2 is not None else dict(idx=len(self.fwd), y=y1, bs=bs1, out=out, act=act, slope=float(slope), resid=resid)
         self.call(self.fwd, self.L.bn_act_fwd, self.dtype, y1.ptr, y1.ldc, bs1.scale.data_ptr(), bs1.shift.data_ptr(),
                   y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
                   bs2.scale.data_ptr() if bs2 is not None else None, bs2.shift.data_ptr() if bs2 is not None else None,
                   resid.ptr if resid is not None else None, resid.ldc if resid is not None else 0,
                   out.ptr, out.ldc, out.M, out.C, act, float(slope))
 
-    def emit_bn_act_bwd(self, dout, y1, bs1, act, slope, y2=None, bs2=None):
+    # ---- 1x1 conv blocks with the neighbouring BatchNorm pass folded into the operand load (csrc/pw_block.hip).  Policy from same-box
+    # timing of the fused launch against the pair it replaces (scripts/pw_block_ab.py, YOLOv3 416^2 batch 32): the forward form wins from
+    # 26^2 upwards (52^2: 32.7 vs 43.3 us, 104^2: 61.5 vs 72.7 us), the backward form at 52^2 (48.7 vs 54.9 us with the fused sums); the
+    # 13^2 layers (K = 1024: 16-pixel tiles re-stream 1 MiB of weights per tile) and the 26^2 backward keep the pairs.
+    pw_fuse = True                     # (tests / A-B scripts flip the class attribute)
+    pw_fwd_px = (20000, 1 << 30)       # pixels M of the layers that take the forward form
+    pw_bwd_px = (50000, 150000)        # ... the backward form
+
+    def _pw_ok(self, mode, cs, M, K, N, *lds):
+        if not self.pw_fuse or self.dtype != BF16 or not self.training:
+            return False
+        if (cs.kh, cs.kw, cs.stride, cs.pad) != (1, 1, 1, 0):
+            return False
+        lo, hi = self.pw_fwd_px if mode == 0 else self.pw_bwd_px
+        if not (lo <= M < hi) or N < 64:
+            return False
+        if mode == 0 and K > 512 or mode == 1 and K > 256:
+            return False
+        if K < 64 or K % 32 or 256 % (K // 8) or N % 8 or any(v % 8 for v in lds):
+            return False
+        return True
+
+    def pw_fwd_candidate(self, cs_shape, x):
+        """-> the remembered bn_act_fwd emission if a 1x1 conv reading `x` emitted NOW could absorb it (it must be the last forward entry
+        and have written exactly x), else None.  cs_shape = (cout, cin, kh, kw, stride, pad)."""
+        lb = getattr(self, "last_bnact", None)
+        if lb is None or lb["idx"] != len(self.fwd) - 1 or lb["out"].ptr != x.ptr or lb["out"].ldc != x.ldc or lb["out"].C != x.C:
+            return None
+        cout, cin, kh, kw, stride, pad = cs_shape
+
+        class _S:                      # the geometry fields _pw_ok looks at
+            pass
+        c = _S(); c.kh, c.kw, c.stride, c.pad = kh, kw, stride, pad
+        r = lb["resid"]
+        if not self._pw_ok(0, c, x.M, x.C, pad8(cout), lb["y"].ldc, x.ldc, r.ldc if r is not None else 8):
+            return None
+        return lb
+
+    def emit_pw_fwd(self, lb, cs, x, y, stats_partial):
+        """Emits ONE launch for  bn_act_fwd(lb) ; conv2d(cs: x -> y)  (lb from pw_fwd_candidate; the caller has popped that bn_act_fwd
+        entry from the forward list and emitted nothing else since).  stats_partial: [pw_rows][2][y.C] or None."""
+        assert lb["idx"] == len(self.fwd) and x.C == cs.cin_pad and y.C == cs.cout_pad
+        self.last_bnact = None
+        r, bs = lb["resid"], lb["bs"]
+        self.call(self.fwd, self.L.pw_conv_fwd, self.dtype, lb["y"].ptr, lb["y"].ldc, bs.scale.data_ptr(), bs.shift.data_ptr(),
+                  r.ptr if r is not None else None, r.ldc if r is not None else 0, lb["act"], lb["slope"], x.ptr, x.ldc,
+                  cs.wf.data_ptr(), cs.bias_pad.data_ptr() if cs.bias_pad is not None else None, y.ptr, y.ldc,
+                  stats_partial.data_ptr() if stats_partial is not None else None, x.M, cs.cin_pad, cs.cout_pad)
+        self.pw_fwd_count = getattr(self, "pw_fwd_count", 0) + 1
+
+    def emit_pw_bwd(self, dout, y, bs, act, slope, cs, xnode):
+        """Backward of  conv1x1(cs) -> BatchNorm(bs) -> activation  from dout = d(activation output): the statistics part of the
+        BatchNorm backward as usual (fused into the producer of dout or the stand-alone reduce), then ONE launch that forms
+        dy = cA*g + cB*y + cC in its operand load, writes it for the weight gradient and computes dx = dy . W (+ the other gradient
+        contributions of x); then the weight gradient.  Returns False (nothing emitted) when the layer does not take this form."""
+        x = xnode.act
+        if not xnode.needs_grad or cs.wd is None:
+            return False
+        if not self._pw_ok(1, cs, y.M, y.C, cs.cin_pad, dout.ldc, y.ldc, x.ldc):
+            return False
+        L, dt = self.L, self.dtype
+        dy = self.emit_bn_act_bwd(dout, y, bs, act, slope, apply=False)
+        out, add = self.grad_target(xnode)
+        n = lambda t: t.data_ptr()  # noqa: E731
+        args = [dt, dout.ptr, dout.ldc, y.ptr, y.ldc, n(bs.scale), n(bs.shift), n(bs.cA), n(bs.cB), n(bs.cC), act, float(slope),
+                dy.ptr, dy.ldc, cs.wd.data_ptr(), out.ptr, out.ldc, add.ptr if add is not None else None, add.ldc if add is not None else 0,
+                None, 0, None, None, None, 0, 0.0, None, y.M, cs.cout_pad, cs.cin_pad]
+        self.dgrad_entries[out.ptr] = dict(
+            idx=len(self.bwd), out=out, used=False, pw=args,
+            geom=(x.B, y.H, y.W, cs.cout_pad, x.H, x.W, cs.cin_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil), head=(dy.ptr, dy.ldc))
+        self.call(self.bwd, L.pw_conv_bwd, *args)
+        self._emit_wgrad_single(cs, x, dy, cs.cin_pad)
+        self.pw_bwd_count = getattr(self, "pw_bwd_count", 0) + 1
+        return True
+
+    def emit_bn_act_bwd(self, dout, y1, bs1, act, slope, y2=None, bs2=None, apply=True):
         """Returns the gradient(s) of the raw conv output(s): dy1 [, dy2]."""
         L, dt = self.L, self.dtype
         dy1 = self._alloc_like(y1)
@@ -440,6 +517,9 @@ class Plan:
                       bs1.bn.weight.data_ptr(), g1.data_ptr(), b1.data_ptr(), n(bs1.cA), n(bs1.cB), n(bs1.cC),
                       bs2.bn.weight.data_ptr() if bs2 else None, n(g2), n(b2), n(bs2.cA) if bs2 else None, n(bs2.cB) if bs2 else None,
                       n(bs2.cC) if bs2 else None)
+        if not apply:                  # the consumer forms dy itself and writes it to dy1 (emit_pw_bwd)
+            assert y2 is None
+            return dy1
         self.call(self.bwd, L.bn_act_bwd_apply, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.cA),
                   n(bs1.cB), n(bs1.cC), dy1.ptr, dy1.ldc,
                   y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
@@ -517,16 +597,23 @@ class Plan:
         L, dt = self.L, self.dtype
         if not self._fuse_pays(e["geom"]):
             return False
-        rows = int(L.conv2d_dgrad_bnsums_rows(dt, *e["geom"], e["head"][1]))
+        pw = e.get("pw")
+        rows = int(L.pw_rows(o.M, e["geom"][3])) if pw is not None else int(L.conv2d_dgrad_bnsums_rows(dt, *e["geom"], e["head"][1]))
         if rows <= 0 or rows > self.fuse_max_rows:
             return False
         fn0, _ = self.bwd[e["idx"]]
-        assert fn0 is L.conv2d
         partial = self.f32(rows * 2 * y.C, zero=False)
-        h = e["head"]
-        self.bwd[e["idx"]] = (L.conv2d_dgrad_bnsums, (dt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], *e["geom"], y.ptr, y.ldc,
-                                                       bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope),
-                                                       partial.data_ptr()))
+        if pw is not None:             # the 1x1 block launch (emit_pw_bwd) carries the sums in its own store loop
+            assert fn0 is L.pw_conv_bwd
+            a2 = list(pw)
+            a2[19:27] = [y.ptr, y.ldc, bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope), partial.data_ptr()]
+            self.bwd[e["idx"]] = (L.pw_conv_bwd, tuple(a2))
+        else:
+            assert fn0 is L.conv2d
+            h = e["head"]
+            self.bwd[e["idx"]] = (L.conv2d_dgrad_bnsums, (dt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], *e["geom"], y.ptr, y.ldc,
+                                                           bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope),
+                                                           partial.data_ptr()))
         e["used"] = True
         self.call(self.bwd, L.bn_bwd_finalize_rows, partial.data_ptr(), rows, y.C, float(y.M), bs.bn.weight.data_ptr(),
                   bs.mean.data_ptr(), bs.invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bs.cA.data_ptr(), bs.cB.data_ptr(),

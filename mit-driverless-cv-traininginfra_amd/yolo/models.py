@@ -665,6 +665,14 @@ class Darknet(FlatParamsMixin, nn.Module):
             if k == "convolutional":
                 conv = mods[i][0]
                 has_bn = d["filters"] != "preyolo"
+                # a 1x1 conv right behind a BatchNorm-apply takes that pass into its operand load (engine.emit_pw_fwd): decided before
+                # emit_pack so that the layer mark points at the fused launch
+                pw_lb = None
+                if bn_train and d["filters"] != "preyolo":
+                    pw_lb = plan.pw_fwd_candidate((conv.out_channels, conv.in_channels, conv.kernel_size[0], conv.kernel_size[1],
+                                                   conv.stride[0], conv.padding[0]), cur.act)
+                    if pw_lb is not None:
+                        plan.fwd.pop()                       # that bn_act_fwd entry is replaced by the fused launch below
                 cs = ConvSpec(plan, conv.weight, conv.bias, conv.stride[0], conv.padding[0], 1, cin_pad=cur.act.C)
                 plan.emit_pack(cs, need_dgrad=with_targets and cur.needs_grad)
                 ho, wo = shp[i][1], shp[i][2]
@@ -674,7 +682,13 @@ class Darknet(FlatParamsMixin, nn.Module):
                     y = plan.new_act(B, ho, wo, conv.out_channels)
                     fuse = (i + 1 < n and defs[i + 1]["type"] == "shortcut" and users[i] == [i + 1]
                             and res(i + 1, int(defs[i + 1]["from"])) != i)
-                    if bn_train:
+                    if bn_train and pw_lb is not None:
+                        rows = int(L.pw_rows(cur.act.M, cs.cin_pad))
+                        partial = plan.f32(rows * 2 * y.C, zero=False)
+                        plan.emit_pw_fwd(pw_lb, cs, cur.act, y, partial)
+                        plan.emit_bn_stats(bs, y, partial, rows)
+                        nbt.append(bn.num_batches_tracked)
+                    elif bn_train:
                         rows = plan.stats_rows(cs, cur.act, y)
                         partial = plan.f32(rows * 2 * y.C, zero=False)
                         plan.emit_conv_fwd(cs, cur.act, y, partial)
@@ -817,8 +831,9 @@ class Darknet(FlatParamsMixin, nn.Module):
                         continue
                     if rnode is not None:
                         plan.grad_identity(rnode, z.grad)
-                    dy = plan.emit_bn_act_bwd(z.grad, y, bs, act_code, slope)
-                    plan.emit_conv_bwd(cs, xn, y, dy)
+                    if not plan.emit_pw_bwd(z.grad, y, bs, act_code, slope, cs, xn):
+                        dy = plan.emit_bn_act_bwd(z.grad, y, bs, act_code, slope)
+                        plan.emit_conv_bwd(cs, xn, y, dy)
                 elif kind == "shortcut":
                     _, a, b, z = r
                     if z.gstate == "none":

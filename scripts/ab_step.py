@@ -1,0 +1,107 @@
+"""Same-box A/B of the whole YOLOv3 training step (BASELINE config 3) under tuning hooks, interleaved in one process, one model per setting
+(plan-build-time switches need their own plan).
+usage: ab_step.py "c-30;c-31;c-31,w30005;P0" [rounds] [steps] [yolo|rektnet]
+  c<n> = mdcv_conv2d_set_variant(n), w<n> = mdcv_conv2d_wgrad_set_variant(n), p<n> = mdcv_pw_set_variant(n)   (applied before every timing block)
+  P0 / P1 = engine.Plan.pw_fuse off / on, F<mask> = engine.Plan.fuse_skip                                      (applied when the model is built)
+Every setting is applied on top of the first one (the baseline), which is re-applied in front of each."""
+import os, sys, tempfile, time, statistics
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from mdcv import _lib
+from mdcv.yolo.models import Darknet
+from mdcv.optim import FusedAdam
+
+L = _lib.lib()
+settings = [s.split(",") for s in (sys.argv[1] if len(sys.argv) > 1 else "c-30;c-31").split(";")]
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+workload = sys.argv[4] if len(sys.argv) > 4 else "yolo"
+
+
+from mdcv import engine
+BUILD_DEFAULTS = dict(pw_fuse=engine.Plan.pw_fuse, fuse_skip=engine.Plan.fuse_skip)
+
+
+def apply(codes):
+    for c in codes:
+        if not c or c[0] in "PF":
+            continue
+        {"c": L.cdll.mdcv_conv2d_set_variant, "w": L.cdll.mdcv_conv2d_wgrad_set_variant, "p": L.cdll.mdcv_pw_set_variant}[c[0]](int(c[1:]))
+
+
+def apply_build(codes):
+    engine.Plan.pw_fuse, engine.Plan.fuse_skip = BUILD_DEFAULTS["pw_fuse"], BUILD_DEFAULTS["fuse_skip"]
+    for c in codes:
+        if c and c[0] == "P":
+            engine.Plan.pw_fuse = bool(int(c[1:]))
+        if c and c[0] == "F":
+            engine.Plan.fuse_skip = int(c[1:])
+
+
+dev = torch.device("cuda", 0)
+tmp = tempfile.mkdtemp()
+g = torch.Generator().manual_seed(1000)
+def make(i):
+    apply_build(settings[0]); apply_build(settings[i])
+    if workload == "yolo":
+        cfg = bench.write_yolo_cfg(tmp)
+        os.chdir(tmp)
+        torch.manual_seed(0)
+        net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True).to(dev).train()
+        opt = FusedAdam(net, lr=1e-3)
+
+        def step():
+            opt.zero_grad()
+            loss = net(x, tg)[0].sum()
+            loss.backward()
+            opt.step()
+            return loss
+    else:
+        from mdcv.rektnet.keypoint_net import KeypointNet
+        from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
+        torch.manual_seed(0)
+        net = KeypointNet(7, (80, 80)).to(dev).train()
+        crit = CrossRatioLoss("l1_softargmax", True, 0.05, 0.05)
+        opt = FusedAdam(net, lr=1e-3)
+
+        def step():
+            opt.zero_grad()
+            out = net(x)
+            loss = crit(out[0], out[1], None, pts)[2]
+            loss.backward()
+            opt.step()
+            return loss
+    apply(settings[0]); apply(settings[i])
+    for _ in range(6): l = step()          # builds the plan under this setting's switches
+    return step, float(l.detach())
+
+
+if workload == "yolo":
+    x, tg = torch.rand(32, 3, 416, 416, generator=g).to(dev), bench.synth_targets(32, 16, g).to(dev)
+    nimg = 32
+else:
+    x = torch.rand(256, 3, 80, 80, generator=g).to(dev)
+    pts = torch.rand(256, 7, 2, generator=g).to(dev) * 0.9
+    nimg = 256
+steps_fn, last = {}, {}
+for i in range(len(settings)):
+    steps_fn[i], last[i] = make(i)
+torch.cuda.synchronize()
+res = {i: [] for i in range(len(settings))}
+for rnd in range(rounds):
+    for i, s in enumerate(settings):
+        apply(settings[0]); apply(s)
+        step = steps_fn[i]
+        for _ in range(3): step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps): l = step()
+        torch.cuda.synchronize()
+        res[i].append((time.perf_counter() - t0) / steps * 1e3)
+        last[i] = float(l.detach())
+for i, s in enumerate(settings):
+    print("%-28s median %.3f ms  min %.3f  (%s)  %.0f img/s  last loss %.4f" % (",".join(s), statistics.median(res[i]), min(res[i]),
+          " ".join("%.3f" % t for t in res[i]), nimg / statistics.median(res[i]) * 1e3, last[i]), flush=True)
+apply(settings[0])
