@@ -13,7 +13,6 @@ struct ShiftArgs {
   int dil;                              // dilation (1 or 2): the stream carries `dil` shared zero columns per image row and zero rows per image
   BnFuseArgs fuse;                      // BatchNorm-backward sums folded into the store loop (fuse.y == NULL: off)
   EpiArgs epi;                          // inference epilogue (oscale == NULL and act == 0: off)
-  int stagger;                          // experiment: late start of every second workgroup (units of 127 x 64 cycles)
   int nchunks, wrow, nca;               // Cin/32 ; 9*Cin elements per weight row ; KiB-chunks per activation chunk
 };
 

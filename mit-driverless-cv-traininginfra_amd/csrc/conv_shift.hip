@@ -46,9 +46,12 @@ int g_shift_wmax = 80;  // widest image row the shift kernel takes (set_variant(
                         // wave); 63..80 take a fourth and still fit two workgroups on a CU: RektNet's 128->128 layers at 80x80 +3.1 % on its step,
                         // the 76x76 layers of the 608^2 detector +1 % on the joint pipeline (same-box A/B)
 static int env_int(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }
-int g_shift_loop = env_int("MDCV_SHIFT_LOOP", 0);   // K-loop form: 0 lockstep, 1 ping-pong wave groups (set_variant(-30) / (-31))
-int g_shift_stagger = 0;
-int g_shift_big = env_int("MDCV_SHIFT_BIG", 0);   // 384 / 512: that tile height (one workgroup per CU, ping-pong loop) where the plan below takes it
+int g_shift_loop = env_int("MDCV_SHIFT_LOOP", 2);   // K-loop form of the FORWARD launches (set_variant(-30 - n)): 0 lockstep ; 1 ping-pong wave groups
+                        // (two groups of four waves one barrier apart: one wave of a SIMD multiplies while its partner reads fragments and issues
+                        // DMAs) ; 2 (default) ping-pong for grids of at most one workgroup per CU, where no second workgroup fills the
+                        // read phase (13^2 512->1024 forward 52.5 -> 48.9 us), and 384-row ping-pong tiles where they make ONE round of
+                        // 193..256 workgroups (26^2 256->512 forward 44.6 -> 42.4 us).  Denser grids: +1..2 % alone, data gradients -5..+3 %.
+int g_shift_big = env_int("MDCV_SHIFT_BIG", 0);   // A/B: 384 forces the 384-row ping-pong tiles on every forward launch they fit
 int g_shift_plan = 0;   // 0 / 5: default plan (192-row tiles where they save a round) ; 1: 256-row tiles only ; 2: 128-row only ; 6: never 192-row
 #else
 extern int g_shift_ring;
@@ -59,7 +62,6 @@ extern int g_shift_n64;
 extern int g_shift_wmax;
 extern int g_shift_plan;
 extern int g_shift_loop;
-extern int g_shift_stagger;
 extern int g_shift_big;
 #endif
 int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes);   // defined by part 1
@@ -119,9 +121,6 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 
   const int logical = (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3);
   if (logical >= a.tiles_total) return;
-  if (a.stagger && ((blockIdx.x >> 8) & 1)) {               // experiment: the second workgroup of a CU starts late
-    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -191,13 +190,6 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   // outstanding, plus the chunk (NPA DMAs) while it is younger than tile s, i.e. at taps 1 .. LA.
   constexpr int LA = BRING - 1;
   const int nch = a.nchunks;
-  constexpr int ABL = LOOP >= 16 ? LOOP - 16 : 0;          // timing ablations of the lockstep loop (never shipped as a default): 1 no MFMA, 2 no reads, 4 no DMA
-  [[maybe_unused]] bf16x8_t abl_frag;
-  if constexpr (ABL & 2) {
-    const float fv = 0.37f + 0.01f * (float)lane;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) abl_frag[e] = (__bf16)(e & 1 ? -fv : fv);
-  }
 #ifdef MDCV_SHIFT_TS
   const bool ts_on = logical == 300 && tid == 64 * 3;
   int ts_i = 0;
@@ -309,18 +301,10 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
           bf16x8_t fa[FM], fb[FN];
           const unsigned char* pa = smem + abase + offA[tap];
           const unsigned char* pb = smem + BBASE + rslot * BTILE + offB;
-          if constexpr (ABL & 2) {                           // timing ablation: no fragment reads (operands = a lane pattern)
-#pragma unroll
-            for (int i = 0; i < FM; ++i) fa[i] = abl_frag;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) fb[j] = abl_frag;
-          } else {
 #pragma unroll
           for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(pa + i * 1024);
 #pragma unroll
           for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(pb + j * 1024);
-          }
-          if constexpr (!(ABL & 4)) {
           {
             const int t2 = (tap + LA) % 9, c2 = c + (tap + LA) / 9;
             if (tap + LA >= 9 && lastc) ISSUE_B(rw0, t2, c2, wslot);   // past the last K step: zero fill, same DMA count
@@ -330,21 +314,13 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
             if (lastc) ISSUE_A(rin0, c + 1, (cc + 1) & 1);
             else ISSUE_A(rin, c + 1, (cc + 1) & 1);
           }
-          }
 #ifdef MDCV_SHIFT_PRIO
           __builtin_amdgcn_s_setprio(MDCV_SHIFT_PRIO);
 #endif
-          if constexpr (ABL & 1) {                           // timing ablation: no MFMAs (the fragments stay live)
-#pragma unroll
-            for (int i = 0; i < FM; ++i) asm volatile("" :: "v"(fa[i]));
-#pragma unroll
-            for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(fb[j]));
-          } else {
 #pragma unroll
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-          }
 #ifdef MDCV_SHIFT_PRIO
           __builtin_amdgcn_s_setprio(0);
 #endif
@@ -437,7 +413,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
         reinterpret_cast<bf16_t*>(smem + (row + 1) * SROW)[col] = (bf16_t)(pk >> 16);
       }
   __syncthreads();
-  constexpr int GR = (BM == 128 || BM == 256 || BM == 512) ? 128 : BM;   // stream positions per partial-statistics row (192- / 384-row tiles: one row per tile)
+  constexpr int GR = (BM == 128 || BM == 256) ? 128 : BM;   // stream positions per partial-statistics row (192- / 384-row tiles: one row per tile)
   constexpr int G = BM / GR, WPG = WM / G;                 // rows per tile; waves (in M) per row
   if (a.stats && tid < BN * G) {
     const int g = tid / BN, col = tid - g * BN;
@@ -470,7 +446,6 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
           for (int e = 0; e < 8; ++e) x[e] += y[e];
           d = ET<bf16_t>::pack(x);
         }
-        if constexpr (ABL & 8) asm volatile("" :: "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w)); else
         *reinterpret_cast<uint4*>(out + ((size_t)pix * a.out_ldc + n)) = d;
       }
     }
@@ -550,33 +525,19 @@ namespace {
 template <int MODE, int BM, int NPA, bool FUSE, int WN, bool EPI = false, int BRING = 3, int BN_ = 128, int LOOP = 0>
 int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   constexpr int NW = WM * WN;
-  if constexpr (LOOP == 0 && WN == 2 && !EPI) {
-    if (g_shift_loop == 1 || BM > 256) return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 1>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-  }
-  if constexpr (LOOP == 0 && WN == 2 && !EPI && MODE == 0 && BM == 256 && BN_ == 128 && !FUSE && BRING == 3 && NPA == 3) {   // timing ablations
-    switch (g_shift_loop) {
-      case 17: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 17>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-      case 18: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 18>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-      case 19: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 19>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-      case 20: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 20>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-      case 21: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 21>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-      case 22: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 22>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-      case 23: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 23>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-      case 24: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 24>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-      case 31: return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 31>(a, p_base, tiles_m, st, in_bytes, w_bytes);
-      default: break;
-    }
-  }
   constexpr int BN = BN_, BTILE = BN * 64, SROW = BN * 2 + 16;
+  if constexpr (LOOP == 0 && WN == 2 && !EPI && MODE == 0 && !FUSE) {   // ping-pong K loop: forward launches only (measured, see g_shift_loop)
+    if (g_shift_loop == 1 || BM > 256 || (g_shift_loop == 2 && tiles_m * a.tiles_n <= 256))
+      return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 1>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  }
   // A grid that puts one workgroup on a CU has only the ring's lookahead in flight on that CU's L2 -> LDS path (latency-bound fill):
   // such launches (batch 32: the 13x13 and 26x26 data gradients) take a 4-slot weight ring.  Same-box A/B of the YOLOv3 step:
   // +0.45 .. 0.6 % (6 slots +0.35 %; 4 slots on EVERY grid -2.8 %: the 36-step unrolled period and the third workgroup's worth of LDS).
-  if constexpr (BRING == 3 && WN == 2 && !EPI && BM <= 384) {
+  if constexpr (BRING == 3 && WN == 2 && !EPI) {
     if ((g_shift_ring == 4 && tiles_m * a.tiles_n <= 256) || g_shift_ring == 5)
       return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 4, BN_, LOOP>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
   a.p_base = p_base;
-  a.stagger = g_shift_stagger;
   a.tiles_total = tiles_m * a.tiles_n;
   a.xcd_chunk = (a.tiles_total + 7) / 8;
   a.nca = (BM + 2 * a.dil * (a.Wq + 1) + 15) / 16;         // KiB-chunks (16 stream rows each) of one activation chunk
@@ -627,7 +588,7 @@ int launch_shift_bm(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st,
 // with the rest; since the BatchNorm sums moved into the data gradients the main stream bounds the step and the 192-row plan is
 // +0.6 % (2043 -> 2055 img/s, same-box A/B), so it is the default where it saves a round (batch 32: the 26x26 layers); 128-row
 // tiles only for grids of at most 128 tiles; plan 6 restores 256-row-only.
-int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128) {
+int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128, bool fwd = false) {
   if (halo > 0 && !fused && 2 * ((256 + halo + 15) / 16) * 1024 + 3 * bn * 64 + 1024 > 80 * 1024) {
     // dilation 2 / very wide rows: the halo (2 * dil * (Wq + 1) rows) dominates the LDS footprint; tallest tile that leaves two workgroups on a CU
     for (int bm = 256; bm >= 128; bm -= 64) {
@@ -636,7 +597,10 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128) {
     }
     return 256;
   }
-  if (g_shift_big && bn == 128 && !fused && halo <= 110) return g_shift_big;
+  if (bn == 128 && !fused && fwd && halo <= 110) {       // 384-row ping-pong tiles (one workgroup per CU): forward only
+    const int t384 = ((Mq + 383) / 384) * tiles_n;
+    if (g_shift_big == 384 || (g_shift_loop == 2 && t384 > 192 && t384 <= 256)) return 384;
+  }
   if (g_shift_plan == 1) return 256;
   if (g_shift_plan == 2) return 128;
   const int t256 = ((Mq + 255) / 256) * tiles_n;
@@ -649,10 +613,9 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128) {
 
 template <int MODE, int BN_>
 int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
-  const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr, 2 * a.dil * (a.Wq + 1), BN_);
+  const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr, 2 * a.dil * (a.Wq + 1), BN_, MODE == 0);
   if constexpr (BN_ == 128 && MODE == 0) {
     if (bm == 384) return launch_shift_bm<MODE, 384, BN_>(a, 0, (a.Mq + 383) / 384, st, in_bytes, w_bytes);
-    if (bm == 512) return launch_shift_bm<MODE, 512, BN_>(a, 0, (a.Mq + 511) / 512, st, in_bytes, w_bytes);
   }
   if (bm == 192) return launch_shift_bm<MODE, 192, BN_>(a, 0, (a.Mq + 191) / 192, st, in_bytes, w_bytes);
   const int big_m = (a.Mq + 255) / 256;
@@ -693,7 +656,7 @@ int mdcv_shift_stats_rows(int B, int H, int W, int dil) { return (int)(((long lo
 int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil) {
   const int Mq = B * (H + dil) * (W + dil);
   const int bn = Nout <= 64 ? Nout : BN;
-  const int bm = shift_plan_bm(Mq, Nout <= 64 ? 1 : Nout / BN, false, 2 * dil * (W + dil + 1), bn);
+  const int bm = shift_plan_bm(Mq, Nout <= 64 ? 1 : Nout / BN, false, 2 * dil * (W + dil + 1), bn, true);
   return (bm == 192 || bm == 384) ? (Mq + bm - 1) / bm : (Mq + 127) / 128;
 }
 
@@ -719,7 +682,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   return launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring >= 200 && ring < 300) { g_shift_big = ring == 200 ? 0 : (ring == 201 ? 384 : 512); return; } if (ring >= 100 && ring < 200) { g_shift_stagger = ring - 100; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

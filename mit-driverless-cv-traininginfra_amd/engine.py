@@ -423,12 +423,14 @@ class Plan:
                   out.ptr, out.ldc, out.M, out.C, act, float(slope))
 
     # ---- 1x1 conv blocks with the neighbouring BatchNorm pass folded into the operand load (csrc/pw_block.hip).  Policy from same-box
-    # timing of the fused launch against the pair it replaces (scripts/pw_block_ab.py, YOLOv3 416^2 batch 32): the forward form wins from
-    # 26^2 upwards (52^2: 32.7 vs 43.3 us, 104^2: 61.5 vs 72.7 us), the backward form at 52^2 (48.7 vs 54.9 us with the fused sums); the
-    # 13^2 layers (K = 1024: 16-pixel tiles re-stream 1 MiB of weights per tile) and the 26^2 backward keep the pairs.
-    pw_fuse = True                     # (tests / A-B scripts flip the class attribute)
-    pw_fwd_px = (20000, 1 << 30)       # pixels M of the layers that take the forward form
-    pw_bwd_px = (50000, 150000)        # ... the backward form
+    # timing of the fused launch against the pair it replaces (scripts/pw_block_ab.py alone, scripts/pw_diag.py inside a serial step;
+    # YOLOv3 416^2 batch 32): the forward form wins where the layer's weights stay resident in LDS -- 52^2: 32.7 vs 43.3 us, 104^2: 61.5
+    # vs 72.7 us -- and is level at 26^2 (25 vs 27 us alone, 29 vs 25 in the step); the backward form is level at 52^2 (48.7 vs 54.9 us
+    # alone, 57 vs 54.5 in the step) and loses elsewhere (13^2, K = 1024: 16-pixel tiles re-stream 1 MiB of weights per tile).  These
+    # layers are HBM-bound and the fold removes one tensor read of four to seven, so the gain is bounded by that ratio.
+    pw_fuse = os.environ.get("MDCV_PW_FUSE", "1") != "0"   # (tests / A-B scripts flip the class attribute)
+    pw_fwd_px = (50000, 1 << 30)       # pixels M of the layers that take the forward form
+    pw_bwd_px = (0, 0)                 # ... the backward form: off (tests and A/B runs set (50000, 150000))
 
     def _pw_ok(self, mode, cs, M, K, N, *lds):
         if not self.pw_fuse or self.dtype != BF16 or not self.training:
