@@ -563,6 +563,93 @@ def gen_post():
         npz(f"post_validate_{name}.npz", **arrs)
 
 
+# ----------------------------------------------------------------------------
+def gen_autocast():
+    """What bf16 costs the REFERENCE's own arithmetic: /root/reference/CVC-YOLOv3/models.Darknet (yolo_baseline topology at 416^2, classes 80)
+    with the weights / batch / targets of tests/test_gpu_models.py::test_full_yolov3_batch32_train_forward_backward_vs_oracle, run once in
+    fp32 and once under torch.autocast("cpu", bfloat16); cosine of every conv weight gradient between the two runs.  The HIP bf16 mode is
+    held to this curve layer by layer.  The CPU oracle's curve (same procedure on oracle/yolo_oracle.py) is stored beside it as a cross-check.
+    usage: make_golden.py autocast [batch=32]"""
+    import json, tempfile, time
+    sys.path.insert(0, os.path.join(REF, "CVC-YOLOv3"))
+    ROOT = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import yolo_oracle as yo
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    S = 416
+    tmp = tempfile.mkdtemp()
+    cfg = bench.write_yolo_cfg(tmp)
+    os.chdir(tmp)                                                # the cfg's train_uri is relative to the CWD (models.py:29-40)
+    import models as ref_models
+    orc = yo.DarknetOracle(cfg, anchors=yo.VANILLA_ANCHORS, seed=3)
+    wpath = os.path.join(tmp, "seed3.weights")
+    orc.save_weights(wpath)
+    ref = ref_models.Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True)
+    ref.load_weights(wpath, [255, 255, 255])                     # the reference's own loader (models.py:339-397)
+    ref.train()
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(B, 3, S, S, generator=g)
+    tg = bench.synth_targets(B, 16, g)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    convs = [(i, m[0]) for i, (d, m) in enumerate(zip(ref.module_defs, ref.module_list)) if d["type"] == "convolutional"]
+    bns = [m[1] for d, m in zip(ref.module_defs, ref.module_list) if d["type"] == "convolutional" and len(m) > 1 and isinstance(m[1], torch.nn.BatchNorm2d)]
+
+    def run_ref(mode):
+        ref.zero_grad()
+        snap = [(b.running_mean.clone(), b.running_var.clone(), b.num_batches_tracked.clone()) for b in bns]
+        t0 = time.time()
+        if mode == "bf16":
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = ref(x, tg)
+        else:
+            out = ref(x, tg)
+        out[0].sum().backward()
+        with torch.no_grad():
+            for b, (rm, rv, nb) in zip(bns, snap):
+                b.running_mean.copy_(rm); b.running_var.copy_(rv); b.num_batches_tracked.copy_(nb)
+        print("reference", mode, "loss %.4f (%.0f s)" % (float(out[0].sum()), time.time() - t0), flush=True)
+        return float(out[0].sum()), {"conv%d.weight" % i: c.weight.grad.detach().double().reshape(-1).clone() for i, c in convs}
+
+    def run_orc(mode):
+        for k in orc.trainable():
+            orc.params[k].requires_grad_(True); orc.params[k].grad = None
+        snap = {k: v.clone() for k, v in orc.params.items() if "running" in k}
+        t0 = time.time()
+        if mode == "bf16":
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = orc.forward(x, tg)
+        else:
+            out = orc.forward(x, tg)
+        out[0].sum().backward()
+        with torch.no_grad():
+            for k, v in snap.items():
+                orc.params[k].copy_(v)
+        print("oracle   ", mode, "loss %.4f (%.0f s)" % (float(out[0].sum()), time.time() - t0), flush=True)
+        return float(out[0].sum()), {k: orc.params[k].grad.detach().double().reshape(-1).clone() for k in orc.trainable()
+                                     if k.endswith("weight") and k.startswith("conv")}
+
+    def cosines(a, b):
+        return {k: round(float(a[k] @ b[k] / (a[k].norm() * b[k].norm() + 1e-30)), 4) for k in a}
+    lr32, gr32 = run_ref("fp32")
+    lr16, gr16 = run_ref("bf16")
+    lo32, go32 = run_orc("fp32")
+    lo16, go16 = run_orc("bf16")
+    cos_ref, cos_orc = cosines(gr32, gr16), cosines(go32, go16)
+    assert set(cos_ref) == set(cos_orc), (sorted(cos_ref)[:5], sorted(cos_orc)[:5])
+    dmax = max(abs(cos_ref[k] - cos_orc[k]) for k in cos_ref)
+    gmax = max(float((gr32[k] - go32[k]).norm() / (go32[k].norm() + 1e-30)) for k in gr32)
+    print("reference vs oracle: max |cos difference| %.4f, max relative fp32 gradient difference %.2e" % (dmax, gmax))
+    out = {"what": "cosine(conv weight gradient under torch.autocast(cpu, bfloat16), same in fp32) of the REFERENCE's models.Darknet "
+                   "(/root/reference/CVC-YOLOv3/models.py) on the yolo_baseline topology; cos_oracle = the same for oracle/yolo_oracle.py",
+           "generator": "tests/golden/make_golden.py autocast", "batch": B, "size": S, "oracle_seed": 3, "data_seed": 21,
+           "targets_per_image": 16, "torch": torch.__version__, "loss": {"fp32": lr32, "bf16": lr16},
+           "loss_oracle": {"fp32": lo32, "bf16": lo16}, "cos": cos_ref, "cos_oracle": cos_orc,
+           "max_abs_cos_difference_reference_vs_oracle": round(dmax, 4), "max_rel_fp32_gradient_difference_reference_vs_oracle": gmax}
+    with open(os.path.join(HERE, "yolo_autocast_bf16_cos.json" if B == 32 else "yolo_autocast_bf16_cos_b%d.json" % B), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"yolo": gen_yolo, "rektnet": gen_rektnet, "post": gen_post}[which]()
+    {"yolo": gen_yolo, "rektnet": gen_rektnet, "post": gen_post, "autocast": gen_autocast}[which]()

@@ -318,12 +318,13 @@ def test_data_parallel_replication_fails_loudly():
 
 
 def test_autocast_gradient_curve_fixture_is_what_the_gpu_test_expects():
-    """tests/golden/yolo_autocast_bf16_cos.json (scripts/ref_autocast_cos.py: the oracle under torch.autocast(bfloat16) against itself in fp32):
-    one cosine per conv layer of yolo_baseline, at the batch / seeds the full-size GPU parity test uses; head convs aligned, conv 0 not."""
+    """tests/golden/yolo_autocast_bf16_cos.json (tests/golden/make_golden.py autocast: the REFERENCE's Darknet under torch.autocast(bfloat16)
+    against itself in fp32): one cosine per conv layer of yolo_baseline, at the batch / seeds the full-size GPU parity test uses; head convs
+    aligned, conv 0 not."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = json.load(open(os.path.join(root, "tests", "golden", "yolo_autocast_bf16_cos.json")))
-    assert os.path.exists(os.path.join(root, d["generator"]))
+    assert os.path.exists(os.path.join(root, d["generator"].split()[0])) and "REFERENCE" in d["what"]
     assert (d["batch"], d["size"], d["oracle_seed"], d["data_seed"], d["targets_per_image"]) == (32, 416, 3, 21, 16)
     assert len(d["cos"]) == 75 and all(0.3 < v <= 1.0 for v in d["cos"].values())
     for head in ("conv81.weight", "conv93.weight", "conv105.weight"):

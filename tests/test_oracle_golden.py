@@ -350,3 +350,15 @@ def test_synth_oracle_heatmap_matches_dense_resize_and_blur():
     vy = SO._blur_reflect101(SO._resize_onehot_axis(iy, oh, 80))
     vx = SO._blur_reflect101(SO._resize_onehot_axis(ix, ow, 80))
     np.testing.assert_allclose(np.outer(vy, vx), blur, atol=1e-7)
+
+
+def test_autocast_bf16_cosine_curve_is_reference_output_and_the_oracle_agrees():
+    """tests/golden/yolo_autocast_bf16_cos.json (the bar of the full-size bf16 GPU test) was produced by the REFERENCE's Darknet under
+    torch.autocast; the same procedure on the oracle, stored beside it, agrees to 1e-3 in every conv layer."""
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yolo_autocast_bf16_cos.json")))
+    assert d["generator"] == "tests/golden/make_golden.py autocast" and d["batch"] == 32 and d["size"] == 416
+    assert set(d["cos"]) == set(d["cos_oracle"]) and len(d["cos"]) == 75
+    assert max(abs(d["cos"][k] - d["cos_oracle"][k]) for k in d["cos"]) <= 1.5e-3
+    assert abs(d["loss"]["fp32"] - d["loss_oracle"]["fp32"]) <= 1e-4 * abs(d["loss"]["fp32"])
+    assert d["max_rel_fp32_gradient_difference_reference_vs_oracle"] < 1e-3
