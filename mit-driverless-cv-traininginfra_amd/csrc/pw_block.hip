@@ -456,7 +456,7 @@ int mdcv_pw_conv_fwd(int dtype, const void* y, int ldy, const float* scale, cons
   if (!y || !w_packed || !out || !mdcv_pw_eligible(dtype, M, K, N, ldy, resid ? ldr : 8, z_out ? ldz : 8, out_ldc)) return MDCV_EARG;
   PwArgs a{};
   a.in0 = y; a.ld0 = ldy; a.in1 = resid; a.ld1 = ldr; a.tout = z_out; a.ldt = ldz;
-  a.scale = scale; a.shift = shift; a.act = act; a.slope = slope;
+  a.scale = scale; a.shift = shift; a.act = act; a.slope = act == 2 ? 0.f : slope;   // (ReLU = slope 0, as mdcv_bn_act_fwd)
   a.w = w_packed; a.w_bytes = (unsigned)((long long)N * K * 2); a.bias = bias; a.out = out; a.out_ldc = out_ldc; a.stats = stats_partial;
   a.M = (int)M; a.K = K; a.N = N; a.ysplit = 1;
   a.fuse = BnFuseArgs{};
@@ -473,7 +473,7 @@ int mdcv_pw_conv_bwd(int dtype, const void* dz, int lddz, const void* y, int ldy
   if (!mdcv_pw_eligible(dtype, M, K, N, lddz, ldy, dy_out ? lddy : 8, dx_ldc) || (addsrc && (add_ldc & 7))) return MDCV_EARG;
   PwArgs a{};
   a.in0 = dz; a.ld0 = lddz; a.in1 = y; a.ld1 = ldy; a.tout = dy_out; a.ldt = lddy;
-  a.scale = scale; a.shift = shift; a.cA = cA; a.cB = cB; a.cC = cC; a.act = act; a.slope = slope;
+  a.scale = scale; a.shift = shift; a.cA = cA; a.cB = cB; a.cC = cC; a.act = act; a.slope = act == 2 ? 0.f : slope;
   a.w = wd_packed; a.w_bytes = (unsigned)((long long)N * K * 2); a.bias = nullptr; a.out = dx; a.out_ldc = dx_ldc;
   a.addsrc = addsrc; a.add_ldc = add_ldc; a.stats = nullptr;
   a.M = (int)M; a.K = K; a.N = N; a.ysplit = 1;
@@ -481,7 +481,7 @@ int mdcv_pw_conv_bwd(int dtype, const void* dz, int lddz, const void* y, int ldy
   if (fy) {
     if (!fscale || !fshift || !fmean || !fpartial || (ldfy & 7)) return MDCV_EARG;
     a.fuse.y = fy; a.fuse.ldy = ldfy; a.fuse.scale = fscale; a.fuse.shift = fshift; a.fuse.mean = fmean; a.fuse.partial = fpartial;
-    a.fuse.act = fact; a.fuse.slope = fslope; a.fuse.row_base = 0;
+    a.fuse.act = fact; a.fuse.slope = fact == 2 ? 0.f : fslope; a.fuse.row_base = 0;
     return dispatch_pw<1, true>(a, (hipStream_t)stream);
   }
   return dispatch_pw<1, false>(a, (hipStream_t)stream);

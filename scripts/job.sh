@@ -1,3 +1,1 @@
-mkdir -p gpurun_out
-( time python bench.py ) > gpurun_out/bench_default.log 2> gpurun_out/bench_default.err
-tail -c 3600 gpurun_out/bench_default.log; tail -5 gpurun_out/bench_default.err
+timeout 1200 python -m pytest tests/test_gpu_models.py -x -q -m gpu -k "pw_block" -s 2>&1 | grep -E "Mismatch|ACTUAL|DESIRED|Max |x:|y:|^pw plans|passed|failed" | cut -c1-400 | head -12

@@ -560,10 +560,11 @@ def test_dgrad_with_fused_bn_sums(case, dt, act, with_add):
         np.testing.assert_allclose(an, bn_, rtol=2e-4, atol=2e-4 * scale_, err_msg=name)
 
 
-@pytest.mark.parametrize("variant", [-8, -9, -12])
+@pytest.mark.parametrize("variant", [-8, -9, -12, -30, -31, -201])
 def test_shift_tile_plans(variant):
-    """Every tuning plan of the 3x3 shift kernel (256 / 128 / mixed rows, 16-wave workgroups, 192-row tiles) gives the forward
-    result and the same BatchNorm statistics as the default plan."""
+    """Every tuning plan of the 3x3 shift kernel (256 / 128 / mixed rows, 192-row tiles; K loop in lockstep (-30) or with ping-pong wave
+    groups on every forward launch (-31); 384-row ping-pong tiles forced (-201)) gives the forward result and the same BatchNorm
+    statistics as the default plan."""
     L = _lib.lib()
     dt = BF16
     g = torch.Generator().manual_seed(5)
@@ -590,10 +591,115 @@ def test_shift_tile_plans(variant):
                 torch.cuda.synchronize()
                 outs.setdefault(v, []).append((y.clone(), stats.sum(0).clone(), dx.clone()))
         finally:
-            L.conv2d_set_variant(-7)
+            L.conv2d_set_variant(-7); L.conv2d_set_variant(-32); L.conv2d_set_variant(-200)
     for (y0, s0, d0), (y1, s1, d1) in zip(outs[-7], outs[variant]):
         assert torch.equal(y0, y1) and torch.equal(d0, d1)
         np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=1e-4, atol=1e-2)
+
+
+PW_CASES = [  # (M, K, N, extra channel stride, resid, act)
+    (64 * 21 + 17, 256, 128, 0, True, 1), (64 * 9, 128, 64, 8, True, 1), (3000, 64, 128, 0, False, 1), (32 * 40 + 5, 512, 256, 16, True, 1),
+    (16 * 70 + 3, 1024, 512, 0, True, 1), (2000, 256, 24, 0, False, 2), (1100, 128, 256, 8, True, 0), (70000, 256, 128, 0, True, 1)]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=[str(c) for c in PW_CASES])
+def test_pw_block_forward(case):
+    """mdcv_pw_conv_fwd (BatchNorm-apply + activation (+ residual) folded into the operand load of a 1x1 conv) == the pair mdcv_bn_act_fwd +
+    mdcv_conv2d bit for bit (z, out), == a torch fp32 reference within bf16 rounding; its partial statistics sum to the pair's."""
+    L = _lib.lib()
+    M, K, N, xs, with_r, act = case
+    g = torch.Generator().manual_seed(M + K + N)
+    ldy, ldz, ldo = K + xs, K + 2 * xs, N + xs
+    y = (torch.randn(M, ldy, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    r = torch.randn(M, ldy, generator=g).to(torch.bfloat16).cuda() if with_r else None
+    scale = (torch.rand(K, generator=g) + 0.5).cuda(); shift = (torch.randn(K, generator=g) * 0.3).cuda()
+    w = torch.randn(N, K, 1, 1, generator=g) / K ** 0.5
+    wf, _ = pack(BF16, w, need_d=False)
+    bias = (torch.randn(pad8(N), generator=g) * 0.1).cuda() if act == 2 else None
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    z0 = torch.zeros(M, ldz, dtype=torch.bfloat16, device="cuda"); z1 = torch.zeros_like(z0)
+    o0 = torch.zeros(M, ldo, dtype=torch.bfloat16, device="cuda"); o1 = torch.zeros_like(o0)
+    rows0 = L.conv2d_stats_rows_geom(BF16, 1, M, 1, K, N, 1, 1, 1, 0, 1, ldz)
+    rows1 = L.pw_rows(M, K)
+    s0 = torch.zeros(rows0, 2, N, device="cuda"); s1 = torch.full((rows1, 2, N), float("nan"), device="cuda")
+    L.check(L.bn_act_fwd(BF16, y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), None, 0, None, None, P(r), ldy, z0.data_ptr(), ldz, M, K,
+                         act, 0.1, st()))
+    L.check(L.conv2d(BF16, 0, z0.data_ptr(), ldz, wf.data_ptr(), o0.data_ptr(), ldo, P(bias), None, 0, s0.data_ptr(), 1, M, 1, K, M, 1, N,
+                     1, 1, 1, 0, 1, st()))
+    L.check(L.pw_conv_fwd(BF16, y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), P(r), ldy, act, 0.1, z1.data_ptr(), ldz, wf.data_ptr(),
+                          P(bias), o1.data_ptr(), ldo, s1.data_ptr(), M, K, N, st()), "pw_conv_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(z0, z1)
+    assert torch.equal(o0[:, :N], o1[:, :N]) and float(o1[:, N:].abs().max() if ldo > N else 0) == 0
+    assert not bool(torch.isnan(s1).any())
+    np.testing.assert_allclose(s1.sum(0).cpu().numpy(), s0.sum(0).cpu().numpy(), rtol=2e-4, atol=2e-2)
+    zf = y[:, :K].float().cpu() * scale.cpu() + shift.cpu()
+    zf = zf if act == 0 else torch.where(zf > 0, zf, zf * (0.1 if act == 1 else 0.0))
+    if with_r:
+        zf = zf + r[:, :K].float().cpu()
+    assert float((z1[:, :K].float().cpu() - zf).abs().max()) <= 2 ** -7 * float(zf.abs().max())
+    of = z1[:, :K].float().cpu() @ w.reshape(N, K).to(torch.bfloat16).float().t() + (bias[:N].cpu() if bias is not None else 0)
+    assert float((o1[:, :N].float().cpu() - of).abs().max()) <= 1e-2 * float(of.abs().max())
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["plain", "bnsums"])
+@pytest.mark.parametrize("case", PW_CASES[:7], ids=[str(c) for c in PW_CASES[:7]])
+def test_pw_block_backward(case, fused):
+    """mdcv_pw_conv_bwd (BatchNorm-backward apply folded into the operand load of a 1x1 data gradient, optional fused BatchNorm-backward
+    sums of the producer layer) == mdcv_bn_act_bwd_apply + mdcv_conv2d(mode 1) bit for bit (dy, dx); its partial sums finalize to the
+    coefficients of the stand-alone reduce over the same stored dx."""
+    L = _lib.lib()
+    M, K, N, xs, with_add, act = case          # K = channels of dz / y (the 1x1 layer's outputs), N = channels of dx (its inputs)
+    if N % 8 or N < 64:
+        pytest.skip("dx channels below one consumer tile are not planned through this path")
+    g = torch.Generator().manual_seed(M + K + N + 1)
+    ldk, ldn = K + xs, N + xs
+    dz = torch.randn(M, ldk, generator=g).to(torch.bfloat16).cuda()
+    y = (torch.randn(M, ldk, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    scale = (torch.rand(K, generator=g) + 0.5).cuda(); shift = (torch.randn(K, generator=g) * 0.3).cuda()
+    cA = (torch.rand(K, generator=g) + 0.5).cuda(); cB = (torch.randn(K, generator=g) * 0.02).cuda(); cC = (torch.randn(K, generator=g) * 0.02).cuda()
+    w = torch.randn(K, N, 1, 1, generator=g) / K ** 0.5          # the layer's weight [Cout = K][Cin = N]
+    _, wd = pack(BF16, w)
+    add = torch.randn(M, ldn, generator=g).to(torch.bfloat16).cuda() if with_add else None
+    fy = (torch.randn(M, ldn, generator=g) * 1.3 + 0.2).to(torch.bfloat16).cuda()
+    fsc = (torch.rand(N, generator=g) + 0.5).cuda(); fsh = (torch.randn(N, generator=g) * 0.3).cuda()
+    fmean = (torch.randn(N, generator=g) * 0.2 + 0.2).cuda(); finv = (torch.rand(N, generator=g) + 0.5).cuda(); gamma = (torch.rand(N, generator=g) + 0.5).cuda()
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    dy0 = torch.zeros(M, ldk, dtype=torch.bfloat16, device="cuda"); dy1 = torch.zeros_like(dy0)
+    dx0 = torch.zeros(M, ldn, dtype=torch.bfloat16, device="cuda"); dx1 = torch.zeros_like(dx0)
+    L.check(L.bn_act_bwd_apply(BF16, dz.data_ptr(), ldk, y.data_ptr(), ldk, scale.data_ptr(), shift.data_ptr(), cA.data_ptr(), cB.data_ptr(),
+                               cC.data_ptr(), dy0.data_ptr(), ldk, None, 0, None, None, None, None, None, None, 0, M, K, act, 0.1, st()))
+    L.check(L.conv2d(BF16, 1, dy0.data_ptr(), ldk, wd.data_ptr(), dx0.data_ptr(), ldn, None, P(add), ldn, None, 1, M, 1, K, M, 1, N, 1, 1, 1, 0, 1,
+                     st()))
+    rows = L.pw_rows(M, K)
+    part = torch.full((rows, 2, N), float("nan"), device="cuda")
+    L.check(L.pw_conv_bwd(BF16, dz.data_ptr(), ldk, y.data_ptr(), ldk, scale.data_ptr(), shift.data_ptr(), cA.data_ptr(), cB.data_ptr(), cC.data_ptr(),
+                          act, 0.1, dy1.data_ptr(), ldk, wd.data_ptr(), dx1.data_ptr(), ldn, P(add), ldn, fy.data_ptr() if fused else None, ldn,
+                          fsc.data_ptr(), fsh.data_ptr(), fmean.data_ptr(), 1, 0.1, part.data_ptr(), M, K, N, st()), "pw_conv_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(dy0, dy1) and torch.equal(dx0[:, :N], dx1[:, :N])
+    pre = y[:, :K].float().cpu() * scale.cpu() + shift.cpu()
+    gg = dz[:, :K].float().cpu() * (1.0 if act == 0 else torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, 0.1 if act == 1 else 0.0)))
+    dyf = cA.cpu() * gg + cB.cpu() * y[:, :K].float().cpu() + cC.cpu()
+    assert float((dy1[:, :K].float().cpu() - dyf).abs().max()) <= 2 ** -7 * float(dyf.abs().max())
+    dxf = dy1[:, :K].float().cpu() @ w.reshape(K, N).to(torch.bfloat16).float() + (add[:, :N].float().cpu() if with_add else 0)
+    assert float((dx1[:, :N].float().cpu() - dxf).abs().max()) <= 1e-2 * float(dxf.abs().max())
+    if fused:
+        assert not bool(torch.isnan(part).any())
+        acc = torch.zeros(3 * N, dtype=torch.float64, device="cuda")
+        pws = torch.empty(L.bn_act_bwd_reduce_ws_floats(BF16, M, N, 2), device="cuda")
+        dxc = dx0[:, :N].contiguous(); fyc = fy[:, :N].contiguous()
+        L.check(L.bn_act_bwd_reduce(BF16, dxc.data_ptr(), N, fyc.data_ptr(), N, fsc.data_ptr(), fsh.data_ptr(), fmean.data_ptr(), finv.data_ptr(),
+                                    None, 0, None, None, None, None, acc.data_ptr(), pws.data_ptr(), M, N, 1, 0.1, st()))
+        ref = [torch.zeros(N, device="cuda") for _ in range(5)]
+        L.check(L.bn_bwd_finalize(acc.data_ptr(), 1, 2, 1, float(M), gamma.data_ptr(), fmean.data_ptr(), finv.data_ptr(), *[b.data_ptr() for b in ref], N, st()))
+        got = [torch.zeros(N, device="cuda") for _ in range(5)]
+        L.check(L.bn_bwd_finalize_rows(part.data_ptr(), rows, N, float(M), gamma.data_ptr(), fmean.data_ptr(), finv.data_ptr(),
+                                       *[b.data_ptr() for b in got], st()))
+        torch.cuda.synchronize()
+        for a, b, name in zip(got, ref, ("dgamma", "dbeta", "cA", "cB", "cC")):
+            an, bn_ = a.cpu().numpy(), b.cpu().numpy()
+            np.testing.assert_allclose(an, bn_, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(bn_).max())), err_msg=name)
 
 
 WGRAD_SHIFT_CASES = [(2, 128, 13, 13, 128), (3, 128, 26, 20, 256), (1, 256, 52, 52, 128), (5, 128, 9, 8, 128), (32, 128, 13, 13, 256),
