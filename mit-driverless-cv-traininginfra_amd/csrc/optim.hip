@@ -96,26 +96,35 @@ int mdcv_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); 
 // Cross-stream ordering inside one device: everything enqueued on `from` so far happens before what is enqueued on `to` afterwards.
 // One event record + one stream wait, on events of a per-device ring created WITHOUT timing and (device_scope != 0) with
 // hipEventReleaseToDevice: the default event releases to SYSTEM scope, which a consumer kernel on the same GPU does not need.
-// Re-recording a ring event is legal once its wait is enqueued (the wait captured the record it saw).
+// Re-recording a ring event is legal once its wait is enqueued (the wait captured the record it saw) -- so record AND wait happen under
+// the ring's lock: with more than RING forks in flight from other threads a slot could otherwise be re-recorded between this thread's
+// record and its wait.  The ring is that of the device OWNING `from` (hipStreamGetDevice; the legacy NULL stream counts for the current
+// device), not of whatever device is current.  Scope: the device-scope release orders the producer's writes for consumers ON THE SAME
+// GPU only; a host or peer-GPU reader needs device_scope == 0.
 int mdcv_stream_fork(void* from, void* to, int device_scope) {
   constexpr int RING = 64, MAXDEV = 16;
   static hipEvent_t ring[MAXDEV][2][RING];
   static unsigned head[MAXDEV][2];
   static std::mutex mu;
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return (int)e;
+  int dev = 0, cur = 0;
+  hipError_t e = hipGetDevice(&cur); if (e != hipSuccess) return (int)e;
+  dev = cur;
+  if (from) {
+    hipDevice_t sd;
+    if (hipStreamGetDevice((hipStream_t)from, &sd) == hipSuccess) dev = (int)sd;
+    else (void)hipGetLastError();
+  }
   if (dev < 0 || dev >= MAXDEV) return MDCV_EARG;
   const int sc = device_scope ? 1 : 0;
-  hipEvent_t ev;
-  {
-    std::lock_guard<std::mutex> g(mu);
-    const unsigned i = head[dev][sc]++ % RING;
-    if (!ring[dev][sc][i]) {
-      e = hipEventCreateWithFlags(&ring[dev][sc][i], hipEventDisableTiming | (sc ? hipEventReleaseToDevice : 0u));
-      if (e != hipSuccess) { ring[dev][sc][i] = nullptr; return (int)e; }
-    }
-    ev = ring[dev][sc][i];
+  std::lock_guard<std::mutex> g(mu);
+  const unsigned i = head[dev][sc]++ % RING;
+  if (!ring[dev][sc][i]) {
+    if (dev != cur) { e = hipSetDevice(dev); if (e != hipSuccess) return (int)e; }     // events belong to the device current at creation
+    e = hipEventCreateWithFlags(&ring[dev][sc][i], hipEventDisableTiming | (sc ? hipEventReleaseToDevice : 0u));
+    if (dev != cur) (void)hipSetDevice(cur);
+    if (e != hipSuccess) { ring[dev][sc][i] = nullptr; return (int)e; }
   }
+  const hipEvent_t ev = ring[dev][sc][i];
   e = hipEventRecord(ev, (hipStream_t)from); if (e != hipSuccess) return (int)e;
   return (int)hipStreamWaitEvent((hipStream_t)to, ev, 0);
 }

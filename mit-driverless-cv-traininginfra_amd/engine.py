@@ -80,12 +80,24 @@ def checked_stream(device, beside, key):
     k = (idx, key) + tuple(s.cuda_stream for s in beside)
     s = _SIDE_STREAMS.get(k)
     if s is None:
+        if torch.cuda.is_current_stream_capturing():   # the probe synchronises: never inside a graph capture
+            return torch.cuda.Stream(device=device)
+        ok = False
         with torch.cuda.device(device):
             for _ in range(16):                        # torch hands out its pool streams round-robin: a few tries walk the hardware queues
                 s = torch.cuda.Stream(device=device)
                 if _runs_beside(beside, s):
+                    ok = True
                     break
-        _SIDE_STREAMS[k] = s
+        if ok:
+            _SIDE_STREAMS[k] = s
+        else:
+            # a busy or shared GPU can fail the 1.5x timing test for every candidate: use the last one for now, say so, and probe
+            # again on the next call instead of caching a stream known to have failed
+            import warnings
+            warnings.warn(f"mdcv: no stream of {device} was measured to run beside {key!r}'s partners (16 candidates; busy or shared GPU, "
+                          "or too few hardware queues -- GPU_MAX_HW_QUEUES=8 gives HIP more): overlap of this stream is not guaranteed",
+                          RuntimeWarning, stacklevel=2)
     return s
 
 

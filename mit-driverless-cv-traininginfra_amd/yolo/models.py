@@ -223,14 +223,19 @@ class _NetPlan(Plan):
 
     err_views = ()        # int32 one-element views of the YOLO heads' `err` words (training plans)
 
-    def check_targets(self):
+    def check_targets(self, block=True):
         """Raises IndexError if the targets of the LAST forward through this plan held a centre coordinate >= 1.0 (the reference's
         build_targets indexes its [B,A,G,G] tensors with gi == G there and raises, utils/utils.py:262; the fused head drops the
-        target and sets a flag).  The flags ride to a pinned host word with a non-blocking copy behind every forward; the
-        training loop looks at them at the start of the NEXT forward, so a bad label surfaces one step late but without a sync."""
+        target and sets a flag).  The flags ride to a pinned host word with a non-blocking copy behind every forward and are
+        looked at (i) when the backward of that step starts -- waiting for the copy (one host wait per step, ~20 us of GPU idle between
+        forward and backward: a bad label then raises BEFORE optimizer.step(), like the reference) unless the model sets
+        `strict_targets = False`, in which case the look is a query and a copy that has not landed stays pending --, (ii) at the
+        start of the NEXT forward and (iii) when the plan is dropped."""
         ev = getattr(self, "_err_event", None)
         if ev is None:
             return
+        if not block and not ev.query():
+            return                                           # not landed yet: the next forward (or the plan's eviction) looks again
         self._err_event = None
         ev.synchronize()
         if bool(self._err_host.any()):
@@ -390,20 +395,29 @@ class FlatParamsMixin:
 
     def _evict_plan(self, key):
         plan = self._plans.pop(key)
+        try:
+            if getattr(self, "_pipe_plan", None) is plan:
+                self._param_sync()                           # its deferred parameter-group updates must land first
+                self._pipe_plan = None
+        finally:
+            if getattr(self, "_last_train_plan", None) is plan:
+                self._last_train_plan = None
         if getattr(plan, "err_views", ()) and _CHECK_TARGETS:
-            plan.check_targets()                             # a pending bad-label flag must not be lost with the plan (last batch of a run)
-        if getattr(self, "_pipe_plan", None) is plan:
-            self._param_sync()                               # its deferred parameter-group updates must land first
-            self._pipe_plan = None
-        if getattr(self, "_last_train_plan", None) is plan:
-            self._last_train_plan = None
+            plan.check_targets()                             # a pending bad-label flag must not be lost with the plan (last batch of a run);
+                                                             # raised AFTER the bookkeeping above, so the model is consistent when it does
         # the plan's buffers go back to the caching allocator when the last reference dies (an autograd graph that still needs the
         # plan for its backward holds one); every stream that used them was joined into the current stream at the end of its step
 
     def release_plans(self):
         """Drop every cached launch plan (and its HBM buffers); the next forward rebuilds what it needs."""
+        err = None
         for k in list(getattr(self, "_plans", {})):
-            self._evict_plan(k)
+            try:
+                self._evict_plan(k)
+            except IndexError as e:                          # a pending bad-label flag: drop every plan first, then report it
+                err = e
+        if err is not None:
+            raise err
 
     def _params_changed(self):
         """Parameters were rewritten behind the optimizer's back (load_weights / load_state_dict): operands packed ahead of the next
@@ -449,7 +463,7 @@ class FlatParamsMixin:
         # a label with cx / cy >= 1.0 (reference: IndexError inside build_targets, BEFORE any update, utils/utils.py:262): the flag copy
         # recorded behind the forward has almost always landed by now, so raising here precedes optimizer.step()
         if getattr(plan, "err_views", ()) and _CHECK_TARGETS:
-            plan.check_targets()
+            plan.check_targets(block=getattr(self, "strict_targets", True))
         pl = self._plist
         keep = None
         if pl[0].grad is not None:                       # gradients were not reset to None: accumulate semantics
