@@ -49,7 +49,7 @@ int g_conv_deep_small = 8;   // 128x128 and 128x64 tiles take the 3-stage DMA ri
                              // Same-box A/B of the YOLOv3 step: never 2031, from 4 steps 2045, from 8 2050, from 16 2045, from 32 2034 img/s
 int g_conv_fuse_narrow = 1;  // (set_variant 92 = off) 1x1 data gradients with fused BatchNorm sums take 128x64 tiles on the 3-stage ring: their store loop (loads of
                              // the shortcut gradient and y, sums, partial-row flush) is serial per workgroup, and three or four narrow workgroups per CU overlap it
-                             // better than one or two wide ones.  Alone (scripts/pw_ab_dgrad.py): 52^2 60 -> 47 us, 104^2 103 -> 78, 26^2 35 -> 32, 13^2 21.5 -> 20
+                             // better than one or two wide ones.  Alone (round-2 A/B): 52^2 60 -> 47 us, 104^2 103 -> 78, 26^2 35 -> 32, 13^2 21.5 -> 20
 int g_conv_variant = -1;   // -1: heuristic ; >= 0: forced tile configuration for wide layers (tuning / A-B benchmarking)
 int g_conv_tall_s2 = 1;      // (set_variant 18 = off; +0.3 % on the YOLOv3 step) the tall narrow tiles for the parity-class launches too
 int g_conv_deep_s2 = 1;      // (set_variant 20 = off; +0.6 % on the YOLOv3 step, same-box A/B) 3-stage ring for the parity-class launches of the stride-2 data gradients
@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 // weight gradient, bf16 production kernel: LDS-DMA + hardware transpose reads.
 // Operand tiles are DMA'ed in their natural HBM order [pixel][128 channels] (256-byte rows, 4 pixel rows per 1 KiB chunk);
 // MFMA fragments need 8 consecutive PIXELS per channel, which ds_read_b64_tr_b16 delivers for free: a 16-lane group reads a
-// 4(pixel) x 16(channel) block and lane i receives column i (verified on MI355X, scripts/probe_tr.py).  Two such reads make one
+// 4(pixel) x 16(channel) block and lane i receives column i (verified on MI355X with a probe kernel in round 1).  Two such reads make one
 // 16x16x32 fragment.  Bank conflicts between the 4 pixel rows of a block (256 B apart = same banks) are removed by a
 // source-side XOR of the 16-byte column index with 2*(pixel & 7).  No ds_write, no VGPR staging, one barrier per 64-pixel step.
 // ------------------------------------------------------------------------------------------------
@@ -1967,7 +1967,7 @@ int mdcv_conv2d_wgrad_set_variant(int v) {   /* tuning hook; 1000 + 100*d + bloc
   return MDCV_OK;
 }
 int mdcv_conv2d_set_variant(int v) {
-  // tuning / A-B hook of the conv family (tests walk the tile variants; scripts/ab_env.sh runs whole steps under a setting).  -1: heuristics.
+  // tuning / A-B hook of the conv family (tests walk the tile variants; scripts/ab_step.py times whole steps under a setting).  -1: heuristics.
   //   0..11  forced tile configuration of wide layers (0-5 register-staged kernels, 6-11 LDS-DMA: 128x128 / 128x64 / 256x128 x 2 / 3 stages); 100 + v: generic address path
   //   14/15  sparse stride-2 data gradients: four class launches / one launch with two workgroups per tile     4000+n  'sparse' = below n tiles
   //   16/17  stride-2 data gradient as four parity-class launches / one launch        18/19, 20/21  its tall tiles, its 3-stage ring off / on

@@ -550,7 +550,7 @@ class Plan:
 
     fuse_skip = 141                    # bit mask of the geometry classes of _fuse_pays that keep the stand-alone reduce pass (0: fuse all);
                                        # 128 (round 3): the sparse stride-2 data gradients 13->26 / 26->52, whose fused store loops ran once per parity
-                                       # class and cost 100 us against 20-28 us for the stand-alone pass (same-box A/B scripts/ab_fuse.py: -0.07 ms per step)
+                                       # class and cost 100 us against 20-28 us for the stand-alone pass (same-box A/B, scripts/ab_step.py "F13;F141": -0.07 ms per step)
     # Data gradients whose fused sums would take more than this many partial rows (RektNet's 80^2 x 256 tensors: 12 800; YOLOv3's 208^2 / 416^2
     # layers) keep the stand-alone reduce pass.  The finalize can take them since round 2 (rows beyond 4096 are folded in place first,
     # csrc/elementwise.hip), but the fused store loops still lose on these HBM-bound layers: RektNet 31.99k -> 31.34k img/s, YOLOv3 2136 -> 2118
@@ -562,7 +562,7 @@ class Plan:
         that keep the stand-alone pass; 0: fuse every eligible data gradient).  The fused store loop runs at the END of every tile;
         when the launch is a single round of workgroups over a large dx tensor nothing hides it and the stand-alone pass (full HBM
         rate) wins.  Classes by pixels of dx (yolo_baseline 416^2 at batch 32 in brackets), chosen by same-box A/B of the whole
-        step (`scripts/ab_fuse_policy.sh`), not by the isolated per-launch times, which rank them differently."""
+        step (scripts/ab_step.py "F<mask>;..."), not by the isolated per-launch times, which rank them differently."""
         B, dyH, dyW, cdy, xH, xW, cdx, kh, kw, stride, pad, dil = geom
         px = B * xH * xW
         k = self.fuse_skip
