@@ -1922,7 +1922,7 @@ int mdcv_conv2d_dgrad_bnsums_rows(int dtype, int B, int Hin, int Win, int Cin, i
   if (dtype != MDCV_BF16) return 0;     // production dtype only: not every fp32 tile variant carries the fused store loop
   if ((long long)B * Hin * Win * in_ldc * es >= (1LL << 31) || (long long)Nout * KH * KW * Cin * es >= (1LL << 31)) return 0;
   if (Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc))
-    return mdcv_shift_stats_rows(B, Hout, Wout, dil);
+    return mdcv_shift_stats_rows(B, Hout, Wout, dil, Nout);
   if (stride == 2 && dil == 1) {
     int rows = 0;
     for (int cls = 0; cls < 4; ++cls) {

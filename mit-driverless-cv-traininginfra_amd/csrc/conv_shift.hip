@@ -51,6 +51,7 @@ int g_shift_loop = env_int("MDCV_SHIFT_LOOP", 2);   // K-loop form of the FORWAR
                         // DMAs) ; 2 (default) ping-pong for grids of at most one workgroup per CU, where no second workgroup fills the
                         // read phase (13^2 512->1024 forward 52.5 -> 48.9 us), and 384-row ping-pong tiles where they make ONE round of
                         // 193..256 workgroups (26^2 256->512 forward 44.6 -> 42.4 us).  Denser grids: +1..2 % alone, data gradients -5..+3 %.
+int g_shift_2d = env_int("MDCV_SHIFT_2D", 1);   // images wider than the 1-D stream takes (below) run as 2-D pixel tiles of 8 x 30 outputs (set_variant(-27) off / (-28) on)
 int g_shift_big = env_int("MDCV_SHIFT_BIG", 0);   // A/B: 384 forces the 384-row ping-pong tiles on every forward launch they fit
 int g_shift_plan = 0;   // 0 / 5: default plan (192-row tiles where they save a round) ; 1: 256-row tiles only ; 2: 128-row only ; 6: never 192-row
 #else
@@ -63,6 +64,7 @@ extern int g_shift_wmax;
 extern int g_shift_plan;
 extern int g_shift_loop;
 extern int g_shift_big;
+extern int g_shift_2d;
 #endif
 int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes);   // defined by part 1
 
@@ -135,11 +137,23 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 #pragma unroll
   for (int k = 0; k < NPA; ++k) {
     const int j = (wave + k * NW) * 16 + lrow;             // LDS row of the activation chunk
-    const int t = p0 + j - a.dil * (a.Wq + 1);
-    bool ok = t >= 0 && t < a.Mq;
-    const int tt = ok ? t : 0;
-    const int img = tt / a.Sq, rem = tt - img * a.Sq;
-    const int yy = rem / a.Wq, xx = rem - yy * a.Wq;
+    int img, yy, xx;
+    bool ok;
+    if (a.t2d) {                                           // 2-D pixel tile: chunk row j = (row cy, column cx) of the tile with its halo ring
+      const int tpi = a.tiles_x * a.tiles_y;
+      img = tile_m / tpi;
+      const int rt = tile_m - img * tpi, ty = rt / a.tiles_x, tx = rt - ty * a.tiles_x;
+      const int cy = j / a.Wq, cx = j - cy * a.Wq;
+      yy = ty * a.TH - 1 + cy; xx = tx * (a.Wq - 2) - 1 + cx;
+      ok = yy >= 0 && xx >= 0;
+    } else {
+      const int t = p0 + j - a.dil * (a.Wq + 1);
+      ok = t >= 0 && t < a.Mq;
+      const int tt = ok ? t : 0;
+      img = tt / a.Sq;
+      const int rem = tt - img * a.Sq;
+      yy = rem / a.Wq; xx = rem - yy * a.Wq;
+    }
     ok = ok && yy < a.H && xx < a.W;
     avo[k] = ok ? (unsigned)((((img * a.H + yy) * a.W + xx) * a.in_ldc + kv * 8) * 2) : OOB;
   }
@@ -339,11 +353,23 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   // ---------------- epilogue ----------------
   int* rowpix = reinterpret_cast<int*>(smem + PIX_OFF);
   if (tid < BM) {
-    const int p = p0 + tid;
-    bool ok = p < a.Mq;
-    const int pp = ok ? p : 0;
-    const int img = pp / a.Sq, rem = pp - img * a.Sq;
-    const int y = rem / a.Wq, x = rem - y * a.Wq;
+    int img, y, x;
+    bool ok;
+    if (a.t2d) {                                           // output position tid of the tile: row tid / Wq, column tid % Wq; the last two columns are junk
+      const int tpi = a.tiles_x * a.tiles_y;
+      img = tile_m / tpi;
+      const int rt = tile_m - img * tpi, ty = rt / a.tiles_x, tx = rt - ty * a.tiles_x;
+      const int ly = tid / a.Wq, lx = tid - ly * a.Wq;
+      y = ty * a.TH + ly; x = tx * (a.Wq - 2) + lx;
+      ok = lx < a.Wq - 2 && ly < a.TH;
+    } else {
+      const int p = p0 + tid;
+      ok = p < a.Mq;
+      const int pp = ok ? p : 0;
+      img = pp / a.Sq;
+      const int rem = pp - img * a.Sq;
+      y = rem / a.Wq; x = rem - y * a.Wq;
+    }
     ok = ok && y < a.H && x < a.W;
     rowpix[tid] = ok ? (img * a.H + y) * a.W + x : -1;
   }
@@ -613,6 +639,7 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128, b
 
 template <int MODE, int BN_>
 int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
+  if (a.t2d) return launch_shift_bm<MODE, 256, BN_>(a, 0, a.Mq / 256, st, in_bytes, w_bytes);   // one 8 x 32 position tile per workgroup
   const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr, 2 * a.dil * (a.Wq + 1), BN_, MODE == 0);
   if constexpr (BN_ == 128 && MODE == 0) {
     if (bm == 384) return launch_shift_bm<MODE, 384, BN_>(a, 0, (a.Mq + 383) / 384, st, in_bytes, w_bytes);
@@ -639,21 +666,39 @@ int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_byte
 }
 #else
 // ---- host side (internal linkage across the library's objects: declared in conv_shift.h)
+// The 1-D position stream keeps a tile's 256 positions + 2 (W+1) + 2 halo rows in LDS: up to W = 62 the chunk is 384 rows, up to 80 (104 for
+// the 64- / 32-wide tiles with their smaller weight ring) two workgroups still fit a CU.  Wider images (YOLOv3's 208^2 layers, the 104^2
+// layers with 128 output channels, 152^2 / 304^2 at 608^2) are cut into 2-D pixel tiles instead: 8 rows x 30 columns of outputs per
+// workgroup, stored with a one-pixel halo ring as a [10][32] mini-image whose taps are again pure row displacements kh * 32 + kw; the
+// two positions per row whose window would wrap are junk (6 %), the chunk is 322 rows however wide the image is.  Same kernel, same
+// K loop: only the DMA source addresses and the position -> pixel table of the epilogue differ (ShiftArgs.t2d).
+static bool shift_fits_1d(int W, int Nout) {
+  return W <= g_shift_wmax || (g_shift_wmax_narrow && Nout <= 64 && W <= g_shift_wmax_narrow) || (g_shift_wmax_n32 && Nout <= 32 && W <= g_shift_wmax_n32);
+}
+static bool shift_is_2d(int W, int Nout, int dil) { return dil == 1 && g_shift_2d && !shift_fits_1d(W, Nout); }
+constexpr int T2D_WQ = 32, T2D_TH = 8;                      // tile = 8 x 32 positions = 256 (30 output columns + 2 junk)
+static long long shift_2d_positions(int B, int H, int W) { return (long long)B * ((H + T2D_TH - 1) / T2D_TH) * ((W + T2D_WQ - 3) / (T2D_WQ - 2)) * 256; }
+
 bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc) {
   if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != dil || (dil != 1 && !(dil == 2 && g_shift_dil2))) return false;
   // dilation 2 pays where the halo-heavy chunk is amortised over >= 2 channel chunks and two workgroups still fit a CU (narrow tiles):
   // RektNet data gradient 128->64 412 -> 332 us, 64->32 193 -> 183 us; forward 64->128 (128-wide tile, one workgroup per CU) 281 -> 360 us
   if (dil == 2 && g_shift_dil2 == 1 && !(Nout <= 64 && Cin >= 64)) return false;
   if ((Cin & 31) || Cin < 32 || ((Nout & 127) && !(Nout == 64 && g_shift_n64) && !(Nout == 32 && g_shift_n64 == 2))) return false;   // 128-wide tiles, or one 64-wide tile column
-  if (H < 8 || W < 8 || (W > g_shift_wmax && !(g_shift_wmax_narrow && Nout <= 64 && W <= g_shift_wmax_narrow) && !(g_shift_wmax_n32 && Nout <= 32 && W <= g_shift_wmax_n32))) return false;        // 62: chunk rows 256 + 2(W+1) + 2 <= 384; up to 86 two workgroups still fit a CU
-  if ((long long)B * (H + dil) * (W + dil) + 1024 >= (1LL << 30)) return false;
+  if (H < 8 || W < 8) return false;
+  if (!shift_fits_1d(W, Nout) && !(g_shift_2d && dil == 1)) return false;   // wider rows: 2-D pixel tiles (dilation 1 only), or not at all
+  if ((long long)B * (H + dil) * (W + dil) + 1024 >= (1LL << 30) || shift_2d_positions(B, H, W) >= (1LL << 30)) return false;
   if ((long long)B * H * W * in_ldc * 2 >= (1LL << 31) || (long long)Nout * 9 * Cin * 2 >= (1LL << 31)) return false;
   return true;
 }
 
-int mdcv_shift_stats_rows(int B, int H, int W, int dil) { return (int)(((long long)B * (H + dil) * (W + dil) + 127) / 128); }
+int mdcv_shift_stats_rows(int B, int H, int W, int dil, int Nout) {
+  if (shift_is_2d(W, Nout, dil)) return (int)(shift_2d_positions(B, H, W) / 128);
+  return (int)(((long long)B * (H + dil) * (W + dil) + 127) / 128);
+}
 // rows of the FORWARD statistics buffer: one per 128 stream positions, or one per tile when the plan picks 192-row tiles
 int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil) {
+  if (shift_is_2d(W, Nout, dil)) return (int)(shift_2d_positions(B, H, W) / 128);
   const int Mq = B * (H + dil) * (W + dil);
   const int bn = Nout <= 64 ? Nout : BN;
   const int bm = shift_plan_bm(Mq, Nout <= 64 ? 1 : Nout / BN, false, 2 * dil * (W + dil + 1), bn, true);
@@ -670,6 +715,12 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   a.in_ldc = in_ldc; a.out_ldc = out_ldc; a.add_ldc = add_ldc;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Nout = Nout;
   a.dil = dil; a.Wq = W + dil; a.Sq = (H + dil) * (W + dil); a.Mq = B * a.Sq;
+  a.t2d = 0; a.tiles_x = a.tiles_y = a.TH = 0;
+  if (shift_is_2d(W, Nout, dil)) {
+    a.t2d = 1; a.Wq = T2D_WQ; a.TH = T2D_TH;
+    a.tiles_x = (W + T2D_WQ - 3) / (T2D_WQ - 2); a.tiles_y = (H + T2D_TH - 1) / T2D_TH;
+    a.Mq = (int)shift_2d_positions(B, H, W); a.Sq = a.tiles_x * a.tiles_y * 256;
+  }
   a.tiles_n = Nout <= 64 ? 1 : Nout / BN;
   a.tiles_total = 0; a.xcd_chunk = 0; a.nca = 0; a.p_base = 0;
   a.nchunks = Cin / 32;
@@ -682,7 +733,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   return launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring == 27 || ring == 28) { g_shift_2d = ring - 27; return; } if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

@@ -1002,6 +1002,74 @@ def test_shift_conv_64_wide_tile_column(case):
     torch.testing.assert_close(outs[-17][1], outs[-18][1], rtol=2e-3, atol=0.5)
 
 
+T2D_CASES = [(2, 32, 208, 208, 64), (1, 64, 208, 208, 32), (3, 64, 104, 104, 128), (2, 32, 97, 131, 128), (1, 128, 9, 161, 128), (2, 32, 41, 300, 32)]
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["plain", "bnsums"])
+@pytest.mark.parametrize("case", T2D_CASES, ids=[str(c) for c in T2D_CASES])
+def test_shift_conv_2d_tiles(case, fused):
+    """Images wider than the 1-D position stream takes run the shift kernel over 2-D pixel tiles (8 x 30 outputs + halo ring; variant -28,
+    the default) == the im2col kernel (-27) == torch: forward with BatchNorm statistics, data gradient with addsrc and (fused) the
+    BatchNorm-backward sums of the producer layer; ragged right / bottom tiles included."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, H, W, Co = case
+    gg = torch.Generator().manual_seed(B + Ci + W + 5)
+    x = torch.randn(B, Ci, H, W, generator=gg)
+    w = torch.randn(Co, Ci, 3, 3, generator=gg) / (Ci * 9) ** 0.5
+    xb = to_nhwc(x, dt)
+    wf, wd = pack(dt, w)
+    dy = torch.randn(B, Co, H, W, generator=gg)
+    dyb = to_nhwc(dy, dt)
+    add = torch.randn(B, Ci, H, W, generator=gg)
+    addb = to_nhwc(add, dt)
+    yb = to_nhwc(torch.randn(B, Ci, H, W, generator=gg) * 1.3 + 0.2, dt)
+    M = B * H * W
+    scale = (torch.rand(Ci, generator=gg) + 0.5).cuda(); shift = (torch.randn(Ci, generator=gg) * 0.3).cuda()
+    mean = (torch.randn(Ci, generator=gg) * 0.2 + 0.2).cuda(); invstd = (torch.rand(Ci, generator=gg) + 0.5).cuda(); gamma = (torch.rand(Ci, generator=gg) + 0.5).cuda()
+    outs = {}
+    for v in (-27, -28):
+        L.conv2d_set_variant(v)
+        try:
+            y = torch.full((B, H, W, Co), float("nan"), dtype=TD[dt], device="cuda")
+            rows = L.conv2d_stats_rows_geom(dt, B, H, W, Ci, Co, 3, 3, 1, 1, 1, Ci)
+            stats = torch.full((rows, 2, Co), float("nan"), device="cuda")
+            L.check(L.conv2d(dt, 0, xb.data_ptr(), Ci, wf.data_ptr(), y.data_ptr(), Co, None, None, 0, stats.data_ptr(),
+                             B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, st()), "conv")
+            dx = torch.full((B, H, W, Ci), float("nan"), dtype=TD[dt], device="cuda")
+            coef = None
+            if fused:
+                prow = L.conv2d_dgrad_bnsums_rows(dt, B, H, W, Co, H, W, Ci, 3, 3, 1, 1, 1, Co)
+                assert prow > 0
+                part = torch.full((prow, 2, Ci), float("nan"), device="cuda")
+                L.check(L.conv2d_dgrad_bnsums(dt, dyb.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, addb.data_ptr(), Ci, B, H, W, Co, H, W, Ci,
+                                              3, 3, 1, 1, 1, yb.data_ptr(), Ci, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), 1, 0.1,
+                                              part.data_ptr(), st()), "fused dgrad")
+                coef = [torch.zeros(Ci, device="cuda") for _ in range(5)]
+                L.check(L.bn_bwd_finalize_rows(part.data_ptr(), prow, Ci, float(M), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                               *[b.data_ptr() for b in coef], st()))
+                torch.cuda.synchronize()
+                assert not bool(torch.isnan(part).any())
+            else:
+                L.check(L.conv2d(dt, 1, dyb.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, None, addb.data_ptr(), Ci, None,
+                                 B, H, W, Co, H, W, Ci, 3, 3, 1, 1, 1, st()), "dgrad")
+            torch.cuda.synchronize()
+            assert not bool(torch.isnan(stats).any())
+            outs[v] = (y.float().cpu(), stats.sum(0).cpu(), dx.float().cpu(), [c.cpu() for c in coef] if coef else None)
+        finally:
+            L.conv2d_set_variant(-28)
+    ref = F.conv2d(rnd(dt, x), rnd(dt, w), None, stride=1, padding=1).permute(0, 2, 3, 1)
+    refd = (F.conv_transpose2d(rnd(dt, dy), rnd(dt, w), None, stride=1, padding=1) + rnd(dt, add)).permute(0, 2, 3, 1)
+    for v in outs:
+        assert torch.isfinite(outs[v][0]).all() and torch.isfinite(outs[v][2]).all(), v
+        torch.testing.assert_close(outs[v][0], ref, rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(outs[v][2], refd, rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(outs[-28][1], outs[-27][1], rtol=2e-3, atol=0.5)
+    if fused:
+        for a_, b_, name in zip(outs[-28][3], outs[-27][3], ("dgamma", "dbeta", "cA", "cB", "cC")):
+            np.testing.assert_allclose(a_.numpy(), b_.numpy(), rtol=5e-3, atol=5e-3 * max(1.0, float(b_.abs().max())), err_msg=name)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 80, 80, 128), (2, 32, 80, 80, 64), (3, 64, 26, 26, 64), (4, 32, 30, 17, 32), (33, 128, 13, 13, 128)])
 def test_shift_conv_dilation2(case):
     """Dilation-2 / pad-2 layers through the shift kernel (variant -20: stream with two shared zero columns / rows) == the im2col kernel
