@@ -1973,7 +1973,9 @@ int mdcv_conv2d_set_variant(int v) {
   //   16/17  stride-2 data gradient as four parity-class launches / one launch        18/19, 20/21  its tall tiles, its 3-stage ring off / on
   //   30+n   3-stage ring for 33..64-channel layers from n K steps (30 never)           60+n  the same for 128x128 / 128x64 tiles (60 never)
   //   92/93  128x64 tiles for fused 1x1 data gradients off / on                         2000+n  256-row tiles for Nout <= 64 from n Ki positions (2000 off)
-  //   -3..-26  shift-kernel hooks (conv_shift.hip: mdcv_shift_set_ring)
+  //   -3..-26  shift-kernel hooks (conv_shift.hip: mdcv_shift_set_ring)      -27 / -28  2-D pixel tiles for wide images off / on
+  //   -30 / -31 / -32  shift-kernel K loop of forward launches: lockstep / ping-pong everywhere / ping-pong where measured faster (default)
+  //   -200 / -201  384-row ping-pong tiles: by the plan / forced on every forward launch they fit
   if (v <= -3 && v >= -299) { mdcv_shift_set_ring(-v); v = -1; }
   if (v == 93 || v == 92) { g_conv_fuse_narrow = v == 93; return MDCV_OK; }
   if (v >= 60 && v < 92) { g_conv_deep_small = v - 60; return MDCV_OK; }

@@ -26,7 +26,6 @@
 #include "common.h"
 #include "conv_shift.h"
 #include "bn_fuse.h"
-#include <cstdlib>
 
 // The file is compiled twice (Makefile: conv_shift_fwd.o with -DMDCV_SHIFT_PART=0, conv_shift_dgrad.o with -DMDCV_SHIFT_PART=1) so that the
 // forward and the data-gradient instantiations build in parallel; part 0 also holds the host entry points and the tuning globals.
@@ -45,14 +44,13 @@ int g_shift_n64 = 2;    // 64- and 32-channel layers run one narrow tile column 
 int g_shift_wmax = 80;  // widest image row the shift kernel takes (set_variant(-15) -> 62, (-14) -> 80).  Up to 62 the chunk is 384 rows (3 DMAs per
                         // wave); 63..80 take a fourth and still fit two workgroups on a CU: RektNet's 128->128 layers at 80x80 +3.1 % on its step,
                         // the 76x76 layers of the 608^2 detector +1 % on the joint pipeline (same-box A/B)
-static int env_int(const char* n, int d) { const char* v = getenv(n); return v ? atoi(v) : d; }
-int g_shift_loop = env_int("MDCV_SHIFT_LOOP", 2);   // K-loop form of the FORWARD launches (set_variant(-30 - n)): 0 lockstep ; 1 ping-pong wave groups
+int g_shift_loop = 2;   // K-loop form of the FORWARD launches (set_variant(-30 - n)): 0 lockstep ; 1 ping-pong wave groups
                         // (two groups of four waves one barrier apart: one wave of a SIMD multiplies while its partner reads fragments and issues
                         // DMAs) ; 2 (default) ping-pong for grids of at most one workgroup per CU, where no second workgroup fills the
                         // read phase (13^2 512->1024 forward 52.5 -> 48.9 us), and 384-row ping-pong tiles where they make ONE round of
                         // 193..256 workgroups (26^2 256->512 forward 44.6 -> 42.4 us).  Denser grids: +1..2 % alone, data gradients -5..+3 %.
-int g_shift_2d = env_int("MDCV_SHIFT_2D", 1);   // images wider than the 1-D stream takes (below) run as 2-D pixel tiles of 8 x 30 outputs (set_variant(-27) off / (-28) on)
-int g_shift_big = env_int("MDCV_SHIFT_BIG", 0);   // A/B: 384 forces the 384-row ping-pong tiles on every forward launch they fit
+int g_shift_2d = 1;   // images wider than the 1-D stream takes (below) run as 2-D pixel tiles of 8 x 30 outputs (set_variant(-27) off / (-28) on)
+int g_shift_big = 0;   // A/B: 384 forces the 384-row ping-pong tiles on every forward launch they fit
 int g_shift_plan = 0;   // 0 / 5: default plan (192-row tiles where they save a round) ; 1: 256-row tiles only ; 2: 128-row only ; 6: never 192-row
 #else
 extern int g_shift_ring;
@@ -86,7 +84,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 #include <cstdio>
 __device__ long long g_shift_wg[3 * 4096];   // per workgroup: wall-clock start, end (100 MHz), hardware id
 #endif
-#ifdef MDCV_SHIFT_TS   /* per-step cycle stamps of one wave (scripts/shift_ts.py); never defined in the shipped build */
+#ifdef MDCV_SHIFT_TS   /* per-step cycle stamps of one wave never defined in the shipped build */
 __device__ long long g_shift_ts[4 * 512];
 #define STS(k) do { if (ts_on && ts_i < 512) g_shift_ts[(k) * 512 + ts_i] = (long long)clock64(); } while (0)
 #else

@@ -440,7 +440,7 @@ class Plan:
     # vs 72.7 us -- and is level at 26^2 (25 vs 27 us alone, 29 vs 25 in the step); the backward form is level at 52^2 (48.7 vs 54.9 us
     # alone, 57 vs 54.5 in the step) and loses elsewhere (13^2, K = 1024: 16-pixel tiles re-stream 1 MiB of weights per tile).  These
     # layers are HBM-bound and the fold removes one tensor read of four to seven, so the gain is bounded by that ratio.
-    pw_fuse = os.environ.get("MDCV_PW_FUSE", "1") != "0"   # (tests / A-B scripts flip the class attribute)
+    pw_fuse = True                     # (tests / A-B scripts flip the class attribute; no environment knob)
     pw_fwd_px = (50000, 1 << 30)       # pixels M of the layers that take the forward form
     pw_bwd_px = (0, 0)                 # ... the backward form: off (tests and A/B runs set (50000, 150000))
 

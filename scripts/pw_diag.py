@@ -1,4 +1,5 @@
-"""How many 1x1 blocks of yolo_baseline 416^2 B=32 take the fused forms, and the per-kernel time of one serial instrumented step."""
+"""How many 1x1 blocks of yolo_baseline 416^2 B=32 take the fused forms, and the per-kernel time of one serial instrumented step.
+usage: pw_diag.py [0|1]   (engine.Plan.pw_fuse)"""
 import os, sys, tempfile, collections
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,6 +8,8 @@ import bench
 from mdcv import engine
 from mdcv.yolo.models import Darknet
 from mdcv.optim import FusedAdam
+if len(sys.argv) > 1:
+    engine.Plan.pw_fuse = bool(int(sys.argv[1]))
 dev = torch.device("cuda", 0)
 tmp = tempfile.mkdtemp()
 cfg = bench.write_yolo_cfg(tmp)
