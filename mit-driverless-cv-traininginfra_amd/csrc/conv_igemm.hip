@@ -1839,6 +1839,10 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   const bool small = (long long)B * Hin * Win * in_ldc * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31) &&
                      (long long)Nout * KH * KW * Cin * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31);
   if (mode == 1 && stride == 2 && dil == 1 && small && (g_conv_variant != 0 || fuse)) {
+    // 32- / 64-channel outputs (208 -> 416, 104 -> 208: HBM-bound): the shift kernel's stride-2 form, whole output rows per store (conv_shift.hip MODE 3)
+    if (!fuse && !bias && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win && g_conv_variant < 0 &&
+        mdcv_shift_s2_dgrad_eligible(dtype, B, Hin, Win, Cin, Nout, in_ldc))
+      return mdcv_shift_conv(3, in, in_ldc, w_packed, out, out_ldc, nullptr, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Nout, nullptr, st, nullptr, 1);
     if (g_conv_s2_allcls && dtype == MDCV_BF16 && KH == 3 && KW == 3 && pad == 1 && !(Hout & 1) && !(Wout & 1) && (Cin % 32) == 0 && g_conv_deep_s2 &&
         g_conv_tall_s2) {
       ConvArgs c = a;                              // every class: Hs x Ws = Hout/2 x Wout/2 positions; taps and Ktot are set per class in the kernel
@@ -1974,6 +1978,7 @@ int mdcv_conv2d_set_variant(int v) {
   //   30+n   3-stage ring for 33..64-channel layers from n K steps (30 never)           60+n  the same for 128x128 / 128x64 tiles (60 never)
   //   92/93  128x64 tiles for fused 1x1 data gradients off / on                         2000+n  256-row tiles for Nout <= 64 from n Ki positions (2000 off)
   //   -3..-26  shift-kernel hooks (conv_shift.hip: mdcv_shift_set_ring)      -27 / -28  2-D pixel tiles for wide images off / on
+  //   -29 / -60  stride-2 data gradients with 32 / 64 output channels through the shift kernel off / on
   //   -30 / -31 / -32  shift-kernel K loop of forward launches: lockstep / ping-pong everywhere / ping-pong where measured faster (default)
   //   -200 / -201  384-row ping-pong tiles: by the plan / forced on every forward launch they fit
   if (v <= -3 && v >= -299) { mdcv_shift_set_ring(-v); v = -1; }

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
       img = tile_m / tpi;
       const int rt = tile_m - img * tpi, ty = rt / a.tiles_x, tx = rt - ty * a.tiles_x;
       const int cy = j / a.Wq, cx = j - cy * a.Wq;
-      yy = ty * a.TH - 1 + cy; xx = tx * (a.Wq - 2) - 1 + cx;
+      if (MODE == 3) { yy = ty * a.TH + cy; xx = tx * (a.Wq - 1) + cx; }        // stride-2 data gradient: the halo is below / right of the tile only
+      else { yy = ty * a.TH - 1 + cy; xx = tx * (a.Wq - 2) - 1 + cx; }
       ok = yy >= 0 && xx >= 0;
     } else {
       const int t = p0 + j - a.dil * (a.Wq + 1);
@@ -166,7 +167,10 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int kh = tap / 3, kw = tap - kh * 3;
-    const int d = a.dil * (MODE == 0 ? kh * a.Wq + kw : (2 - kh) * a.Wq + (2 - kw));
+    // MODE 3 (stride-2 data gradient, see the epilogue): tap (kh, kw) feeds output parity class (kh != 1, kw != 1) from the dY row / column
+    // one further on when kh == 0 / kw == 0
+    const int d = MODE == 3 ? (kh == 0 ? a.Wq : 0) + (kw == 0 ? 1 : 0)
+                            : a.dil * (MODE == 0 ? kh * a.Wq + kw : (2 - kh) * a.Wq + (2 - kw));
     const int row = wm * TM + d + r;
     offA[tap] = row * 64 + ((q ^ swz(row)) << 4);
   }
@@ -191,9 +195,11 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lds_void_t*)(smem + (wave < BN / 16 ? BBASE + (SLOT) * BTILE + wave * 1024 : SINK)), 16, (int)bvo, \
                                            ((TAP) * a.Cin + (CHUNK) * 32) * 2, 0, 0)
 
-  f32x4_t acc[FM][FN];
+  constexpr int NCLS = MODE == 3 ? 4 : 1;                   // stride-2 data gradient: one accumulator set per output parity class
+#define TAP_CLS(T) (MODE == 3 ? ((((T) / 3) != 1 ? 2 : 0) + (((T) % 3) != 1 ? 1 : 0)) * FM : 0)
+  f32x4_t acc[NCLS * FM][FN];
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+  for (int i = 0; i < NCLS * FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-              for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < FN; ++j) acc[TAP_CLS(tap) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[TAP_CLS(tap) + i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
           // Every MFMA of the previous step is ISSUED before this barrier -- hence each fragment read it consumes has RETURNED (see
           // wait_vm_reads_done above for why that matters; pinning the accumulators costs nothing measurable, draining lgkmcnt here +0.4 %).
 #pragma unroll
-          for (int i = 0; i < FM; ++i)
+          for (int i = 0; i < NCLS * FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(acc[i][j]));
           if (tap >= 1 && tap <= LA) wait_vm_reads_done<LA - 1 + NPA>(); else wait_vm_reads_done<LA - 1>();
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
 #pragma unroll
           for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FN; ++j) acc[TAP_CLS(tap) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[TAP_CLS(tap) + i][j], 0, 0, 0);
 #ifdef MDCV_SHIFT_PRIO
           __builtin_amdgcn_s_setprio(0);
 #endif
@@ -348,6 +354,55 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   wait_vm<0>();
   __syncthreads();                                         // the epilogue reuses the pipeline LDS
 
+  if constexpr (MODE == 3) {
+    // Stride-2 data gradient: dx[2a + py][2b + px] of the tile's dY positions (a, b), class (py, px) in accumulator set 2 py + px.  For each
+    // py the two column classes are interleaved in LDS as OUTPUT rows (row la, 64 pixels 2 lb + px of BN channels), so the stores are whole
+    // contiguous output rows (the per-class launches of the im2col path write every 128-byte line as two 64-byte halves at different times).
+    static_assert(MODE != 3 || (BM == 256 && !FUSE && !EPI), "stride-2 data gradient: 8 x 32 dY positions per tile");
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int img = tile_m / tpi, rt = tile_m - img * tpi, ty = rt / a.tiles_x, tx = rt - ty * a.tiles_x;
+    const int a0 = ty * a.TH, b0 = tx * (a.Wq - 1);
+    const int Ho = 2 * a.H, Wo = 2 * a.W;
+    bf16_t* __restrict__ out3 = reinterpret_cast<bf16_t*>(a.out);
+    const bf16_t* __restrict__ add3 = reinterpret_cast<const bf16_t*>(a.addsrc);
+    constexpr int VPRO3 = BN / 8;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int p = wm * TM + i * 16 + (lane >> 4) * 4 + rr, col = wn * TN + j * 16 + (lane & 15);
+              const int srow = (p >> 5) * 64 + 2 * (p & 31) + px;
+              reinterpret_cast<bf16_t*>(smem + srow * SROW)[col] = f2bf(acc[(2 * py + px) * FM + i][j][rr]);
+            }
+      __syncthreads();
+      for (int v = tid; v < 512 * VPRO3; v += NW * 64) {
+        const int srow = v / VPRO3, cv = v - srow * VPRO3;
+        const int la = srow >> 6, ox = srow & 63;
+        const int Y = 2 * (a0 + la) + py, X = 2 * b0 + ox, n = tile_n * BN + cv * 8;
+        if (ox < 2 * (a.Wq - 1) && Y < Ho && X < Wo && n < a.Nout) {
+          const size_t pix = ((size_t)img * Ho + Y) * Wo + X;
+          uint4 d = *reinterpret_cast<const uint4*>(smem + srow * SROW + cv * 16);
+          if (add3) {
+            float x[8], y[8];
+            ET<bf16_t>::unpack(d, x);
+            ET<bf16_t>::unpack(*reinterpret_cast<const uint4*>(add3 + pix * a.add_ldc + n), y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += y[e];
+            d = ET<bf16_t>::pack(x);
+          }
+          *reinterpret_cast<uint4*>(out3 + pix * a.out_ldc + n) = d;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
   // ---------------- epilogue ----------------
   int* rowpix = reinterpret_cast<int*>(smem + PIX_OFF);
   if (tid < BM) {
@@ -566,7 +621,8 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   a.xcd_chunk = (a.tiles_total + 7) / 8;
   a.nca = (BM + 2 * a.dil * (a.Wq + 1) + 15) / 16;         // KiB-chunks (16 stream rows each) of one activation chunk
   const int pipe = 2 * a.nca * 1024 + BRING * BTILE + 1024;
-  const int epi = BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics (the fused sums fold inside dead staging rows)
+  const int epi = MODE == 3 ? 512 * SROW                    // stride-2 data gradient: two column classes of the tile interleaved as output rows
+                            : BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics (the fused sums fold inside dead staging rows)
   const int lds = pipe > epi ? pipe : epi;
   static int attr_lds = 0;
   auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE, WN, EPI, BN_, LOOP>;
@@ -637,6 +693,9 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128, b
 
 template <int MODE, int BN_>
 int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
+  if constexpr (MODE == 3) {                                 // stride-2 data gradient: one 8 x 32 position tile per workgroup
+    return launch_shift_bm<MODE, 256, BN_>(a, 0, a.Mq / 256, st, in_bytes, w_bytes);
+  } else {
   if (a.t2d) return launch_shift_bm<MODE, 256, BN_>(a, 0, a.Mq / 256, st, in_bytes, w_bytes);   // one 8 x 32 position tile per workgroup
   const int bm = shift_plan_bm(a.Mq, a.tiles_n, a.fuse.y != nullptr, 2 * a.dil * (a.Wq + 1), BN_, MODE == 0);
   if constexpr (BN_ == 128 && MODE == 0) {
@@ -652,12 +711,18 @@ int launch_shift_mode(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, uns
   const int p_base = nbig_m * 256;
   if (p_base < a.Mq) return launch_shift_bm<MODE, 128, BN_>(a, p_base, (a.Mq - p_base + 127) / 128, st, in_bytes, w_bytes);
   return MDCV_OK;
+  }
 }
 
 }  // namespace
 
 #if MDCV_SHIFT_PART == 1
 int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
+  if (a.t2d == 2) {                                          // stride-2 data gradient (MODE 3): 32- and 64-channel outputs
+    if (a.Nout == 32) return launch_shift_mode<3, 32>(a, st, in_bytes, w_bytes);
+    if (a.Nout == 64) return launch_shift_mode<3, 64>(a, st, in_bytes, w_bytes);
+    return MDCV_EARG;
+  }
   if (a.Nout == 32) return launch_shift_mode<1, 32>(a, st, in_bytes, w_bytes);
   if (a.Nout == 64) return launch_shift_mode<1, 64>(a, st, in_bytes, w_bytes);
   return launch_shift_mode<1, 128>(a, st, in_bytes, w_bytes);
@@ -690,6 +755,16 @@ bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int 
   return true;
 }
 
+// 3x3 / stride-2 / pad-1 data gradient with an even output (dx = 2H x 2W from dY = H x W) and 32 or 64 output channels: the two HBM-bound
+// layers of YOLOv3 (208 -> 416, 104 -> 208).  mdcv_shift_conv(mode 3).
+int g_shift_s2 = 1;        // set_variant(-29) off / (-60) on
+bool mdcv_shift_s2_dgrad_eligible(int dtype, int B, int H, int W, int Cin, int Nout, long long in_ldc) {
+  if (!g_shift_s2 || dtype != MDCV_BF16 || (Cin & 31) || Cin < 32 || !(Nout == 32 || Nout == 64) || H < 1 || W < 1) return false;
+  if ((long long)B * ((H + 7) / 8) * ((W + 30) / 31) * 256 >= (1LL << 30)) return false;
+  if ((long long)B * H * W * in_ldc * 2 >= (1LL << 31) || (long long)Nout * 9 * Cin * 2 >= (1LL << 31)) return false;
+  return true;
+}
+
 int mdcv_shift_stats_rows(int B, int H, int W, int dil, int Nout) {
   if (shift_is_2d(W, Nout, dil)) return (int)(shift_2d_positions(B, H, W) / 128);
   return (int)(((long long)B * (H + dil) * (W + dil) + 127) / 128);
@@ -714,7 +789,11 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Nout = Nout;
   a.dil = dil; a.Wq = W + dil; a.Sq = (H + dil) * (W + dil); a.Mq = B * a.Sq;
   a.t2d = 0; a.tiles_x = a.tiles_y = a.TH = 0;
-  if (shift_is_2d(W, Nout, dil)) {
+  if (mode == 3) {                                           // stride-2 data gradient: H, W are dY's; tiles of 8 x 31 dY positions + one halo row / column
+    a.t2d = 2; a.Wq = T2D_WQ; a.TH = T2D_TH;
+    a.tiles_x = (W + T2D_WQ - 2) / (T2D_WQ - 1); a.tiles_y = (H + T2D_TH - 1) / T2D_TH;
+    a.Mq = B * a.tiles_x * a.tiles_y * 256; a.Sq = a.tiles_x * a.tiles_y * 256;
+  } else if (shift_is_2d(W, Nout, dil)) {
     a.t2d = 1; a.Wq = T2D_WQ; a.TH = T2D_TH;
     a.tiles_x = (W + T2D_WQ - 3) / (T2D_WQ - 2); a.tiles_y = (H + T2D_TH - 1) / T2D_TH;
     a.Mq = (int)shift_2d_positions(B, H, W); a.Sq = a.tiles_x * a.tiles_y * 256;
@@ -725,13 +804,14 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   a.wrow = 9 * Cin;
   const unsigned in_bytes = (unsigned)((long long)B * H * W * in_ldc * 2);
   const unsigned w_bytes = (unsigned)((long long)Nout * 9 * Cin * 2);
+  if (mode == 3 && (fuse || epi || stats || bias)) return MDCV_EARG;
   if (mode != 0) return mdcv_shift_launch_dgrad(a, st, in_bytes, w_bytes);
   if (Nout == 32) return launch_shift_mode<0, 32>(a, st, in_bytes, w_bytes);
   if (Nout == 64) return launch_shift_mode<0, 64>(a, st, in_bytes, w_bytes);
   return launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring == 27 || ring == 28) { g_shift_2d = ring - 27; return; } if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring == 29 || ring == 60) { g_shift_s2 = ring == 60; return; } if (ring == 27 || ring == 28) { g_shift_2d = ring - 27; return; } if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

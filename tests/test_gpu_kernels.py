@@ -1002,6 +1002,46 @@ def test_shift_conv_64_wide_tile_column(case):
     torch.testing.assert_close(outs[-17][1], outs[-18][1], rtol=2e-3, atol=0.5)
 
 
+S2D_CASES = [(2, 64, 104, 104, 32), (1, 128, 52, 52, 64), (3, 32, 17, 45, 32), (2, 64, 8, 31, 64), (1, 32, 9, 63, 32), (32, 64, 208, 208, 32)]
+
+
+@pytest.mark.parametrize("with_add", [False, True], ids=["plain", "addsrc"])
+@pytest.mark.parametrize("case", S2D_CASES, ids=[str(c) for c in S2D_CASES])
+def test_shift_stride2_dgrad(case, with_add):
+    """3x3 / stride-2 / pad-1 data gradients with 32 or 64 output channels run the shift kernel's stride-2 form (one accumulator set per
+    output parity class, whole output rows per store; variant -60, the default) == the per-class im2col path (-29) == torch
+    conv_transpose2d; ragged tiles and addsrc included.  case = (B, Cdy, Hdy, Wdy, Cdx)."""
+    L = _lib.lib()
+    dt = BF16
+    B, Co, H, W, Ci = case                      # the layer: Ci -> Co, stride 2, input 2H x 2W
+    gg = torch.Generator().manual_seed(B + Co + W + 9)
+    w = torch.randn(Co, Ci, 3, 3, generator=gg) / (Co * 9 / 4) ** 0.5
+    _, wd = pack(dt, w)
+    dy = torch.randn(B, Co, H, W, generator=gg)
+    dyb = to_nhwc(dy, dt)
+    add = torch.randn(B, Ci, 2 * H, 2 * W, generator=gg)
+    addb = to_nhwc(add, dt) if with_add else None
+    outs = {}
+    for v in (-29, -60):
+        L.conv2d_set_variant(v)
+        try:
+            dx = torch.full((B, 2 * H, 2 * W, Ci), float("nan"), dtype=TD[dt], device="cuda")
+            L.check(L.conv2d(dt, 1, dyb.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, None, addb.data_ptr() if with_add else None, Ci, None,
+                             B, H, W, Co, 2 * H, 2 * W, Ci, 3, 3, 2, 1, 1, st()), "s2 dgrad")
+            torch.cuda.synchronize()
+            outs[v] = dx.float().cpu()
+        finally:
+            L.conv2d_set_variant(-60)
+    ref = F.conv_transpose2d(rnd(dt, dy), rnd(dt, w), None, stride=2, padding=1, output_padding=1)
+    if with_add:
+        ref = ref + rnd(dt, add)
+    ref = ref.permute(0, 2, 3, 1)
+    for v in outs:
+        assert torch.isfinite(outs[v]).all(), v
+        torch.testing.assert_close(outs[v], ref, rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(outs[-60], outs[-29], rtol=1e-2, atol=2e-2)
+
+
 T2D_CASES = [(2, 32, 208, 208, 64), (1, 64, 208, 208, 32), (3, 64, 104, 104, 128), (2, 32, 97, 131, 128), (1, 128, 9, 161, 128), (2, 32, 41, 300, 32)]
 
 
