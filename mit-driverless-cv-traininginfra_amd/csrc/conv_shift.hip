@@ -49,6 +49,8 @@ int g_shift_loop = 2;   // K-loop form of the FORWARD launches (set_variant(-30 
                         // DMAs) ; 2 (default) ping-pong for grids of at most one workgroup per CU, where no second workgroup fills the
                         // read phase (13^2 512->1024 forward 52.5 -> 48.9 us), and 384-row ping-pong tiles where they make ONE round of
                         // 193..256 workgroups (26^2 256->512 forward 44.6 -> 42.4 us).  Denser grids: +1..2 % alone, data gradients -5..+3 %.
+int g_shift_c8 = 0;   // 8-channel inputs (YOLOv3's first layer: 3 -> 8 padded channels) as one quarter-filled 32-channel chunk: correct (tested) and
+                      // SLOWER than the im2col kernel, 240 vs 159 us at 416^2 (4x the MFMAs, 23 296 tiles of 9 K steps): off (set_variant(-61) off / (-62) on)
 int g_shift_2d = 1;   // images wider than the 1-D stream takes (below) run as 2-D pixel tiles of 8 x 30 outputs (set_variant(-27) off / (-28) on)
 int g_shift_big = 0;   // A/B: 384 forces the 384-row ping-pong tiles on every forward launch they fit
 int g_shift_plan = 0;   // 0 / 5: default plan (192-row tiles where they save a round) ; 1: 256-row tiles only ; 2: 128-row only ; 6: never 192-row
@@ -63,6 +65,7 @@ extern int g_shift_plan;
 extern int g_shift_loop;
 extern int g_shift_big;
 extern int g_shift_2d;
+extern int g_shift_c8;
 #endif
 int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes);   // defined by part 1
 
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
       const int rem = tt - img * a.Sq;
       yy = rem / a.Wq; xx = rem - yy * a.Wq;
     }
-    ok = ok && yy < a.H && xx < a.W;
+    ok = ok && yy < a.H && xx < a.W && kv * 8 < a.Cin;     // (Cin = 8: the other three k-vectors of a row are zeros, whatever the weight tile holds there)
     avo[k] = ok ? (unsigned)((((img * a.H + yy) * a.W + xx) * a.in_ldc + kv * 8) * 2) : OOB;
   }
   unsigned bvo;                                            // the weight tile is 8 KiB-chunks: waves 8..15 (16-wave variant) fill the sink
@@ -747,7 +750,7 @@ bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int 
   // dilation 2 pays where the halo-heavy chunk is amortised over >= 2 channel chunks and two workgroups still fit a CU (narrow tiles):
   // RektNet data gradient 128->64 412 -> 332 us, 64->32 193 -> 183 us; forward 64->128 (128-wide tile, one workgroup per CU) 281 -> 360 us
   if (dil == 2 && g_shift_dil2 == 1 && !(Nout <= 64 && Cin >= 64)) return false;
-  if ((Cin & 31) || Cin < 32 || ((Nout & 127) && !(Nout == 64 && g_shift_n64) && !(Nout == 32 && g_shift_n64 == 2))) return false;   // 128-wide tiles, or one 64-wide tile column
+  if (((Cin & 31) && !(Cin == 8 && g_shift_c8 && dil == 1)) || ((Nout & 127) && !(Nout == 64 && g_shift_n64) && !(Nout == 32 && g_shift_n64 == 2))) return false;   // 128-wide tiles, or one 64-wide tile column
   if (H < 8 || W < 8) return false;
   if (!shift_fits_1d(W, Nout) && !(g_shift_2d && dil == 1)) return false;   // wider rows: 2-D pixel tiles (dilation 1 only), or not at all
   if ((long long)B * (H + dil) * (W + dil) + 1024 >= (1LL << 30) || shift_2d_positions(B, H, W) >= (1LL << 30)) return false;
@@ -800,7 +803,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   }
   a.tiles_n = Nout <= 64 ? 1 : Nout / BN;
   a.tiles_total = 0; a.xcd_chunk = 0; a.nca = 0; a.p_base = 0;
-  a.nchunks = Cin / 32;
+  a.nchunks = (Cin + 31) / 32;
   a.wrow = 9 * Cin;
   const unsigned in_bytes = (unsigned)((long long)B * H * W * in_ldc * 2);
   const unsigned w_bytes = (unsigned)((long long)Nout * 9 * Cin * 2);
@@ -811,7 +814,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   return launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring == 29 || ring == 60) { g_shift_s2 = ring == 60; return; } if (ring == 27 || ring == 28) { g_shift_2d = ring - 27; return; } if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring == 61 || ring == 62) { g_shift_c8 = ring - 61; return; } if (ring == 29 || ring == 60) { g_shift_s2 = ring == 60; return; } if (ring == 27 || ring == 28) { g_shift_2d = ring - 27; return; } if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

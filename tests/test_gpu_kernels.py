@@ -1042,6 +1042,40 @@ def test_shift_stride2_dgrad(case, with_add):
     torch.testing.assert_close(outs[-60], outs[-29], rtol=1e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("case", [(2, 3, 416, 416, 32), (3, 3, 37, 61, 32), (2, 5, 20, 20, 64), (1, 8, 9, 100, 128)], ids=str)
+def test_shift_conv_8_channel_input(case):
+    """A 3x3 conv whose input has (at most) 8 padded channels -- YOLOv3's first layer -- runs the shift kernel with one quarter-filled
+    32-channel chunk (variant -62; off by default, it measured slower: the three missing k-vectors of every activation row are zero-filled by the DMA's range
+    check) == the im2col kernel (-61) == torch; forward with BatchNorm statistics."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, H, W, Co = case
+    gg = torch.Generator().manual_seed(B + Ci + W + 3)
+    x = torch.randn(B, Ci, H, W, generator=gg)
+    w = torch.randn(Co, Ci, 3, 3, generator=gg) / (Ci * 9) ** 0.5
+    xb = to_nhwc(x, dt)
+    wf, _ = pack(dt, w, need_d=False)
+    outs = {}
+    for v in (-61, -62):
+        L.conv2d_set_variant(v)
+        try:
+            y = torch.full((B, H, W, Co), float("nan"), dtype=TD[dt], device="cuda")
+            rows = L.conv2d_stats_rows_geom(dt, B, H, W, 8, Co, 3, 3, 1, 1, 1, 8)
+            stats = torch.full((rows, 2, Co), float("nan"), device="cuda")
+            L.check(L.conv2d(dt, 0, xb.data_ptr(), 8, wf.data_ptr(), y.data_ptr(), Co, None, None, 0, stats.data_ptr(),
+                             B, H, W, 8, H, W, Co, 3, 3, 1, 1, 1, st()), "conv")
+            torch.cuda.synchronize()
+            assert not bool(torch.isnan(stats).any())
+            outs[v] = (y.float().cpu(), stats.sum(0).cpu())
+        finally:
+            L.conv2d_set_variant(-61)
+    ref = F.conv2d(rnd(dt, x), rnd(dt, w), None, stride=1, padding=1).permute(0, 2, 3, 1)
+    for v in outs:
+        assert torch.isfinite(outs[v][0]).all(), v
+        torch.testing.assert_close(outs[v][0], ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(outs[-62][1], outs[-61][1], rtol=2e-3, atol=0.5)
+
+
 T2D_CASES = [(2, 32, 208, 208, 64), (1, 64, 208, 208, 32), (3, 64, 104, 104, 128), (2, 32, 97, 131, 128), (1, 128, 9, 161, 128), (2, 32, 41, 300, 32)]
 
 
