@@ -2,7 +2,7 @@
 (plan-build-time switches need their own plan).
 usage: ab_step.py "c-30;c-31;c-31,w30005;P0" [rounds] [steps] [yolo|rektnet]
   c<n> = mdcv_conv2d_set_variant(n), w<n> = mdcv_conv2d_wgrad_set_variant(n), p<n> = mdcv_pw_set_variant(n)   (applied before every timing block)
-  P0 / P1 = engine.Plan.pw_fuse off / on, F<mask> = engine.Plan.fuse_skip                                      (applied when the model is built)
+  P0 / P1 = engine.Plan.pw_fuse off / on, F<mask> = engine.Plan.fuse_skip, S0 = model.strict_targets off                                      (applied when the model is built)
 Every setting is applied on top of the first one (the baseline), which is re-applied in front of each."""
 import os, sys, tempfile, time, statistics
 import torch
@@ -26,7 +26,7 @@ BUILD_DEFAULTS = dict(pw_fuse=engine.Plan.pw_fuse, fuse_skip=engine.Plan.fuse_sk
 
 def apply(codes):
     for c in codes:
-        if not c or c[0] in "PF":
+        if not c or c[0] in "PFS":
             continue
         {"c": L.cdll.mdcv_conv2d_set_variant, "w": L.cdll.mdcv_conv2d_wgrad_set_variant, "p": L.cdll.mdcv_pw_set_variant}[c[0]](int(c[1:]))
 
@@ -50,6 +50,7 @@ def make(i):
         os.chdir(tmp)
         torch.manual_seed(0)
         net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True).to(dev).train()
+        net.strict_targets = "S0" not in settings[i]          # S0: the bad-label check at the start of backward does not wait for the forward
         opt = FusedAdam(net, lr=1e-3)
 
         def step():
