@@ -132,18 +132,24 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
       __builtin_amdgcn_s_barrier();                          /* ... and the consumers are done with the buffer written next */ \
     }                                                                                                                   \
   } while (0)
-    // Three register sets rotate over the half tiles: two half tiles of HBM loads are in flight while a third is transformed.  No
-    // conditional load in front of a use (at a join hipcc would wait vmcnt(0) and drain the prefetch): the loop leaves through breaks
-    // behind an EMIT, and the loads past the last item are clamped repeats.
-    uint4 qa0[UN], qa1[UN], qb0[UN], qb1[UN], qc0[UN], qc1[UN];
+    // NS register sets rotate over the half tiles: NS - 1 half tiles of HBM loads are in flight while one is transformed (three sets of 4
+    // vectors for the widest operands, five sets of 1 - 2 vectors for the narrow ones: >= 64 KiB of reads in flight per CU either way).
+    // No conditional load in front of a use (at a join hipcc would wait vmcnt(0) and drain the prefetch): the loop leaves through a goto
+    // behind an EMIT, and the loads past the last item are clamped repeats.  The set indices are compile-time (unrolled rotation).
+    constexpr int NS = UN >= 4 ? 3 : 5;
+    uint4 q0[NS][UN], q1[NS][UN];
     int it = 0;
-    PW_LOAD(qa0, qa1, 0);
-    PW_LOAD(qb0, qb1, 1);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) PW_LOAD(q0[s], q1[s], s);
     while (true) {
-      PW_LOAD(qc0, qc1, it + 2); PW_EMIT(qa0, qa1, it); if (++it == nitems) break;
-      PW_LOAD(qa0, qa1, it + 2); PW_EMIT(qb0, qb1, it); if (++it == nitems) break;
-      PW_LOAD(qb0, qb1, it + 2); PW_EMIT(qc0, qc1, it); if (++it == nitems) break;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        PW_LOAD(q0[(s + NS - 1) % NS], q1[(s + NS - 1) % NS], it + NS - 1);
+        PW_EMIT(q0[s], q1[s], it);
+        if (++it == nitems) goto produced;
+      }
     }
+  produced:
 #undef PW_LOAD
 #undef PW_EMIT
     __builtin_amdgcn_s_barrier();                              // the consumers' last tile

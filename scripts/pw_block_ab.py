@@ -30,7 +30,9 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-SH = [(32 * 52 * 52, 256, 128, 52), (32 * 26 * 26, 512, 256, 26), (32 * 13 * 13, 1024, 512, 13), (32 * 104 * 104, 128, 64, 104)]
+# forward shapes of yolo_baseline (K = channels of the BatchNorm output, N = the 1x1 conv's outputs), then the backward shapes of the same layers (K <-> N)
+SH = [(32 * 52 * 52, 256, 128, 52), (32 * 26 * 26, 512, 256, 26), (32 * 13 * 13, 1024, 512, 13), (32 * 104 * 104, 128, 64, 104),
+      (32 * 52 * 52, 128, 256, 52), (32 * 26 * 26, 256, 512, 26), (32 * 104 * 104, 64, 128, 104)]
 NS = 4
 for (M, K, N, H) in SH:
     B = 32
