@@ -1840,9 +1840,9 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
                      (long long)Nout * KH * KW * Cin * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31);
   if (mode == 1 && stride == 2 && dil == 1 && small && (g_conv_variant != 0 || fuse)) {
     // 32- / 64-channel outputs (208 -> 416, 104 -> 208: HBM-bound): the shift kernel's stride-2 form, whole output rows per store (conv_shift.hip MODE 3)
-    if (!fuse && !bias && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win && g_conv_variant < 0 &&
+    if (!bias && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win && g_conv_variant < 0 &&
         mdcv_shift_s2_dgrad_eligible(dtype, B, Hin, Win, Cin, Nout, in_ldc))
-      return mdcv_shift_conv(3, in, in_ldc, w_packed, out, out_ldc, nullptr, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Nout, nullptr, st, nullptr, 1);
+      return mdcv_shift_conv(3, in, in_ldc, w_packed, out, out_ldc, nullptr, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Nout, fuse, st, nullptr, 1);
     if (g_conv_s2_allcls && dtype == MDCV_BF16 && KH == 3 && KW == 3 && pad == 1 && !(Hout & 1) && !(Wout & 1) && (Cin % 32) == 0 && g_conv_deep_s2 &&
         g_conv_tall_s2) {
       ConvArgs c = a;                              // every class: Hs x Ws = Hout/2 x Wout/2 positions; taps and Ktot are set per class in the kernel
@@ -1927,6 +1927,9 @@ int mdcv_conv2d_dgrad_bnsums_rows(int dtype, int B, int Hin, int Win, int Cin, i
   if ((long long)B * Hin * Win * in_ldc * es >= (1LL << 31) || (long long)Nout * KH * KW * Cin * es >= (1LL << 31)) return 0;
   if (Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc))
     return mdcv_shift_stats_rows(B, Hout, Wout, dil, Nout);
+  if (stride == 2 && dil == 1 && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win && g_conv_variant < 0 &&
+      mdcv_shift_s2_dgrad_eligible(dtype, B, Hin, Win, Cin, Nout, in_ldc))
+    return mdcv_shift_s2_rows(B, Hin, Win);             // the shift kernel's stride-2 form: one row per tile of 8 x 31 dY positions
   if (stride == 2 && dil == 1) {
     int rows = 0;
     for (int cls = 0; cls < 4; ++cls) {

@@ -361,14 +361,19 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
     // Stride-2 data gradient: dx[2a + py][2b + px] of the tile's dY positions (a, b), class (py, px) in accumulator set 2 py + px.  For each
     // py the two column classes are interleaved in LDS as OUTPUT rows (row la, 64 pixels 2 lb + px of BN channels), so the stores are whole
     // contiguous output rows (the per-class launches of the im2col path write every 128-byte line as two 64-byte halves at different times).
-    static_assert(MODE != 3 || (BM == 256 && !FUSE && !EPI), "stride-2 data gradient: 8 x 32 dY positions per tile");
+    static_assert(MODE != 3 || (BM == 256 && !EPI), "stride-2 data gradient: 8 x 32 dY positions per tile");
     const int tpi = a.tiles_x * a.tiles_y;
     const int img = tile_m / tpi, rt = tile_m - img * tpi, ty = rt / a.tiles_x, tx = rt - ty * a.tiles_x;
     const int a0 = ty * a.TH, b0 = tx * (a.Wq - 1);
     const int Ho = 2 * a.H, Wo = 2 * a.W;
     bf16_t* __restrict__ out3 = reinterpret_cast<bf16_t*>(a.out);
     const bf16_t* __restrict__ add3 = reinterpret_cast<const bf16_t*>(a.addsrc);
-    constexpr int VPRO3 = BN / 8;
+    constexpr int VPRO3 = BN / 8;                          // 16-byte vectors per output pixel = vectors per thread and row-parity pass
+    static_assert((512 * VPRO3) % (NW * 64) == 0 && (NW * 64) % VPRO3 == 0, "every thread keeps one channel vector");
+    using Acc3 = BnFuseAcc<bf16_t, BN, NW * 64>;
+    Acc3 fz3;
+    const bf16_t* __restrict__ fy3 = reinterpret_cast<const bf16_t*>(a.fuse.y);
+    if constexpr (FUSE) fz3.init(a.fuse, tile_n * BN + (tid % VPRO3) * 8, a.Nout);
 #pragma unroll
     for (int py = 0; py < 2; ++py) {
 #pragma unroll
@@ -384,26 +389,44 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
               reinterpret_cast<bf16_t*>(smem + srow * SROW)[col] = f2bf(acc[(2 * py + px) * FM + i][j][rr]);
             }
       __syncthreads();
-      for (int v = tid; v < 512 * VPRO3; v += NW * 64) {
-        const int srow = v / VPRO3, cv = v - srow * VPRO3;
+      // every thread: VPRO3 vectors of this pass; their global operands (addsrc, y of the fused sums) are all issued first
+      long long pixv[VPRO3]; uint4 aq[VPRO3], yq[VPRO3];
+      const int cv = tid % VPRO3, n = tile_n * BN + cv * 8;
+#pragma unroll
+      for (int k = 0; k < VPRO3; ++k) {
+        const int srow = (tid + k * NW * 64) / VPRO3;
         const int la = srow >> 6, ox = srow & 63;
-        const int Y = 2 * (a0 + la) + py, X = 2 * b0 + ox, n = tile_n * BN + cv * 8;
-        if (ox < 2 * (a.Wq - 1) && Y < Ho && X < Wo && n < a.Nout) {
-          const size_t pix = ((size_t)img * Ho + Y) * Wo + X;
+        const int Y = 2 * (a0 + la) + py, X = 2 * b0 + ox;
+        const bool ok = ox < 2 * (a.Wq - 1) && Y < Ho && X < Wo && n < a.Nout;
+        pixv[k] = ok ? ((long long)img * Ho + Y) * Wo + X : -1;
+        if (ok) {
+          if (add3) aq[k] = *reinterpret_cast<const uint4*>(add3 + pixv[k] * a.add_ldc + n);
+          if constexpr (FUSE) yq[k] = *reinterpret_cast<const uint4*>(fy3 + pixv[k] * a.fuse.ldy + n);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < VPRO3; ++k) {
+        if (pixv[k] >= 0) {
+          const int srow = (tid + k * NW * 64) / VPRO3;
           uint4 d = *reinterpret_cast<const uint4*>(smem + srow * SROW + cv * 16);
+          float x[8];
+          if (add3 || FUSE) ET<bf16_t>::unpack(d, x);
           if (add3) {
-            float x[8], y[8];
-            ET<bf16_t>::unpack(d, x);
-            ET<bf16_t>::unpack(*reinterpret_cast<const uint4*>(add3 + pix * a.add_ldc + n), y);
+            float y[8];
+            ET<bf16_t>::unpack(aq[k], y);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] += y[e];
             d = ET<bf16_t>::pack(x);
+            if constexpr (FUSE) ET<bf16_t>::unpack(d, x);   // the sums see dz as stored
           }
-          *reinterpret_cast<uint4*>(out3 + pix * a.out_ldc + n) = d;
+          *reinterpret_cast<uint4*>(out3 + pixv[k] * a.out_ldc + n) = d;
+          if constexpr (FUSE) fz3.add(a.fuse, x, yq[k]);
         }
       }
       __syncthreads();
     }
+    if constexpr (FUSE)                                      // one partial row per tile (mdcv_shift_s2_rows)
+      fz3.flush(a.fuse, reinterpret_cast<float*>(smem + 512 * SROW), tid, tile_n * BN, a.Nout, tile_m);
     return;
   }
   // ---------------- epilogue ----------------
@@ -624,7 +647,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   a.xcd_chunk = (a.tiles_total + 7) / 8;
   a.nca = (BM + 2 * a.dil * (a.Wq + 1) + 15) / 16;         // KiB-chunks (16 stream rows each) of one activation chunk
   const int pipe = 2 * a.nca * 1024 + BRING * BTILE + 1024;
-  const int epi = MODE == 3 ? 512 * SROW                    // stride-2 data gradient: two column classes of the tile interleaved as output rows
+  const int epi = MODE == 3 ? 512 * SROW + NW * BN * 4      // stride-2 data gradient: two column classes of the tile interleaved as output rows (+ fold scratch)
                             : BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics (the fused sums fold inside dead staging rows)
   const int lds = pipe > epi ? pipe : epi;
   static int attr_lds = 0;
@@ -641,6 +664,9 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
 
 template <int MODE, int BM, int NPA, int WN, int BN_>
 int launch_shift(const ShiftArgs& a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
+  if constexpr (MODE == 3) {
+    if (a.fuse.y) return launch_shift_f<MODE, BM, NPA, true, WN, false, 3, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
+  }
   if constexpr (MODE == 1 && WN == 2 && BM % 128 == 0) {   // the fused BatchNorm-backward sums exist for 8-wave data gradients only
     if (a.fuse.y) return launch_shift_f<MODE, BM, NPA, true, WN, false, 3, BN_>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
@@ -768,6 +794,8 @@ bool mdcv_shift_s2_dgrad_eligible(int dtype, int B, int H, int W, int Cin, int N
   return true;
 }
 
+int mdcv_shift_s2_rows(int B, int H, int W) { return B * ((H + T2D_TH - 1) / T2D_TH) * ((W + T2D_WQ - 2) / (T2D_WQ - 1)); }   // fused-sum rows of mode 3: one per tile
+
 int mdcv_shift_stats_rows(int B, int H, int W, int dil, int Nout) {
   if (shift_is_2d(W, Nout, dil)) return (int)(shift_2d_positions(B, H, W) / 128);
   return (int)(((long long)B * (H + dil) * (W + dil) + 127) / 128);
@@ -807,7 +835,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   a.wrow = 9 * Cin;
   const unsigned in_bytes = (unsigned)((long long)B * H * W * in_ldc * 2);
   const unsigned w_bytes = (unsigned)((long long)Nout * 9 * Cin * 2);
-  if (mode == 3 && (fuse || epi || stats || bias)) return MDCV_EARG;
+  if (mode == 3 && (epi || stats || bias)) return MDCV_EARG;
   if (mode != 0) return mdcv_shift_launch_dgrad(a, st, in_bytes, w_bytes);
   if (Nout == 32) return launch_shift_mode<0, 32>(a, st, in_bytes, w_bytes);
   if (Nout == 64) return launch_shift_mode<0, 64>(a, st, in_bytes, w_bytes);

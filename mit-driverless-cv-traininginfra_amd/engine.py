@@ -556,6 +556,7 @@ class Plan:
     # csrc/elementwise.hip), but the fused store loops still lose on these HBM-bound layers: RektNet 31.99k -> 31.34k img/s, YOLOv3 2136 -> 2118
     # with the limit lifted (same-box A/B).
     fuse_max_rows = 4096
+    fuse_max_rows_s2 = 1 << 16          # the stride-2 shift form (see _fuse_bn_sums); rows beyond 4096 are folded in place by the finalize
 
     def _fuse_pays(self, geom):
         """Per-geometry choice between the fused sums and the stand-alone reduce pass (Plan.fuse_skip = bit mask of the classes
@@ -613,7 +614,11 @@ class Plan:
             return False
         pw = e.get("pw")
         rows = int(L.pw_rows(o.M, e["geom"][3])) if pw is not None else int(L.conv2d_dgrad_bnsums_rows(dt, *e["geom"], e["head"][1]))
-        if rows <= 0 or rows > self.fuse_max_rows:
+        g = e["geom"]
+        s2_shift = pw is None and g[9] == 2 and g[7] == 3 and g[6] <= 64        # the shift kernel's stride-2 form (csrc/conv_shift.hip MODE 3): its
+        # store loop writes whole output rows from LDS and takes the y loads of the sums in its stride -- 208 -> 416: stand-alone reduce
+        # 180 us in the step against +70 us in the data gradient, at the HBM-bound tail of the backward; one row per 8 x 31 tile
+        if rows <= 0 or rows > (self.fuse_max_rows_s2 if s2_shift else self.fuse_max_rows):
             return False
         fn0, _ = self.bwd[e["idx"]]
         partial = self.f32(rows * 2 * y.C, zero=False)

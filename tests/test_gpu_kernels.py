@@ -1005,7 +1005,7 @@ def test_shift_conv_64_wide_tile_column(case):
 S2D_CASES = [(2, 64, 104, 104, 32), (1, 128, 52, 52, 64), (3, 32, 17, 45, 32), (2, 64, 8, 31, 64), (1, 32, 9, 63, 32), (32, 64, 208, 208, 32)]
 
 
-@pytest.mark.parametrize("with_add", [False, True], ids=["plain", "addsrc"])
+@pytest.mark.parametrize("with_add", [False, True, "fused"], ids=["plain", "addsrc", "addsrc+bnsums"])
 @pytest.mark.parametrize("case", S2D_CASES, ids=[str(c) for c in S2D_CASES])
 def test_shift_stride2_dgrad(case, with_add):
     """3x3 / stride-2 / pad-1 data gradients with 32 or 64 output channels run the shift kernel's stride-2 form (one accumulator set per
@@ -1021,17 +1021,46 @@ def test_shift_stride2_dgrad(case, with_add):
     dyb = to_nhwc(dy, dt)
     add = torch.randn(B, Ci, 2 * H, 2 * W, generator=gg)
     addb = to_nhwc(add, dt) if with_add else None
-    outs = {}
+    fused = with_add == "fused"
+    yb = to_nhwc(torch.randn(B, Ci, 2 * H, 2 * W, generator=gg) * 1.3 + 0.2, dt)
+    M = B * 4 * H * W
+    scale = (torch.rand(Ci, generator=gg) + 0.5).cuda(); shift = (torch.randn(Ci, generator=gg) * 0.3).cuda()
+    mean = (torch.randn(Ci, generator=gg) * 0.2 + 0.2).cuda(); invstd = (torch.rand(Ci, generator=gg) + 0.5).cuda(); gamma = (torch.rand(Ci, generator=gg) + 0.5).cuda()
+    outs, coefs = {}, {}
     for v in (-29, -60):
         L.conv2d_set_variant(v)
         try:
             dx = torch.full((B, 2 * H, 2 * W, Ci), float("nan"), dtype=TD[dt], device="cuda")
-            L.check(L.conv2d(dt, 1, dyb.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, None, addb.data_ptr() if with_add else None, Ci, None,
-                             B, H, W, Co, 2 * H, 2 * W, Ci, 3, 3, 2, 1, 1, st()), "s2 dgrad")
+            if fused:
+                prow = L.conv2d_dgrad_bnsums_rows(dt, B, H, W, Co, 2 * H, 2 * W, Ci, 3, 3, 2, 1, 1, Co)
+                assert prow > 0
+                part = torch.full((prow, 2, Ci), float("nan"), device="cuda")
+                L.check(L.conv2d_dgrad_bnsums(dt, dyb.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, addb.data_ptr(), Ci, B, H, W, Co, 2 * H, 2 * W, Ci,
+                                              3, 3, 2, 1, 1, yb.data_ptr(), Ci, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), 1, 0.1,
+                                              part.data_ptr(), st()), "fused s2 dgrad")
+                torch.cuda.synchronize()
+                assert not bool(torch.isnan(part).any())
+                coefs[v] = [torch.zeros(Ci, device="cuda") for _ in range(5)]
+                L.check(L.bn_bwd_finalize_rows(part.data_ptr(), prow, Ci, float(M), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                               *[b.data_ptr() for b in coefs[v]], st()))
+            else:
+                L.check(L.conv2d(dt, 1, dyb.data_ptr(), Co, wd.data_ptr(), dx.data_ptr(), Ci, None, addb.data_ptr() if with_add else None, Ci, None,
+                                 B, H, W, Co, 2 * H, 2 * W, Ci, 3, 3, 2, 1, 1, st()), "s2 dgrad")
             torch.cuda.synchronize()
             outs[v] = dx.float().cpu()
         finally:
             L.conv2d_set_variant(-60)
+    if fused:                                   # the sums of the shift form against a stand-alone reduce over ITS stored dx
+        acc = torch.zeros(3 * Ci, dtype=torch.float64, device="cuda")
+        pws = torch.empty(L.bn_act_bwd_reduce_ws_floats(dt, M, Ci, 2), device="cuda")
+        dxs = outs[-60].to(TD[dt]).cuda().contiguous()
+        L.check(L.bn_act_bwd_reduce(dt, dxs.data_ptr(), Ci, yb.data_ptr(), Ci, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                    None, 0, None, None, None, None, acc.data_ptr(), pws.data_ptr(), M, Ci, 1, 0.1, st()))
+        refc = [torch.zeros(Ci, device="cuda") for _ in range(5)]
+        L.check(L.bn_bwd_finalize(acc.data_ptr(), 1, 2, 1, float(M), gamma.data_ptr(), mean.data_ptr(), invstd.data_ptr(), *[b.data_ptr() for b in refc], Ci, st()))
+        torch.cuda.synchronize()
+        for a_, b_, name in zip(coefs[-60], refc, ("dgamma", "dbeta", "cA", "cB", "cC")):
+            np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=2e-4, atol=2e-4 * max(1.0, float(b_.abs().max())), err_msg=name)
     ref = F.conv_transpose2d(rnd(dt, dy), rnd(dt, w), None, stride=2, padding=1, output_padding=1)
     if with_add:
         ref = ref + rnd(dt, add)
