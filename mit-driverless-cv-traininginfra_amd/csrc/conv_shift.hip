@@ -425,8 +425,13 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
       }
       __syncthreads();
     }
-    if constexpr (FUSE)                                      // one partial row per tile (mdcv_shift_s2_rows)
-      fz3.flush(a.fuse, reinterpret_cast<float*>(smem + 512 * SROW), tid, tile_n * BN, a.Nout, tile_m);
+    if constexpr (FUSE) {                                    // one partial row per tile (mdcv_shift_s2_rows): every wave folds its sums with row swaps
+      static_assert(Acc3::kWaveFold, "bf16, at most 16 channel vectors per pixel");   // into 2*BN floats of its own, the waves meet once
+      float* ws3 = reinterpret_cast<float*>(smem + 512 * SROW);
+      fz3.fold_wave(ws3 + wave * 2 * BN, lane);
+      lds_only_barrier();
+      for (int t = tid; t < 2 * BN; t += NW * 64) Acc3::write_row(a.fuse, ws3, 2 * BN, t, tile_n * BN, a.Nout, tile_m);
+    }
     return;
   }
   // ---------------- epilogue ----------------
@@ -647,7 +652,7 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   a.xcd_chunk = (a.tiles_total + 7) / 8;
   a.nca = (BM + 2 * a.dil * (a.Wq + 1) + 15) / 16;         // KiB-chunks (16 stream rows each) of one activation chunk
   const int pipe = 2 * a.nca * 1024 + BRING * BTILE + 1024;
-  const int epi = MODE == 3 ? 512 * SROW + NW * BN * 4      // stride-2 data gradient: two column classes of the tile interleaved as output rows (+ fold scratch)
+  const int epi = MODE == 3 ? 512 * SROW + NW * 2 * BN * 4      // stride-2 data gradient: two column classes of the tile interleaved as output rows (+ fold scratch)
                             : BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics (the fused sums fold inside dead staging rows)
   const int lds = pipe > epi ? pipe : epi;
   static int attr_lds = 0;
