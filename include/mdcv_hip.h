@@ -50,6 +50,27 @@ int mdcv_conv2d_dgrad_bnsums(int dtype, const void* in, int in_ldc, const void* 
                              int add_ldc, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
                              int pad, int dil, const void* y, int ldy, const float* scale, const float* shift, const float* mean, int act,
                              float slope, float* partial, void* stream);
+/* The same launch storing g = dz * act'(scale*y + shift) in place of dz (the sums are those of g either way).  Only the stride-2 form of the
+ * 3x3 shift kernel carries it (_masked_ok() = 1: bf16, 3x3 / stride 2 / pad 1, Hout = 2 Hin, 32 or 64 output channels); anything else is
+ * MDCV_EARG.  Consumer: a first layer (no data gradient of its own) whose weight gradient is assembled from correlations of g, y and 1 with
+ * the layer input -- mdcv_conv_tap_sums / mdcv_first_layer_wgrad_combine below -- so that its BatchNorm-apply pass never runs
+ * (reference: autograd of layer 0, CVC-YOLOv3/models.py:57-71). */
+int mdcv_conv2d_dgrad_masked_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
+                                int pad, int dil, int in_ldc);
+int mdcv_conv2d_dgrad_bnsums_masked(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const void* addsrc,
+                                    int add_ldc, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
+                                    int pad, int dil, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
+                                    int act, float slope, float* partial, void* stream);
+/* X1[kh*KW + kw][c] (c < 8, fp32) = sum over images and output positions of x[b][oh*stride - pad + kh*dil][ow*stride - pad + kw*dil][c]
+ * (zero outside the image): the column sums of the layer's im2col matrix.  x: bf16 NHWC, 8 padded channels; KH, KW <= 7; ws: _ws_floats() floats. */
+long long mdcv_conv_tap_sums_ws_floats(int B, int H, int W, int KH, int KW);
+int mdcv_conv_tap_sums(int dtype, const void* x, int ldc, int B, int H, int W, int Hout, int Wout, int KH, int KW, int stride, int pad, int dil,
+                       float* ws, float* out, void* stream);
+/* dw[co][ci][t] = cA[co]*G[co][ci][t] + cB[co]*Y[co][ci][t] + cC[co]*X1[t][ci]: the weight gradient of conv -> BatchNorm -> act with
+ * dy = cA*g + cB*y + cC never formed.  G, Y: mdcv_conv2d_wgrad of g and of the forward output y against the layer input (OIHW fp32, real
+ * channel counts); cA, cB, cC: mdcv_bn_bwd_finalize_rows.  Cin <= 8. */
+int mdcv_first_layer_wgrad_combine(const float* G, const float* Y, const float* X1, const float* cA, const float* cB, const float* cC,
+                                   float* dw, int Cout, int Cin, int KK, void* stream);
 int mdcv_conv2d_stats_rows(int M);      /* generic kernels: one row per 128 output pixels */
 /* rows of stats_partial a FORWARD launch with this geometry writes (use this one to size the buffer: the 3x3 / stride-1 /
  * pad-1 shift kernel walks a padded pixel stream and writes more rows than M / 128; every row it returns is written). */

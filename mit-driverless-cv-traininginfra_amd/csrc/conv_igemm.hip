@@ -1951,6 +1951,30 @@ int mdcv_conv2d_dgrad_bnsums(int dtype, const void* in, int in_ldc, const void* 
   BnFuseArgs f;
   f.y = y; f.scale = scale; f.shift = shift; f.mean = mean; f.partial = partial; f.ldy = ldy; f.act = act; f.row_base = 0;
   f.slope = act == 2 ? 0.f : slope;
+  f.store_g = 0;
+  return conv2d_impl(dtype, 1, in, in_ldc, w_packed, out, out_ldc, nullptr, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Hout, Wout, Nout,
+                     KH, KW, stride, pad, dil, &f, stream);
+}
+
+// The same launch storing g = dz * act'(scale * y + shift) in place of dz (the BatchNorm-backward sums are those of g either way).  Only the
+// stride-2 form of the shift kernel carries it (mdcv_conv2d_dgrad_masked_ok); the consumer is a first layer whose weight gradient is then
+// assembled from three correlations with the layer input without a BatchNorm-apply pass (mdcv_first_layer_wgrad_combine).
+int mdcv_conv2d_dgrad_masked_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
+                                int pad, int dil, int in_ldc) {
+  return dtype == MDCV_BF16 && stride == 2 && dil == 1 && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win &&
+         g_conv_variant < 0 && (long long)B * Hin * Win * in_ldc * 2 < (1LL << 31) &&
+         mdcv_shift_s2_dgrad_eligible(dtype, B, Hin, Win, Cin, Nout, in_ldc);
+}
+int mdcv_conv2d_dgrad_bnsums_masked(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const void* addsrc,
+                                    int add_ldc, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
+                                    int pad, int dil, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
+                                    int act, float slope, float* partial, void* stream) {
+  if (!y || !scale || !shift || !mean || !partial || (ldy & 7)) return MDCV_EARG;
+  if (!mdcv_conv2d_dgrad_masked_ok(dtype, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW, stride, pad, dil, in_ldc)) return MDCV_EARG;
+  BnFuseArgs f;
+  f.y = y; f.scale = scale; f.shift = shift; f.mean = mean; f.partial = partial; f.ldy = ldy; f.act = act; f.row_base = 0;
+  f.slope = act == 2 ? 0.f : slope;
+  f.store_g = 1;
   return conv2d_impl(dtype, 1, in, in_ldc, w_packed, out, out_ldc, nullptr, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Hout, Wout, Nout,
                      KH, KW, stride, pad, dil, &f, stream);
 }

@@ -419,8 +419,11 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
             d = ET<bf16_t>::pack(x);
             if constexpr (FUSE) ET<bf16_t>::unpack(d, x);   // the sums see dz as stored
           }
+          if constexpr (FUSE) {
+            if (a.fuse.store_g) d = fz3.add_store_g(a.fuse, x, yq[k]);      // the first layer's backward: g = dz * act' goes to HBM, dz does not
+            else fz3.add(a.fuse, x, yq[k]);
+          }
           *reinterpret_cast<uint4*>(out3 + pixv[k] * a.out_ldc + n) = d;
-          if constexpr (FUSE) fz3.add(a.fuse, x, yq[k]);
         }
       }
       __syncthreads();

@@ -542,6 +542,71 @@ class Plan:
                   dy2.ptr if dy2 is not None else None, dy2.ldc if dy2 is not None else 0, y1.M, y1.C, act, float(slope))
         return (dy1, dy2) if y2 is not None else dy1
 
+    # ------------------------------------------------------------------ first layer: weight gradient without the BatchNorm-apply pass
+    # OFF by default: correct, tested and more accurate (dy is never rounded to bf16), but step-neutral at best.  YOLOv3 416^2 batch 32, same-box
+    # A/B (scripts/ab_step.py "A0;A1"): the tail of the backward gets 0.2 ms shorter (measured with the forward-only terms skipped) and those
+    # terms -- wgrad(y, x) 130 us alone / 260 us beside the forward, the tap sums 85 us -- cost 0.15 .. 0.3 ms wherever they are put (side stream
+    # under the 52^2 layers, behind layer 1, at the end of the forward; inline on the main stream): 13.95 -> 13.99 .. 14.11 ms.
+    first_layer_algebra = False        # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
+
+    fwd_mid_layer = None               # first packed layer whose input has shrunk to 1/8 of the image (set by the model's lowering): from there on
+                                       # the forward is MFMA- / latency-bound and leaves HBM to a side stream
+
+    def emit_first_layer_bwd(self, dout, y, bs, act, slope, cs, xnode):
+        """Backward of conv -> BatchNorm -> activation for a layer whose input needs no gradient (csrc/first_layer.hip): dy = cA g + cB y + cC
+        exists for the weight gradient alone and the correlation with the input patches is linear in it, so
+            dW = cA * wgrad(g, x) + cB * wgrad(y, x) + cC * tapsums(x)
+        with g = dz * act' stored by the data gradient that produced dz (its fused BatchNorm sums are those of g anyway).  wgrad(y, x) and the
+        tap sums depend on forward data only: they are launched from the FORWARD list in front of layer `fwd_mid_layer`, on the side stream when the plan has one
+        (both backward queues are full; the forward's side queue is empty).  The apply pass (read dz, y; write dy: 1.06 GB at YOLOv3 416^2
+        batch 32, at the HBM-bound tail of the backward) never runs, and dy is never rounded to bf16: against float64 the result is 4e-7
+        off where apply + wgrad is 0.3 % .. 3.6 % off (tests/test_gpu_kernels.py::test_first_layer_wgrad_without_bn_apply).
+        Returns False when the layer does not qualify."""
+        L, dt = self.L, self.dtype
+        x = xnode.act
+        if (not self.first_layer_algebra or xnode.needs_grad or dt != BF16 or x.C != 8 or cs.cin_pad != 8 or cs.kw > 7 or cs.kh > 7 or cs.bias is not None):
+            return False
+        g1, b1 = self.param_grad(bs.bn.weight), self.param_grad(bs.bn.bias)
+        if not self._fuse_bn_sums(dout, y, bs, act, slope, g1, b1, masked=True):
+            return False
+        gw = self.param_grad(cs.weight)
+        kk = cs.kh * cs.kw
+        G, Y = self.f32(cs.cout * cs.cin * kk, zero=False), self.f32(cs.cout * cs.cin * kk, zero=False)
+        X1 = self.f32(kk * 8, zero=False)
+        tws = self.f32(int(L.conv_tap_sums_ws_floats(x.B, x.H, x.W, cs.kh, cs.kw)), zero=False)
+        splits = int(L.conv2d_wgrad_splits_geom(dt, x.B, x.H, x.W, 8, y.H, y.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil, y.ldc, x.ldc))
+        self.ws_floats = max(self.ws_floats, splits * cs.cout_pad * kk * 8)
+        plan = self
+
+        def corr(dy, out, stream):
+            return L.conv2d_wgrad(dt, dy.ptr, dy.ldc, x.ptr, x.ldc, plan.wgrad_ws(stream).data_ptr(), splits, out.data_ptr(), 0,
+                                  x.B, x.H, x.W, 8, cs.cin, y.H, y.W, cs.cout_pad, cs.cout, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil, stream)
+
+        def forward_terms(stream):             # Y and X1: forward data only
+            side = None
+            if getattr(plan, "overlap_wgrad", False) and not plan.use_graph and "run" not in plan.__dict__ and hasattr(plan, "side"):
+                side = plan.side().cuda_stream       # the stream the backward's weight gradients use: gradient_term is ordered behind this
+                L.check(L.stream_fork(stream, side, plan.fork_device_scope), "stream_fork")
+            s = side if side is not None else stream
+            rc = L.conv_tap_sums(dt, x.ptr, x.ldc, x.B, x.H, x.W, y.H, y.W, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil, tws.data_ptr(),
+                                 X1.data_ptr(), s)
+            return rc or corr(y, Y, s)
+
+        def gradient_term(stream):             # G from the stored g, then the three terms with the coefficients the finalize just wrote
+            rc = corr(dout, G, stream)
+            return rc or L.first_layer_wgrad_combine(G.data_ptr(), Y.data_ptr(), X1.data_ptr(), bs.cA.data_ptr(), bs.cB.data_ptr(),
+                                                     bs.cC.data_ptr(), gw.data_ptr(), cs.cout, cs.cin, kk, stream)
+        forward_terms.__name__ = "first_layer_forward_terms"
+        gradient_term.__name__ = "conv2d_wgrad"                                # (side stream, run_bwd_list)
+        gradient_term.info = (x.B, x.H, x.W, 8, y.H, y.W, cs.cout_pad, cs.kh, cs.stride, splits)
+        k = self.fwd_mid_layer
+        pos = self.layer_marks[k] if k is not None and k < len(self.layer_marks) else len(self.fwd)
+        self.fwd.insert(pos, (forward_terms, ()))
+        self.layer_marks = [m + 1 if m >= pos else m for m in self.layer_marks]
+        self.bwd.append((gradient_term, ()))
+        self.first_layer_fused = True
+        return True
+
     # On by default (Plan.fuse_bn = False restores the two-pass form).  YOLOv3 416^2 B=32: it removes 0.95 ms of stand-alone reduce kernels
     # per step and adds ~1.1 ms to the 66 data gradients' store loops (the y loads are HBM misses whose latency is exposed once per
     # 128-row group at the end of each tile) -- neutral while everything ran on one stream, +0.9 % (2039 -> 2058 img/s, same-box A/B)
@@ -591,7 +656,7 @@ class Plan:
             return not (k & 128)
         return True
 
-    def _fuse_bn_sums(self, dout, y, bs, act, slope, dgamma, dbeta):
+    def _fuse_bn_sums(self, dout, y, bs, act, slope, dgamma, dbeta, masked=False):
         """Fold the BatchNorm-backward reduction over (dout, y) into the store loop of the data gradient that wrote `dout`.
 
         Legal when that launch is the LAST writer of the buffer (nothing between it and this point of the backward list mentions
@@ -610,15 +675,18 @@ class Plan:
             if dout.ptr in args:
                 return False
         L, dt = self.L, self.dtype
-        if not self._fuse_pays(e["geom"]):
-            return False
         pw = e.get("pw")
-        rows = int(L.pw_rows(o.M, e["geom"][3])) if pw is not None else int(L.conv2d_dgrad_bnsums_rows(dt, *e["geom"], e["head"][1]))
         g = e["geom"]
-        s2_shift = pw is None and g[9] == 2 and g[7] == 3 and g[6] <= 64        # the shift kernel's stride-2 form (csrc/conv_shift.hip MODE 3): its
+        s2_shift = pw is None and bool(L.conv2d_dgrad_masked_ok(dt, *g, e["head"][1]))    # the shift kernel's stride-2 form (csrc/conv_shift.hip MODE 3): its
         # store loop writes whole output rows from LDS and takes the y loads of the sums in its stride -- 208 -> 416: stand-alone reduce
-        # 180 us in the step against +70 us in the data gradient, at the HBM-bound tail of the backward; one row per 8 x 31 tile
+        # 180 us in the step against +70 us in the data gradient, at the HBM-bound tail of the backward; one row per 8 x 31 tile.
+        # (It pays at every size: the pixel classes of _fuse_pays describe the per-class im2col launches.)
+        if not s2_shift and not self._fuse_pays(g):
+            return False
+        rows = int(L.pw_rows(o.M, g[3])) if pw is not None else int(L.conv2d_dgrad_bnsums_rows(dt, *g, e["head"][1]))
         if rows <= 0 or rows > (self.fuse_max_rows_s2 if s2_shift else self.fuse_max_rows):
+            return False
+        if masked and not s2_shift:    # (emit_first_layer_bwd: the launch stores g, not dz; only that form can)
             return False
         fn0, _ = self.bwd[e["idx"]]
         partial = self.f32(rows * 2 * y.C, zero=False)
@@ -630,9 +698,9 @@ class Plan:
         else:
             assert fn0 is L.conv2d
             h = e["head"]
-            self.bwd[e["idx"]] = (L.conv2d_dgrad_bnsums, (dt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], *e["geom"], y.ptr, y.ldc,
-                                                           bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope),
-                                                           partial.data_ptr()))
+            self.bwd[e["idx"]] = (L.conv2d_dgrad_bnsums_masked if masked else L.conv2d_dgrad_bnsums,
+                                  (dt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], *e["geom"], y.ptr, y.ldc,
+                                   bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope), partial.data_ptr()))
         e["used"] = True
         self.call(self.bwd, L.bn_bwd_finalize_rows, partial.data_ptr(), rows, y.C, float(y.M), bs.bn.weight.data_ptr(),
                   bs.mean.data_ptr(), bs.invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bs.cA.data_ptr(), bs.cB.data_ptr(),

@@ -688,6 +688,8 @@ class Darknet(FlatParamsMixin, nn.Module):
                     if pw_lb is not None:
                         plan.fwd.pop()                       # that bn_act_fwd entry is replaced by the fused launch below
                 cs = ConvSpec(plan, conv.weight, conv.bias, conv.stride[0], conv.padding[0], 1, cin_pad=cur.act.C)
+                if plan.fwd_mid_layer is None and cur.act.H * 8 <= xin.act.H:
+                    plan.fwd_mid_layer = len(plan.pack_list)          # (the first layer's forward-only gradient terms start here on the side stream)
                 plan.emit_pack(cs, need_dgrad=with_targets and cur.needs_grad)
                 ho, wo = shp[i][1], shp[i][2]
                 if has_bn:
@@ -845,7 +847,9 @@ class Darknet(FlatParamsMixin, nn.Module):
                         continue
                     if rnode is not None:
                         plan.grad_identity(rnode, z.grad)
-                    if not plan.emit_pw_bwd(z.grad, y, bs, act_code, slope, cs, xn):
+                    if rnode is None and z.gstate == "own" and plan.emit_first_layer_bwd(z.grad, y, bs, act_code, slope, cs, xn):
+                        pass                   # (z.grad is this layer's alone: the data gradient that wrote it may store g = dz * act' instead)
+                    elif not plan.emit_pw_bwd(z.grad, y, bs, act_code, slope, cs, xn):
                         dy = plan.emit_bn_act_bwd(z.grad, y, bs, act_code, slope)
                         plan.emit_conv_bwd(cs, xn, y, dy)
                 elif kind == "shortcut":
