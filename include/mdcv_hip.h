@@ -71,6 +71,24 @@ int mdcv_conv_tap_sums(int dtype, const void* x, int ldc, int B, int H, int W, i
  * channel counts); cA, cB, cC: mdcv_bn_bwd_finalize_rows.  Cin <= 8. */
 int mdcv_first_layer_wgrad_combine(const float* G, const float* Y, const float* X1, const float* cA, const float* cB, const float* cC,
                                    float* dw, int Cout, int Cin, int KK, void* stream);
+/* Forward statistics WITHOUT a finalize launch.  mdcv_conv2d_statsfold = mdcv_conv2d(mode 0) with stats_partial, and additionally the
+ * workgroup that completes a group of G consecutive partial rows (G even) sums them in row order into super[group][2][Nout]
+ * (ceil(rows / G) groups; rows = mdcv_conv2d_stats_rows_geom of the geometry).  counters: ceil(rows / G) * (Nout / 32 + 1) 32-bit words, ZERO
+ * before the launch.  _ok() = 1 where the forward kernel of the geometry carries it (bf16, 3x3 / stride 1 / pad 1 shift kernel); else MDCV_EARG.
+ * Consumer: mdcv_bn_act_fwd_statsfold -- BatchNorm(batch statistics) + activation (+ residual) whose prologue finishes the statistics from
+ * the super rows (ngroups * ceil(C / 256) <= 16) and writes scale / shift / mean / invstd / running statistics as mdcv_bn_stats_finalize does (C <= 1024).
+ * Replaces conv -> mdcv_bn_stats_finalize -> mdcv_bn_act_fwd of the reference's nn.Sequential(conv, BatchNorm2d, LeakyReLU)
+ * (CVC-YOLOv3/models.py:57-71) by two launches. */
+int mdcv_conv2d_statsfold_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride, int pad,
+                             int dil, int in_ldc);
+int mdcv_conv2d_statsfold(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const float* bias,
+                          float* stats_partial, float* super, void* counters, int G, int rows, int B, int Hin, int Win, int Cin, int Hout,
+                          int Wout, int Nout, int KH, int KW, int stride, int pad, int dil, void* stream);
+int mdcv_bn_act_fwd_statsfold(int dtype, const void* y, int ldy, const float* super, int ngroups, double count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                              float* shift, float* mean, float* invstd, const void* resid, int ldr, void* out, int ldo, int M, int C,
+                              int act, float slope, void* stream);
+int mdcv_bn_act_fwd_statsfold_blocks(int n);   /* tuning hook: workgroup target of mdcv_bn_act_fwd_statsfold (default 512) */
 int mdcv_conv2d_stats_rows(int M);      /* generic kernels: one row per 128 output pixels */
 /* rows of stats_partial a FORWARD launch with this geometry writes (use this one to size the buffer: the 3x3 / stride-1 /
  * pad-1 shift kernel walks a padded pixel stream and writes more rows than M / 128; every row it returns is written). */

@@ -1818,7 +1818,8 @@ extern "C" {
 static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc,
                        const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
                        int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
-                       int KH, int KW, int stride, int pad, int dil, const BnFuseArgs* fuse, void* stream, const EpiArgs* epi = nullptr) {
+                       int KH, int KW, int stride, int pad, int dil, const BnFuseArgs* fuse, void* stream, const EpiArgs* epi = nullptr,
+                       const StatsFoldArgs* fold = nullptr) {
   if (!in || !w_packed || !out) return MDCV_EARG;
   if (epi && (mode != 0 || stats_partial || fuse)) return MDCV_EARG;        // the inference epilogue is a forward-only, statistics-free path
   if ((Cin & 7) || (Nout & 7) || (in_ldc & 7) || (out_ldc & 7) || (addsrc && (add_ldc & 7))) return MDCV_EARG;
@@ -1876,7 +1877,8 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   // 3x3 / stride 1 / pad 1 on wide layers: nine shifted GEMMs over one LDS-resident activation chunk (conv_shift.hip)
   const bool shift_ok = Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc);
   if (shift_ok && (g_conv_variant < 0 || fuse))
-    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st, epi, dil);
+    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st, epi, dil, fold);
+  if (fold) return MDCV_EARG;                     // (only the kernels above fold their statistics rows: mdcv_conv2d_statsfold_ok)
   if (fuse) {                                     // the fused store loop lives in the LDS-DMA kernels: never fall back to the staged ones
     if (!small) return MDCV_EARG;
     const int keep = g_conv_variant;
@@ -1903,6 +1905,25 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
                 int KH, int KW, int stride, int pad, int dil, void* stream) {
   return conv2d_impl(dtype, mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hin, Win, Cin, Hout, Wout, Nout,
                      KH, KW, stride, pad, dil, nullptr, stream);
+}
+
+// Forward conv with BatchNorm statistics whose partial rows are summed per group of G rows INSIDE the launch (stats_fold.h): the consumer
+// (mdcv_bn_act_fwd_statsfold) finishes the statistics in its prologue and no finalize launch runs between the two.
+int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, int in_ldc);
+int mdcv_conv2d_statsfold_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride, int pad,
+                             int dil, int in_ldc) {
+  return dtype == MDCV_BF16 && g_conv_variant < 0 && Hin == Hout && Win == Wout &&
+         mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc);
+}
+int mdcv_conv2d_statsfold(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const float* bias,
+                          float* stats_partial, float* super, void* counters, int G, int rows, int B, int Hin, int Win, int Cin, int Hout,
+                          int Wout, int Nout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+  if (!stats_partial || !super || !counters || G < 2 || (G & 1) || rows < 1) return MDCV_EARG;
+  if (!mdcv_conv2d_statsfold_ok(dtype, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW, stride, pad, dil, in_ldc)) return MDCV_EARG;
+  if (rows != mdcv_conv2d_stats_rows_geom(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc)) return MDCV_EARG;
+  const StatsFoldArgs f{super, reinterpret_cast<unsigned*>(counters), G, rows};
+  return conv2d_impl(dtype, 0, in, in_ldc, w_packed, out, out_ldc, bias, nullptr, 0, stats_partial, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW,
+                     stride, pad, dil, nullptr, stream, nullptr, &f);
 }
 
 // Data gradient (mode 1 of mdcv_conv2d, same geometry arguments) that ALSO writes the BatchNorm-backward partial sums of the

@@ -527,6 +527,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
       }
   __syncthreads();
   constexpr int GR = (BM == 128 || BM == 256) ? 128 : BM;   // stream positions per partial-statistics row (192- / 384-row tiles: one row per tile)
+  constexpr bool kFold = MODE == 0 && !FUSE && !EPI;         // forward launches with statistics: the rows may be folded per group inside the launch (stats_fold.h)
   constexpr int G = BM / GR, WPG = WM / G;                 // rows per tile; waves (in M) per row
   if (a.stats && tid < BN * G) {
     const int g = tid / BN, col = tid - g * BN;
@@ -537,8 +538,13 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
       for (int w2 = 0; w2 < WPG; ++w2) { s += sstat[((g * WPG + w2) * 2 + 0) * BN + col]; qq += sstat[((g * WPG + w2) * 2 + 1) * BN + col]; }
       const size_t srow = (size_t)(p0 / GR) + g;
       if (srow * GR < (size_t)a.Mq) {                       // the last tile may reach past the stream: the caller holds ceil(Mq/GR) rows
-        a.stats[(srow * 2 + 0) * a.Nout + n] = s;           // (an unguarded second row of the last 256-row tile wrote 2*Nout floats past
-        a.stats[(srow * 2 + 1) * a.Nout + n] = qq;          //  the buffer whenever ceil(Mq/128) was odd, e.g. batch 32 at 52/26/13)
+        if (kFold && a.fold.super) {                        // write-through: another workgroup may sum these rows inside this launch (stats_fold.h)
+          sf_store(a.stats + (srow * 2 + 0) * a.Nout + n, s);
+          sf_store(a.stats + (srow * 2 + 1) * a.Nout + n, qq);
+        } else {
+          a.stats[(srow * 2 + 0) * a.Nout + n] = s;         // (an unguarded second row of the last 256-row tile wrote 2*Nout floats past
+          a.stats[(srow * 2 + 1) * a.Nout + n] = qq;        //  the buffer whenever ceil(Mq/128) was odd, e.g. batch 32 at 52/26/13)
+        }
       }
     }
   }
@@ -560,6 +566,16 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
           d = ET<bf16_t>::pack(x);
         }
         *reinterpret_cast<uint4*>(out + ((size_t)pix * a.out_ldc + n)) = d;
+      }
+    }
+    if constexpr (kFold) {
+      if (a.stats && a.fold.super) {                        // (uniform) behind the store loop, so that the write-through of the rows and the counter's
+        const int srow0 = p0 / GR;                          // round trip cost this workgroup nothing while it still has stores to issue
+        int nr = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) nr += (size_t)(srow0 + g) * GR < (size_t)a.Mq;
+        const int grp = sf_arrive(a.fold, srow0, nr, tile_n, a.tiles_n, reinterpret_cast<volatile int*>(smem + STAT_OFF), tid);
+        if (grp >= 0) sf_fold<NW * 64>(a.fold, a.stats, grp, tile_n * BN, BN, a.Nout, tid, reinterpret_cast<float*>(smem));   // this tile completed its row group
       }
     }
   } else {
@@ -819,8 +835,10 @@ int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil) {
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
                     int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st,
-                    const EpiArgs* epi, int dil) {
+                    const EpiArgs* epi, int dil, const StatsFoldArgs* fold) {
   ShiftArgs a;
+  if (fold && mode == 0 && stats && !epi) a.fold = *fold; else a.fold = StatsFoldArgs{nullptr, nullptr, 0, 0};
+  if (fold && !a.fold.super) return MDCV_EARG;
   if (fuse) a.fuse = *fuse; else a.fuse = BnFuseArgs{};
   if (epi) a.epi = *epi; else a.epi = EpiArgs{nullptr, 0, 0.f};
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addsrc = addsrc; a.stats = stats;

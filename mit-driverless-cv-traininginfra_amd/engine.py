@@ -210,6 +210,7 @@ class Plan:
         self.on_ready = None               # set per backward by the data-parallel reducer
         self.dgrad_entries = {}            # grad buffer ptr -> backward-list entry of the data gradient that wrote it last
         self.fused_bn = 0                  # BatchNorm backward reductions folded into data-gradient store loops
+        self._fold_candidates, self._fold_arena, self.stats_folded = [], None, 0
 
     # ------------------------------------------------------------------ buffers
     def new_act(self, B, H, W, C, zero=False):
@@ -433,6 +434,64 @@ class Plan:
                   bs2.scale.data_ptr() if bs2 is not None else None, bs2.shift.data_ptr() if bs2 is not None else None,
                   resid.ptr if resid is not None else None, resid.ldc if resid is not None else 0,
                   out.ptr, out.ldc, out.M, out.C, act, float(slope))
+
+    # ---- forward BatchNorm statistics without a finalize launch (csrc/stats_fold.h).  What-if timing of the YOLOv3 step without its 72
+    # mdcv_bn_stats_finalize launches (scripts/ab_step.py "Xbn_stats_finalize"): 13.79 -> 12.94 ms -- 6 us kernels, 12 us of critical path each.
+    # Built for the 3x3 shift kernel + mdcv_bn_act_fwd consumers (22 layers of YOLOv3), correct and bit-reproducible, and OFF: the hand-off
+    # costs what the launch cost.  Consumer alone (scripts/fold_ab.py): 13^2 x 1024 8.9 us against 14.8 for finalize + apply, 26^2 x 512 12.6 vs
+    # 15.7, 52^2 x 256 22.8 vs 19.8 (every workgroup re-derives all channels' coefficients); the producer's tail (drain of its stores, counter
+    # round trip, the completing workgroup's fold) takes the rest back: step 13.90 -> 13.99 ms (same-box A/B, "T0;T1").
+    stats_fold = False                 # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
+    stats_fold_counters = 1 << 16      # 32-bit words of the counter arena (zeroed by one memset at the head of the forward list)
+
+    def note_stats_fold(self, conv, fin, act, cs, x, y, bs, partial, rows, out, act_code, slope, resid):
+        """Remember one conv -> statistics finalize -> BatchNorm-apply triple of the forward list (the three list entries themselves) for
+        fold_forward_stats, which runs after the whole list is built: a later peephole may still replace the apply entry."""
+        self._fold_candidates.append((conv, fin, act, cs, x, y, bs, partial, rows, out, act_code, float(slope), resid))
+
+    def fold_forward_stats(self):
+        """Rewrite conv / finalize / apply triples into mdcv_conv2d_statsfold + mdcv_bn_act_fwd_statsfold where the library can."""
+        L, dt = self.L, self.dtype
+        cands, self._fold_candidates = self._fold_candidates, []
+        if not self.stats_fold or dt != BF16 or not cands:
+            return 0
+        arena = self._fold_arena
+        if arena is None:
+            return 0
+        used, done = 0, 0
+        for conv, fin, act, cs, x, y, bs, partial, rows, out, act_code, slope, resid in cands:
+            idx = [i for i, e in enumerate(self.fwd) if e is conv]
+            if len(idx) != 1:
+                continue
+            i = idx[0]
+            if i + 2 > len(self.fwd) - 1 or self.fwd[i + 1] is not fin or self.fwd[i + 2] is not act:
+                continue
+            geom = (x.B, x.H, x.W, cs.cin_pad, y.H, y.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
+            if y.C > 1024 or rows < 4 or not int(L.conv2d_statsfold_ok(dt, *geom, x.ldc)):
+                continue
+            ng = 16 // (1 if y.C <= 256 else (2 if y.C <= 512 else 4))      # (the consumer's prologue holds ngroups * ceil(C / 256) <= 16 value pairs per thread)
+            G = 2 * ((rows + 2 * ng - 1) // (2 * ng))
+            ngroups = (rows + G - 1) // G
+            need = ngroups * (cs.cout_pad // 32 + 1)
+            if used + need > arena.numel():
+                continue
+            cnt = arena[used:used + need]
+            used += need
+            sup = self.f32(ngroups * 2 * y.C, zero=False)
+            bn = bs.bn
+            self.fwd[i] = (L.conv2d_statsfold, (dt, x.ptr, x.ldc, cs.wf.data_ptr(), y.ptr, y.ldc,
+                                                cs.bias_pad.data_ptr() if cs.bias_pad is not None else None, partial.data_ptr(), sup.data_ptr(),
+                                                cnt.data_ptr(), G, rows, *geom))
+            self.fwd[i + 2] = (L.bn_act_fwd_statsfold, (dt, y.ptr, y.ldc, sup.data_ptr(), ngroups, float(y.M), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                                                        bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), bs.invstd.data_ptr(),
+                                                        resid.ptr if resid is not None else None, resid.ldc if resid is not None else 0,
+                                                        out.ptr, out.ldc, out.M, out.C, act_code, slope))
+            del self.fwd[i + 1]
+            self.layer_marks = [m - 1 if m > i + 1 else m for m in self.layer_marks]
+            done += 1
+        self.stats_folded = done
+        return done
 
     # ---- 1x1 conv blocks with the neighbouring BatchNorm pass folded into the operand load (csrc/pw_block.hip).  Policy from same-box
     # timing of the fused launch against the pair it replaces (scripts/pw_block_ab.py alone, scripts/pw_diag.py inside a serial step;

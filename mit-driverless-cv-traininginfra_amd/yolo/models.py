@@ -659,6 +659,10 @@ class Darknet(FlatParamsMixin, nn.Module):
             return plan.new_act(B, h_, w_, c_)
 
         plan.call(plan.fwd, _zero_tensor, plan.out7)
+        if bn_train and plan.stats_fold and dt == _lib.BF16:      # counters of the in-launch statistics folds (engine.fold_forward_stats): one memset per forward
+            plan._fold_arena = torch.zeros(plan.stats_fold_counters, dtype=torch.int32, device=device)
+            plan.keep.append(plan._fold_arena)
+            plan.call(plan.fwd, _zero_tensor, plan._fold_arena)
         outs = [None] * n
         recs = []
         cur = xin
@@ -692,6 +696,7 @@ class Darknet(FlatParamsMixin, nn.Module):
                     plan.fwd_mid_layer = len(plan.pack_list)          # (the first layer's forward-only gradient terms start here on the side stream)
                 plan.emit_pack(cs, need_dgrad=with_targets and cur.needs_grad)
                 ho, wo = shp[i][1], shp[i][2]
+                fold_c = None
                 if has_bn:
                     bn = mods[i][1]
                     bs = BnSpec(plan, bn)
@@ -708,7 +713,9 @@ class Darknet(FlatParamsMixin, nn.Module):
                         rows = plan.stats_rows(cs, cur.act, y)
                         partial = plan.f32(rows * 2 * y.C, zero=False)
                         plan.emit_conv_fwd(cs, cur.act, y, partial)
+                        fold_c = [plan.fwd[-1]]
                         plan.emit_bn_stats(bs, y, partial, rows)
+                        fold_c += [plan.fwd[-1], cs, cur.act, y, bs, partial, rows]
                         nbt.append(bn.num_batches_tracked)
                     else:
                         one_launch = _EVAL_FUSE and not with_targets       # inference: BN + activation in the conv's store path
@@ -722,6 +729,8 @@ class Darknet(FlatParamsMixin, nn.Module):
                             plan.emit_conv_bn_act_eval(cs, bs, cur.act, z.act, act_code, slope, resid=rnode.act)
                         else:
                             plan.emit_bn_act_fwd(y, bs, z.act, act_code, slope, resid=rnode.act)
+                            if fold_c:
+                                plan.note_stats_fold(fold_c[0], fold_c[1], plan.fwd[-1], *fold_c[2:], z.act, act_code, slope, rnode.act)
                         fused_into[i + 1] = z
                         recs.append(("convbn", cs, bs, cur, y, z, rnode))
                         outs[i] = None
@@ -731,6 +740,8 @@ class Darknet(FlatParamsMixin, nn.Module):
                             plan.emit_conv_bn_act_eval(cs, bs, cur.act, z.act, act_code, slope)
                         else:
                             plan.emit_bn_act_fwd(y, bs, z.act, act_code, slope)
+                            if fold_c:
+                                plan.note_stats_fold(fold_c[0], fold_c[1], plan.fwd[-1], *fold_c[2:], z.act, act_code, slope, None)
                         recs.append(("convbn", cs, bs, cur, y, z, None))
                         outs[i] = z
                     cur = z
@@ -822,6 +833,7 @@ class Darknet(FlatParamsMixin, nn.Module):
                 outs[i] = cur
         if bn_train and nbt:
             plan.call(plan.fwd, _bump_counters, nbt)
+        plan.fold_forward_stats()          # conv -> finalize -> apply triples that survived the peepholes become two launches (csrc/stats_fold.h)
         plan.finish_pack(0)
 
         # ---- backward list: mirror of the records, consumers before producers

@@ -1071,6 +1071,86 @@ def test_shift_stride2_dgrad(case, with_add):
     torch.testing.assert_close(outs[-60], outs[-29], rtol=1e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("G", [12, 44, 180])
+@pytest.mark.parametrize("case", [(32, 128, 52, 52, 256), (32, 256, 26, 26, 512), (32, 512, 13, 13, 1024), (3, 64, 37, 41, 128), (2, 32, 20, 24, 64),
+                                  (4, 32, 104, 104, 64)], ids=str)
+def test_conv_statsfold_without_finalize_launch(case, G):
+    """conv 3x3 -> BatchNorm(batch statistics) -> LeakyReLU (+ residual) as TWO launches: mdcv_conv2d_statsfold sums the partial statistics rows per
+    group of G inside the launch (the workgroup that completes a group; agent-scope counter, write-through rows: csrc/stats_fold.h) and
+    mdcv_bn_act_fwd_statsfold finishes the statistics in its prologue, against the three-launch form conv -> mdcv_bn_stats_finalize ->
+    mdcv_bn_act_fwd on the same buffers: conv output and partial rows bit-identical, super rows == the row sums of each group (fp32, row order:
+    bit-identical to a torch cumulative check within 1e-6), scale / shift / mean / invstd / running statistics within fp32 rounding of the
+    different summation order, activations equal up to one bf16 rounding on a handful of elements.  Run three times with re-zeroed counters:
+    bit-identical every time (the fold's order does not depend on which workgroup performs it).  case = (B, Cin, H, W, Cout)."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, H, W, Co = case
+    gg = torch.Generator().manual_seed(B + Ci + W + G)
+    x = torch.randn(B, Ci, H, W, generator=gg)
+    w = torch.randn(Co, Ci, 3, 3, generator=gg) / (Ci * 9) ** 0.5
+    xb = to_nhwc(x, dt)
+    wf, _ = pack(dt, w, need_d=False)
+    res = to_nhwc(torch.randn(B, Co, H, W, generator=gg), dt)
+    M = B * H * W
+    gamma = (torch.rand(Co, generator=gg) + 0.5).cuda(); beta = (torch.randn(Co, generator=gg) * 0.3).cuda()
+    geom = (B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1)
+    assert L.conv2d_statsfold_ok(dt, *geom, Ci) == 1
+    rows = L.conv2d_stats_rows_geom(dt, B, H, W, Ci, Co, 3, 3, 1, 1, 1, Ci)
+    ngroups = (rows + G - 1) // G
+    if ngroups * (1 if Co <= 256 else (2 if Co <= 512 else 4)) > 16:
+        pytest.skip("more super rows than the consumer's prologue holds")
+
+    def three_launches():
+        y = torch.full((B, H, W, Co), float("nan"), dtype=TD[dt], device="cuda")
+        stats = torch.full((rows, 2, Co), float("nan"), device="cuda")
+        L.check(L.conv2d(dt, 0, xb.data_ptr(), Ci, wf.data_ptr(), y.data_ptr(), Co, None, None, 0, stats.data_ptr(), *geom, st()), "conv")
+        co = [torch.zeros(Co, device="cuda") for _ in range(4)]
+        rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        scratch = torch.zeros(3 * Co, dtype=torch.float64, device="cuda")
+        L.check(L.bn_stats_finalize(stats.data_ptr(), rows, scratch.data_ptr(), float(M), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                    0.1, 1e-5, *[c.data_ptr() for c in co], Co, st()))
+        z = torch.full((B, H, W, Co), float("nan"), dtype=TD[dt], device="cuda")
+        L.check(L.bn_act_fwd(dt, y.data_ptr(), Co, co[0].data_ptr(), co[1].data_ptr(), None, 0, None, None, res.data_ptr(), Co, z.data_ptr(), Co, M, Co,
+                             1, 0.1, st()))
+        torch.cuda.synchronize()
+        return y, stats, co, rm, rv, z
+
+    def two_launches():
+        y = torch.full((B, H, W, Co), float("nan"), dtype=TD[dt], device="cuda")
+        stats = torch.full((rows, 2, Co), float("nan"), device="cuda")
+        sup = torch.full((ngroups, 2, Co), float("nan"), device="cuda")
+        cnt = torch.zeros(ngroups * (Co // 32 + 1), dtype=torch.int32, device="cuda")
+        L.check(L.conv2d_statsfold(dt, xb.data_ptr(), Ci, wf.data_ptr(), y.data_ptr(), Co, None, stats.data_ptr(), sup.data_ptr(), cnt.data_ptr(), G, rows,
+                                   *geom, st()), "conv + fold")
+        co = [torch.full((Co,), float("nan"), device="cuda") for _ in range(4)]
+        rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        z = torch.full((B, H, W, Co), float("nan"), dtype=TD[dt], device="cuda")
+        L.check(L.bn_act_fwd_statsfold(dt, y.data_ptr(), Co, sup.data_ptr(), ngroups, float(M), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                       0.1, 1e-5, *[c.data_ptr() for c in co], res.data_ptr(), Co, z.data_ptr(), Co, M, Co, 1, 0.1, st()))
+        torch.cuda.synchronize()
+        return y, stats, co, rm, rv, z, sup
+
+    ya, sa, ca, rma, rva, za = three_launches()
+    runs = [two_launches() for _ in range(3)]
+    yb, sb, cb, rmb, rvb, zb, sup = runs[0]
+    assert torch.equal(ya, yb) and torch.equal(sa, sb)
+    assert not bool(torch.isnan(sup).any())
+    pad = torch.zeros(ngroups * G - rows, 2, Co, device="cuda")
+    ref_sup = torch.cat([sb, pad]).reshape(ngroups, G, 2, Co).double().sum(1)
+    np.testing.assert_allclose(sup.double().cpu().numpy(), ref_sup.cpu().numpy(), rtol=2e-6, atol=1e-4)
+    for a_, b_, name in zip(ca, cb, ("scale", "shift", "mean", "invstd")):
+        np.testing.assert_allclose(b_.cpu().numpy(), a_.cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=name)
+    np.testing.assert_allclose(rmb.cpu().numpy(), rma.cpu().numpy(), rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(rvb.cpu().numpy(), rva.cpu().numpy(), rtol=2e-5, atol=2e-7)
+    diff = (za.float() != zb.float())
+    assert float(diff.float().mean()) < 2e-3, float(diff.float().mean())
+    torch.testing.assert_close(zb.float(), za.float(), rtol=1.6e-2, atol=1e-3)
+    for r in runs[1:]:
+        assert torch.equal(r[6], sup) and torch.equal(r[5], zb) and all(torch.equal(p, q) for p, q in zip(r[2], cb))
+    assert L.conv2d_statsfold(dt, xb.data_ptr(), Ci, wf.data_ptr(), yb.data_ptr(), Co, None, sb.data_ptr(), sup.data_ptr(), runs[0][6].data_ptr(), 3, rows,
+                              *geom, st()) != 0       # odd G
+
+
 @pytest.mark.parametrize("case", [(2, 3, 33, 47, 3, 3, 1, 1, 1), (3, 3, 40, 40, 7, 7, 2, 3, 1), (2, 5, 21, 300, 3, 3, 2, 1, 1), (1, 8, 30, 26, 3, 3, 1, 2, 2),
                                   (2, 3, 16, 20, 1, 1, 1, 0, 1), (2, 3, 17, 19, 5, 3, 1, 1, 1)], ids=str)
 def test_conv_tap_sums(case):
