@@ -2029,6 +2029,7 @@ int mdcv_conv2d_set_variant(int v) {
   //   -29 / -60  stride-2 data gradients with 32 / 64 output channels through the shift kernel off / on
   //   -30 / -31 / -32  shift-kernel K loop of forward launches: lockstep / ping-pong everywhere / ping-pong where measured faster (default)
   //   -200 / -201  384-row ping-pong tiles: by the plan / forced on every forward launch they fit
+  //   -63 / -64  3x3 data gradients with few positions and > 64 channels (13^2 layers) on 256 x 64 tiles off / on
   if (v <= -3 && v >= -299) { mdcv_shift_set_ring(-v); v = -1; }
   if (v == 93 || v == 92) { g_conv_fuse_narrow = v == 93; return MDCV_OK; }
   if (v >= 60 && v < 92) { g_conv_deep_small = v - 60; return MDCV_OK; }

@@ -53,6 +53,7 @@ int g_shift_c8 = 0;   // 8-channel inputs (YOLOv3's first layer: 3 -> 8 padded c
                       // SLOWER than the im2col kernel, 240 vs 159 us at 416^2 (4x the MFMAs, 23 296 tiles of 9 K steps): off (set_variant(-61) off / (-62) on)
 int g_shift_2d = 1;   // images wider than the 1-D stream takes (below) run as 2-D pixel tiles of 8 x 30 outputs (set_variant(-27) off / (-28) on)
 int g_shift_big = 0;   // A/B: 384 forces the 384-row ping-pong tiles on every forward launch they fit
+int g_shift_n64_wide = 1;   // data gradients with few positions and > 64 channels on 256 x 64 tiles (see mdcv_shift_launch_dgrad)
 int g_shift_plan = 0;   // 0 / 5: default plan (192-row tiles where they save a round) ; 1: 256-row tiles only ; 2: 128-row only ; 6: never 192-row
 #else
 extern int g_shift_ring;
@@ -61,7 +62,7 @@ extern int g_shift_wmax_n32;
 extern int g_shift_dil2;
 extern int g_shift_n64;
 extern int g_shift_wmax;
-extern int g_shift_plan;
+extern int g_shift_plan, g_shift_n64_wide;
 extern int g_shift_loop;
 extern int g_shift_big;
 extern int g_shift_2d;
@@ -778,6 +779,14 @@ int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_byte
   }
   if (a.Nout == 32) return launch_shift_mode<1, 32>(a, st, in_bytes, w_bytes);
   if (a.Nout == 64) return launch_shift_mode<1, 64>(a, st, in_bytes, w_bytes);
+  // Few positions, many channels (13^2 x 32 images, 1024 -> 512: 25 x 4 tiles of 256 x 128): the plan below would fall back to 128-row tiles,
+  // which stream the same 2.4 MB of weights per tile for half the MFMA work.  256 x 64 tiles give the same number of workgroups with half
+  // the weight stream each (variant -64 / -63: on / off).
+  if (g_shift_n64_wide && !a.t2d && a.Nout % 64 == 0 && ((a.Mq + 255) / 256) * a.tiles_n <= 128) {
+    ShiftArgs b = a;
+    b.tiles_n = a.Nout / 64;
+    return launch_shift_mode<1, 64>(b, st, in_bytes, w_bytes);
+  }
   return launch_shift_mode<1, 128>(a, st, in_bytes, w_bytes);
 }
 #else
@@ -868,7 +877,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   return launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring == 61 || ring == 62) { g_shift_c8 = ring - 61; return; } if (ring == 29 || ring == 60) { g_shift_s2 = ring == 60; return; } if (ring == 27 || ring == 28) { g_shift_2d = ring - 27; return; } if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring == 63 || ring == 64) { g_shift_n64_wide = ring - 63; return; } if (ring == 61 || ring == 62) { g_shift_c8 = ring - 61; return; } if (ring == 29 || ring == 60) { g_shift_s2 = ring == 60; return; } if (ring == 27 || ring == 28) { g_shift_2d = ring - 27; return; } if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

@@ -16,13 +16,13 @@ e0 = ctypes.c_void_p(); e1 = ctypes.c_void_p(); L.event_create(ctypes.byref(e0))
 for (B, H, Ci, Co, k, s, mode) in SHAPES:
     pad = (k - 1) // 2
     Ho = (H + 2 * pad - k) // s + 1
-    nsets = 6
+    nsets = int(os.environ.get("NSETS", "6"))
     xs = [torch.randn(B * H * H * Ci, device="cuda").to(torch.bfloat16) for _ in range(nsets)]
     ys = [torch.randn(B * Ho * Ho * Co, device="cuda").to(torch.bfloat16) for _ in range(nsets)]
-    wf = (torch.randn(Co * k * k * Ci, device="cuda") * 0.05).to(torch.bfloat16)
+    wfs = [(torch.randn(Co * k * k * Ci, device="cuda") * 0.05).to(torch.bfloat16) for _ in range(nsets if os.environ.get("COLDW") else 1)]
     stt = torch.zeros(L.conv2d_stats_rows_geom(1, B, Ho, Ho, Ci, Co, k, k, s, pad, 1, Ci) * 2 * Co + 4096, device="cuda")
     def call(i):
-        x, y = xs[i % nsets], ys[i % nsets]
+        x, y, wf = xs[i % nsets], ys[i % nsets], wfs[i % len(wfs)]
         if mode == 0:
             return L.conv2d(1, 0, x.data_ptr(), Ci, wf.data_ptr(), y.data_ptr(), Co, None, None, 0, stt.data_ptr(), B, H, H, Ci, Ho, Ho, Co, k, k, s, pad, 1, st)
         return L.conv2d(1, 1, y.data_ptr(), Co, wf.data_ptr(), x.data_ptr(), Ci, None, None, 0, None, B, Ho, Ho, Co, H, H, Ci, k, k, s, pad, 1, st)
