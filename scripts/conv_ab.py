@@ -21,11 +21,20 @@ for (B, H, Ci, Co, k, s, mode) in SHAPES:
     ys = [torch.randn(B * Ho * Ho * Co, device="cuda").to(torch.bfloat16) for _ in range(nsets)]
     wfs = [(torch.randn(Co * k * k * Ci, device="cuda") * 0.05).to(torch.bfloat16) for _ in range(nsets if os.environ.get("COLDW") else 1)]
     stt = torch.zeros(L.conv2d_stats_rows_geom(1, B, Ho, Ho, Ci, Co, k, k, s, pad, 1, Ci) * 2 * Co + 4096, device="cuda")
+    coef = [torch.rand(Ci, device="cuda") + 0.5 for _ in range(3)]
+    prow = L.conv2d_dgrad_bnsums_rows(1, B, Ho, Ho, Co, H, H, Ci, k, k, s, pad, 1, Co) if mode >= 2 else 0
+    part = torch.zeros(max(1, prow) * 2 * Ci + 4096, device="cuda")
     def call(i):
         x, y, wf = xs[i % nsets], ys[i % nsets], wfs[i % len(wfs)]
         if mode == 0:
             return L.conv2d(1, 0, x.data_ptr(), Ci, wf.data_ptr(), y.data_ptr(), Co, None, None, 0, stt.data_ptr(), B, H, H, Ci, Ho, Ho, Co, k, k, s, pad, 1, st)
-        return L.conv2d(1, 1, y.data_ptr(), Co, wf.data_ptr(), x.data_ptr(), Ci, None, None, 0, None, B, Ho, Ho, Co, H, H, Ci, k, k, s, pad, 1, st)
+        if mode == 1:
+            return L.conv2d(1, 1, y.data_ptr(), Co, wf.data_ptr(), x.data_ptr(), Ci, None, None, 0, None, B, Ho, Ho, Co, H, H, Ci, k, k, s, pad, 1, st)
+        # mode 2: data gradient with the fused BatchNorm-backward sums (+ addsrc, as in a residual block); mode 3: the same without addsrc
+        yy = xs[(i + 1) % nsets]
+        return L.conv2d_dgrad_bnsums(1, y.data_ptr(), Co, wf.data_ptr(), x.data_ptr(), Ci, xs[(i + 2) % nsets].data_ptr() if mode == 2 else None, Ci,
+                                     B, Ho, Ho, Co, H, H, Ci, k, k, s, pad, 1, yy.data_ptr(), Ci, coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
+                                     1, 0.1, part.data_ptr(), st)
     res = {v: [] for v in variants}
     for v in variants:
         L.conv2d_set_variant(v)
