@@ -606,7 +606,10 @@ class Plan:
     # A/B (scripts/ab_step.py "A0;A1"): the tail of the backward gets 0.2 ms shorter (measured with the forward-only terms skipped) and those
     # terms -- wgrad(y, x) 130 us alone / 260 us beside the forward, the tap sums 85 us -- cost 0.15 .. 0.3 ms wherever they are put (side stream
     # under the 52^2 layers, behind layer 1, at the end of the forward; inline on the main stream): 13.95 -> 13.99 .. 14.11 ms.
+    # With those terms at the tail of the backward instead (first_layer_place = 1: x read twice there, no forward cost): 13.57 -> 13.49 ms on
+    # one box, 13.60 -> 13.65 on the next -- level.
     first_layer_algebra = False        # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
+    first_layer_place = 0              # 0: the forward-only terms under the forward pass; 1: at the tail of the backward, beside the data gradient above
 
     fwd_mid_layer = None               # first packed layer whose input has shrunk to 1/8 of the image (set by the model's lowering): from there on
                                        # the forward is MFMA- / latency-bound and leaves HBM to a side stream
@@ -658,10 +661,25 @@ class Plan:
         forward_terms.__name__ = "first_layer_forward_terms"
         gradient_term.__name__ = "conv2d_wgrad"                                # (side stream, run_bwd_list)
         gradient_term.info = (x.B, x.H, x.W, 8, y.H, y.W, cs.cout_pad, cs.kh, cs.stride, splits)
-        k = self.fwd_mid_layer
-        pos = self.layer_marks[k] if k is not None and k < len(self.layer_marks) else len(self.fwd)
-        self.fwd.insert(pos, (forward_terms, ()))
-        self.layer_marks = [m + 1 if m >= pos else m for m in self.layer_marks]
+        if self.first_layer_place == 1:
+            # in the backward list in FRONT of the data gradient that writes g: the side stream takes them behind the weight gradient of the
+            # layer above, beside that data gradient -- no forward cost, x is read twice at the tail instead of dy0 written and read
+            def tail_terms(stream):
+                rc = L.conv_tap_sums(dt, x.ptr, x.ldc, x.B, x.H, x.W, y.H, y.W, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil, tws.data_ptr(),
+                                     X1.data_ptr(), stream)
+                return rc or corr(y, Y, stream)
+            tail_terms.__name__ = "conv2d_wgrad"
+            tail_terms.info = gradient_term.info
+            self.bwd.insert(self.dgrad_entries[dout.ptr]["idx"], (tail_terms, ()))
+            for e in self.dgrad_entries.values():
+                if e["idx"] >= self.dgrad_entries[dout.ptr]["idx"] and e["out"].ptr != dout.ptr:
+                    e["idx"] += 1
+            self.dgrad_entries[dout.ptr]["idx"] += 1
+        else:
+            k = self.fwd_mid_layer
+            pos = self.layer_marks[k] if k is not None and k < len(self.layer_marks) else len(self.fwd)
+            self.fwd.insert(pos, (forward_terms, ()))
+            self.layer_marks = [m + 1 if m >= pos else m for m in self.layer_marks]
         self.bwd.append((gradient_term, ()))
         self.first_layer_fused = True
         return True

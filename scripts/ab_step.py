@@ -39,7 +39,8 @@ def apply_build(codes):
         if c and c[0] == "T":          # T0 / T1: forward statistics finalized by a launch / folded inside the conv + consumer prologue
             engine.Plan.stats_fold = bool(int(c[1:]))
         if c and c[0] == "A":          # A0 / A1: the first layer's weight gradient with / without its BatchNorm-apply pass
-            engine.Plan.first_layer_algebra = bool(int(c[1:]))
+            engine.Plan.first_layer_algebra = bool(int(c[1:]) & 1)      # A3: with the forward-only terms at the tail of the backward
+            engine.Plan.first_layer_place = int(c[1:]) >> 1
         if c and c[0] == "P":
             engine.Plan.pw_fuse = bool(int(c[1:]))
         if c and c[0] == "F":
