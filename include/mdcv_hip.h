@@ -89,6 +89,26 @@ int mdcv_bn_act_fwd_statsfold(int dtype, const void* y, int ldy, const float* su
                               float* shift, float* mean, float* invstd, const void* resid, int ldr, void* out, int ldo, int M, int C,
                               int act, float slope, void* stream);
 int mdcv_bn_act_fwd_statsfold_blocks(int n);   /* tuning hook: workgroup target of mdcv_bn_act_fwd_statsfold (default 512) */
+/* Forward statistics through EXACT ACCUMULATORS (csrc/exact_acc.h): the conv's epilogue adds its per-tile sums (per output channel: sum, sum of
+ * squares) to xacc = [reps][3][2][Nout] signed 64-bit words (mdcv_xstats_words; ZERO before the launch) with fire-and-forget integer atomics --
+ * three 40-bit digits of a fixed-point number with quantum 2^-70, so every addition is exact and the totals do not depend on the order the
+ * atomics land in (bit-reproducible, unlike float atomics).  reps (a power of two; mdcv_xstats_reps(rows, C) for a layer that performs `rows`
+ * additions per channel, rows = mdcv_conv2d_stats_rows_geom / mdcv_pw_rows) spreads a word's additions over replicas.  Every forward kernel of
+ * mdcv_conv2d carries it (both dtypes), and mdcv_pw_conv_fwd_xstats is mdcv_pw_conv_fwd with the same sink.  Consumer: mdcv_bn_act_fwd_xstats --
+ * BatchNorm(batch statistics) + activation (+ residual) whose prologue adds the replicas and forms the statistics; it writes scale / shift /
+ * mean / invstd / running statistics as mdcv_bn_stats_finalize does (C <= 1024).  Replaces conv -> mdcv_bn_stats_finalize -> mdcv_bn_act_fwd of
+ * the reference's nn.Sequential(conv, BatchNorm2d, LeakyReLU) (CVC-YOLOv3/models.py:57-71) by two launches with no hand-off inside a launch. */
+int mdcv_xstats_words(int reps, int C);
+int mdcv_xstats_reps(int rows, int C);
+int mdcv_conv2d_xstats(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const float* bias, void* xacc,
+                       int reps, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride, int pad, int dil,
+                       void* stream);
+int mdcv_pw_conv_fwd_xstats(int dtype, const void* y, int ldy, const float* scale, const float* shift, const void* resid, int ldr, int act,
+                            float slope, void* z_out, int ldz, const void* w_packed, const float* bias, void* out, int out_ldc, void* xacc,
+                            int reps, long long M, int K, int N, void* stream);
+int mdcv_bn_act_fwd_xstats(int dtype, const void* y, int ldy, const void* xacc, int reps, double count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                           float* invstd, const void* resid, int ldr, void* out, int ldo, int M, int C, int act, float slope, void* stream);
 int mdcv_conv2d_stats_rows(int M);      /* generic kernels: one row per 128 output pixels */
 /* rows of stats_partial a FORWARD launch with this geometry writes (use this one to size the buffer: the 3x3 / stride-1 /
  * pad-1 shift kernel walks a padded pixel stream and writes more rows than M / 128; every row it returns is written). */

@@ -37,6 +37,7 @@ struct ConvArgs {
   int cls_split;                              // ALLCLS: 1 = two workgroups per tile, the 4-tap class and the 1+2+2-tap classes (sparse grids)
   BnFuseArgs fuse;                            // BatchNorm-backward sums folded into the store loop of a data gradient (fuse.y == NULL: off)
   EpiArgs epi;                                // inference epilogue act(acc * oscale + bias) (oscale == NULL and act == 0: off)
+  XAccArgs xacc;                              // forward statistics added to exact accumulators instead of written as rows (exact_acc.h; acc == NULL: off)
 };
 
 #if MDCV_CONV_PART == 0
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
     }
   }
   float* sstat = reinterpret_cast<float*>(smem + STAT_OFF);   // [WM][2][BN]
-  if (a.stats) {
+  const bool want_stats = a.stats || a.xacc.acc;
+  if (want_stats) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       float s = 0.f, q = 0.f;
@@ -284,15 +286,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(ConvArgs a) {
   __syncthreads();
   // statistics rows are per 128 pixels regardless of the tile height (one row per group of wave-rows)
   constexpr int G = BM / 128, WPG = WM / G;
-  if (a.stats && tid < BN * G) {
+  if (want_stats && tid < BN * G) {
     const int g = tid / BN, col = tid - g * BN;
     const int n = tile_n * BN + col, srow = tile_m * G + g;
     if (n < a.Nout && srow * 128 < a.M) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int r = 0; r < WPG; ++r) { s += sstat[((g * WPG + r) * 2 + 0) * BN + col]; q += sstat[((g * WPG + r) * 2 + 1) * BN + col]; }
-      a.stats[((size_t)srow * 2 + 0) * a.Nout + n] = s;
-      a.stats[((size_t)srow * 2 + 1) * a.Nout + n] = q;
+      if (a.xacc.acc) {                                     // fire-and-forget exact accumulation (exact_acc.h): no rows, no finalize launch
+        long long* xp = a.xacc.acc + (size_t)(srow & (a.xacc.reps - 1)) * (XACC_DIGITS * 2) * a.Nout + n;
+        xacc_add(xp, 2 * (size_t)a.Nout, s);
+        xacc_add(xp + a.Nout, 2 * (size_t)a.Nout, q);
+      } else {
+        a.stats[((size_t)srow * 2 + 0) * a.Nout + n] = s;
+        a.stats[((size_t)srow * 2 + 1) * a.Nout + n] = q;
+      }
     }
   }
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
@@ -684,7 +692,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a0, un
     }
   }
   float* sstat = reinterpret_cast<float*>(smem + STAT_OFF);
-  if (a.stats) {
+  const bool want_stats = a.stats || a.xacc.acc;
+  if (want_stats) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       float s = 0.f, q = 0.f;
@@ -715,15 +724,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_glds_kernel(ConvArgs a0, un
       }
   __syncthreads();
   constexpr int G = BM / 128 > 0 ? BM / 128 : 1, WPG = WM / G;
-  if (a.stats && tid < BN * G) {
+  if (want_stats && tid < BN * G) {
     const int g = tid / BN, col = tid - g * BN;
     const int n = tile_n * BN + col, srow = tile_m * G + g;
     if (n < a.Nout && srow * 128 < a.M) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int r = 0; r < WPG; ++r) { s += sstat[((g * WPG + r) * 2 + 0) * BN + col]; q += sstat[((g * WPG + r) * 2 + 1) * BN + col]; }
-      a.stats[((size_t)srow * 2 + 0) * a.Nout + n] = s;
-      a.stats[((size_t)srow * 2 + 1) * a.Nout + n] = q;
+      if (a.xacc.acc) {                                     // fire-and-forget exact accumulation (exact_acc.h): no rows, no finalize launch
+        long long* xp = a.xacc.acc + (size_t)(srow & (a.xacc.reps - 1)) * (XACC_DIGITS * 2) * a.Nout + n;
+        xacc_add(xp, 2 * (size_t)a.Nout, s);
+        xacc_add(xp + a.Nout, 2 * (size_t)a.Nout, q);
+      } else {
+        a.stats[((size_t)srow * 2 + 0) * a.Nout + n] = s;
+        a.stats[((size_t)srow * 2 + 1) * a.Nout + n] = q;
+      }
     }
   }
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
@@ -1819,8 +1834,9 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
                        const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
                        int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
                        int KH, int KW, int stride, int pad, int dil, const BnFuseArgs* fuse, void* stream, const EpiArgs* epi = nullptr,
-                       const StatsFoldArgs* fold = nullptr) {
+                       const StatsFoldArgs* fold = nullptr, const XAccArgs* xacc = nullptr) {
   if (!in || !w_packed || !out) return MDCV_EARG;
+  if (xacc && (mode != 0 || stats_partial || fuse || epi || fold || !xacc->acc || xacc->reps < 1 || (xacc->reps & (xacc->reps - 1)))) return MDCV_EARG;
   if (epi && (mode != 0 || stats_partial || fuse)) return MDCV_EARG;        // the inference epilogue is a forward-only, statistics-free path
   if ((Cin & 7) || (Nout & 7) || (in_ldc & 7) || (out_ldc & 7) || (addsrc && (add_ldc & 7))) return MDCV_EARG;
   if (stride != 1 && stride != 2) return MDCV_EARG;
@@ -1834,6 +1850,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   a.ph = a.pw = a.kh0 = a.kw0 = 0; a.Hs = Hout; a.Ws = Wout; a.nkh = KH; a.nkw = KW; a.cls_split = 0;
   a.fuse = fuse ? *fuse : BnFuseArgs{};
   a.epi = epi ? *epi : EpiArgs{nullptr, 0, 0.f};
+  a.xacc = xacc ? *xacc : XAccArgs{nullptr, 1};
   if (a.M <= 0) return MDCV_OK;
   hipStream_t st = (hipStream_t)stream;
   // stride-2 data gradient: 4 launches, one per output-parity class, each visiting only its live taps (no masked MACs)
@@ -1877,7 +1894,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   // 3x3 / stride 1 / pad 1 on wide layers: nine shifted GEMMs over one LDS-resident activation chunk (conv_shift.hip)
   const bool shift_ok = Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc);
   if (shift_ok && (g_conv_variant < 0 || fuse))
-    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st, epi, dil, fold);
+    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st, epi, dil, fold, xacc);
   if (fold) return MDCV_EARG;                     // (only the kernels above fold their statistics rows: mdcv_conv2d_statsfold_ok)
   if (fuse) {                                     // the fused store loop lives in the LDS-DMA kernels: never fall back to the staged ones
     if (!small) return MDCV_EARG;
@@ -1924,6 +1941,18 @@ int mdcv_conv2d_statsfold(int dtype, const void* in, int in_ldc, const void* w_p
   const StatsFoldArgs f{super, reinterpret_cast<unsigned*>(counters), G, rows};
   return conv2d_impl(dtype, 0, in, in_ldc, w_packed, out, out_ldc, bias, nullptr, 0, stats_partial, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW,
                      stride, pad, dil, nullptr, stream, nullptr, &f);
+}
+
+// Forward conv whose BatchNorm statistics (per output channel: sum, sum of squares) are ADDED to exact accumulators (exact_acc.h:
+// [reps][3][2][Nout] 64-bit words, zero before the launch; mdcv_xstats_words) instead of written as partial rows.  Every forward kernel takes
+// it (both dtypes); the consumer (mdcv_bn_act_fwd_xstats) finishes the statistics in its prologue and no finalize launch runs in between.
+int mdcv_xstats_words(int reps, int C) { return reps * XACC_DIGITS * 2 * C; }
+int mdcv_conv2d_xstats(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const float* bias, void* xacc,
+                       int reps, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride, int pad, int dil,
+                       void* stream) {
+  const XAccArgs x{reinterpret_cast<long long*>(xacc), reps};
+  return conv2d_impl(dtype, 0, in, in_ldc, w_packed, out, out_ldc, bias, nullptr, 0, nullptr, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW,
+                     stride, pad, dil, nullptr, stream, nullptr, nullptr, &x);
 }
 
 // Data gradient (mode 1 of mdcv_conv2d, same geometry arguments) that ALSO writes the BatchNorm-backward partial sums of the

@@ -491,7 +491,8 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   }
   __syncthreads();
   float* sstat = reinterpret_cast<float*>(smem + STAT_OFF);
-  if (a.stats) {
+  const bool want_stats = a.stats || a.xacc.acc;
+  if (want_stats) {
     bool live[FM][4];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
   constexpr int GR = (BM == 128 || BM == 256) ? 128 : BM;   // stream positions per partial-statistics row (192- / 384-row tiles: one row per tile)
   constexpr bool kFold = MODE == 0 && !FUSE && !EPI;         // forward launches with statistics: the rows may be folded per group inside the launch (stats_fold.h)
   constexpr int G = BM / GR, WPG = WM / G;                 // rows per tile; waves (in M) per row
-  if (a.stats && tid < BN * G) {
+  if (want_stats && tid < BN * G) {
     const int g = tid / BN, col = tid - g * BN;
     const int n = tile_n * BN + col;
     if (n < a.Nout) {
@@ -539,7 +540,11 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
       for (int w2 = 0; w2 < WPG; ++w2) { s += sstat[((g * WPG + w2) * 2 + 0) * BN + col]; qq += sstat[((g * WPG + w2) * 2 + 1) * BN + col]; }
       const size_t srow = (size_t)(p0 / GR) + g;
       if (srow * GR < (size_t)a.Mq) {                       // the last tile may reach past the stream: the caller holds ceil(Mq/GR) rows
-        if (kFold && a.fold.super) {                        // write-through: another workgroup may sum these rows inside this launch (stats_fold.h)
+        if (a.xacc.acc) {                                   // fire-and-forget exact accumulation (exact_acc.h): no rows, no finalize launch
+          long long* xp = a.xacc.acc + (size_t)(srow & (size_t)(a.xacc.reps - 1)) * (XACC_DIGITS * 2) * a.Nout + n;
+          xacc_add(xp, 2 * (size_t)a.Nout, s);
+          xacc_add(xp + a.Nout, 2 * (size_t)a.Nout, qq);
+        } else if (kFold && a.fold.super) {                        // write-through: another workgroup may sum these rows inside this launch (stats_fold.h)
           sf_store(a.stats + (srow * 2 + 0) * a.Nout + n, s);
           sf_store(a.stats + (srow * 2 + 1) * a.Nout + n, qq);
         } else {
@@ -844,8 +849,10 @@ int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil) {
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
                     int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st,
-                    const EpiArgs* epi, int dil, const StatsFoldArgs* fold) {
+                    const EpiArgs* epi, int dil, const StatsFoldArgs* fold, const XAccArgs* xacc) {
   ShiftArgs a;
+  a.xacc = XAccArgs{nullptr, 1};
+  if (xacc) { if (mode != 0 || stats || epi || fold || !xacc->acc || xacc->reps < 1 || (xacc->reps & (xacc->reps - 1))) return MDCV_EARG; a.xacc = *xacc; }
   if (fold && mode == 0 && stats && !epi) a.fold = *fold; else a.fold = StatsFoldArgs{nullptr, nullptr, 0, 0};
   if (fold && !a.fold.super) return MDCV_EARG;
   if (fuse) a.fuse = *fuse; else a.fuse = BnFuseArgs{};

@@ -8,6 +8,7 @@
 // vector (8 bf16 / 4 fp32) and walks down the strip, so every access is a coalesced 16-byte load/store and per-channel
 // reductions stay in registers until one LDS fold + one fp64 atomic per channel per block.
 #include "common.h"
+#include "exact_acc.h"
 
 namespace {
 
@@ -330,6 +331,160 @@ __global__ __launch_bounds__(256) void bn_act_fwd_fold_kernel(BnActArgs a, BnFol
     pb += 4 * a.PPI;
     if (pb < p1) request();
     pb -= 4 * a.PPI;
+  }
+}
+
+// The same pass with the statistics read from exact accumulators (exact_acc.h): the conv ADDED its per-tile sums to [reps][3][2][C] 64-bit
+// words with fire-and-forget integer atomics; every workgroup here adds the replicas (integers: exact, any order), converts and forms
+// scale / shift for all C channels in LDS, with its first strip of y already requested; workgroup 0 also publishes scale / shift / mean /
+// invstd for the backward and updates the running statistics.  No rows, no finalize launch, no hand-off inside a launch.
+// Thread layout of the prologue: C <= 256: the 256 threads are G = 256 / Cp groups (Cp = C rounded up to a power of two), group g adds
+// replicas [g rp, (g + 1) rp) of channel tid % Cp and the groups meet in LDS; C > 256: thread t owns channels t + 256 k, k < NCH, all replicas.
+// NCH * rp <= 4: at most 24 words per thread are in flight together (one memory round trip) and the kernel keeps the register budget -- i.e.
+// the occupancy -- of the plain apply pass (with 48 words: 138 registers, three waves per SIMD instead of four, +7 us on the 104^2 tensors).
+struct BnXAccArgs {
+  const long long* acc; int reps; double count, inv_count;
+  const float* gamma; const float* beta; float* rm; float* rv; float momentum, eps;
+  float* scale; float* shift; float* mean; float* invstd;
+  int Cp, rp;                               // C <= 256: Cp = pow2 >= C, rp = max(1, reps / (256 / Cp)); C > 256: Cp = 256, rp = reps
+};
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void bn_act_fwd_xacc_kernel(BnActArgs a, BnXAccArgs f) {
+  // (waves_per_eu(4, 4): with a bare minimum of four the scheduler went for five waves and paid for the registers by waiting for every
+  //  strip load before issuing the next one and for every store before the next -- 28 us where the plain pass takes 23)
+  constexpr int VEC = ET<T>::VEC;
+  constexpr int RPMAX = 4 / NCH;
+  __shared__ float cs[1024], cb[1024];
+  __shared__ long long sd[NCH == 1 ? 6 * 256 : 1];
+  const int tid = threadIdx.x;
+  const int cl = tid & (f.Cp - 1), g = tid / f.Cp;                     // (NCH > 1: Cp = 256, g = 0)
+  const size_t ds = 2 * (size_t)a.C, rs = (size_t)XACC_DIGITS * 2 * a.C;
+  long long w[NCH][RPMAX][6];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = cl + 256 * k;
+#pragma unroll
+    for (int j = 0; j < RPMAX; ++j) {
+      const int rep = g * f.rp + j;
+      const bool ok = c < a.C && j < f.rp && rep < f.reps;
+      const long long* p = f.acc + (size_t)(ok ? rep : 0) * rs + (ok ? c : 0);
+#pragma unroll
+      for (int d = 0; d < XACC_DIGITS; ++d) {
+        w[k][j][2 * d + 0] = ok ? p[d * ds] : 0;
+        w[k][j][2 * d + 1] = ok ? p[d * ds + a.C] : 0;
+      }
+    }
+  }
+  // gamma / beta (and, in the publishing workgroup, the running statistics) are requested NOW, beside the accumulator words: behind the
+  // statistics arithmetic each would be one more dependent memory round trip in front of every workgroup's first store.
+  const bool publisher = blockIdx.x == gridDim.x - 1;                  // one extra workgroup with an empty strip: nobody's strip waits for the publishing stores
+  float gmv[NCH], btv[NCH], rmv[NCH], rvv[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = cl + 256 * k;
+    const bool ok = g == 0 && c < a.C;
+    gmv[k] = ok ? f.gamma[c] : 0.f; btv[k] = ok ? f.beta[c] : 0.f;
+    rmv[k] = ok && publisher && f.rm ? f.rm[c] : 0.f; rvv[k] = ok && publisher && f.rm ? f.rv[c] : 0.f;
+  }
+  const bool active = tid < a.PPI * a.CV;
+  const int cv = active ? tid % a.CV : 0, pi = active ? tid / a.CV : 0;
+  const long long p0 = (long long)blockIdx.x * a.PB;
+  const long long p1 = active ? min((long long)a.M, p0 + a.PB) : 0;    // (inactive threads and the publisher: an empty strip)
+  const T* y1 = reinterpret_cast<const T*>(a.y1);
+  const T* rsd = reinterpret_cast<const T*>(a.resid);
+  T* out = reinterpret_cast<T*>(a.out);
+  // the first strip is requested above the prologue
+  uint4 q1[4], qr[4];
+  long long pb = p0 + pi;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long p = pb + (long long)u * a.PPI;
+    if (p < p1) {
+      q1[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
+      if (rsd) qr[u] = *reinterpret_cast<const uint4*>(rsd + p * a.ldr + cv * VEC);
+    }
+  }
+  long long t[NCH][6];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      long long x = 0;
+#pragma unroll
+      for (int j = 0; j < RPMAX; ++j) x += w[k][j][e];
+      t[k][e] = x;
+    }
+  if constexpr (NCH == 1) {
+    if (f.Cp < 256) {                                                  // (uniform) the replica groups meet
+#pragma unroll
+      for (int e = 0; e < 6; ++e) sd[e * 256 + tid] = t[0][e];
+      __syncthreads();
+      if (g == 0) {
+        const int ng = 256 / f.Cp;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          long long x = 0;
+          for (int gg = 0; gg < ng; ++gg) x += sd[e * 256 + gg * f.Cp + cl];
+          t[0][e] = x;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = cl + 256 * k;
+    if (g == 0 && c < a.C) {
+      const double s0 = xacc_value(t[k][0], t[k][2], t[k][4]), s1 = xacc_value(t[k][1], t[k][3], t[k][5]);
+      const double mean = s0 * f.inv_count;                               // (no fp64 division / square root in every workgroup's prologue)
+      double var = s1 * f.inv_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = 1.0f / sqrtf((float)var + f.eps);
+      const float gm = gmv[k], b = btv[k];
+      const float sc = gm * invstd, sh = b - (float)mean * gm * invstd;
+      cs[c] = sc; cb[c] = sh;
+      if (publisher) {
+        f.scale[c] = sc; f.shift[c] = sh; f.mean[c] = (float)mean; f.invstd[c] = invstd;
+        if (f.rm) {
+          const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+          f.rm[c] = (1.f - f.momentum) * rmv[k] + f.momentum * (float)mean;
+          f.rv[c] = (1.f - f.momentum) * rvv[k] + f.momentum * (float)unbiased;
+        }
+      }
+    }
+  }
+  if (publisher) return;                                               // (uniform: its strip is empty)
+  __syncthreads();
+  if (!active) return;
+  float s1[VEC], b1[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { s1[e] = cs[cv * VEC + e]; b1[e] = cb[cv * VEC + e]; }
+  // (only the FIRST strip is requested ahead; from the second on this is the loop of bn_act_fwd_kernel: load four, compute, store four)
+  for (bool first = true; pb < p1; pb += 4 * a.PPI, first = false) {
+    if (!first) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long p = pb + (long long)u * a.PPI;
+        if (p < p1) {
+          q1[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
+          if (rsd) qr[u] = *reinterpret_cast<const uint4*>(rsd + p * a.ldr + cv * VEC);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long p = pb + (long long)u * a.PPI;
+      if (p >= p1) break;
+      float v[VEC], x[VEC];
+      ET<T>::unpack(q1[u], v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = act_fwd(v[e] * s1[e] + b1[e], a.act, a.slope);
+      if (rsd) {
+        ET<T>::unpack(qr[u], x);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += x[e];
+      }
+      *reinterpret_cast<uint4*>(out + p * a.ldo + cv * VEC) = ET<T>::pack(v);
+    }
   }
 }
 
@@ -959,6 +1114,50 @@ int mdcv_bn_stats_finalize(const float* partial, int rows, double* accum, double
   a.partial = partial; a.rows = rows; a.nsums = 2; a.C = C; a.count = count; a.gamma = gamma; a.beta = beta; a.rm = running_mean;
   a.rv = running_var; a.momentum = momentum; a.eps = eps; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
   MDCV_LAUNCH(bn_colfinal_kernel<0>, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, a);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+// BatchNorm(batch statistics) + activation (+ residual) with the statistics taken from the exact accumulators mdcv_conv2d_xstats /
+// mdcv_pw_conv_fwd_xstats added to (`count` positions; [reps][3][2][C] words).  Writes scale / shift / mean / invstd and updates the running
+// statistics as mdcv_bn_stats_finalize does.  C <= 1024.  mdcv_xstats_reps: the replica count to use for a layer with `rows` additions per word.
+extern int g_fold_blocks;
+int mdcv_xstats_reps(int rows, int C) {
+  int cp = 32; while (cp < C && cp < 256) cp <<= 1;
+  const int cap = C <= 256 ? 1024 / cp : (C <= 512 ? 2 : 1);
+  int r = 1; while (r < cap && r * 128 < rows) r <<= 1;
+  return r;
+}
+int mdcv_bn_act_fwd_xstats(int dtype, const void* y, int ldy, const void* xacc, int reps, double count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                           float* invstd, const void* resid, int ldr, void* out, int ldo, int M, int C, int act, float slope, void* stream) {
+  if (!y || !out || !xacc || !gamma || !beta || !scale || !shift || !mean || !invstd || reps < 1 || (reps & (reps - 1)) || (C & 7) || C > 1024 ||
+      (ldy & 7) || (ldo & 7) || (dtype != MDCV_BF16 && dtype != MDCV_F32))
+    return MDCV_EARG;
+  BnActArgs a;
+  a.y1 = y; a.y2 = nullptr; a.resid = resid; a.out = out; a.s1 = nullptr; a.b1 = nullptr; a.s2 = nullptr; a.b2 = nullptr;
+  a.ld1 = ldy; a.ld2 = 0; a.ldr = ldr; a.ldo = ldo; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
+  BnXAccArgs f{reinterpret_cast<const long long*>(xacc), reps, count, 1.0 / count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, 256, reps};
+  const int nch = C <= 256 ? 1 : (C <= 512 ? 2 : 4);
+  if (nch == 1) {
+    int cp = 32; while (cp < C) cp <<= 1;
+    f.Cp = cp; f.rp = reps / (256 / cp) > 0 ? reps / (256 / cp) : 1;
+  }
+  if (nch * f.rp > 4) return MDCV_EARG;                    // (the prologue keeps a thread's words in registers: mdcv_xstats_reps stays inside)
+  const Strip s = dtype == MDCV_BF16 ? make_strip<bf16_t>(M, C, g_fold_blocks, 4) : make_strip<float>(M, C, g_fold_blocks, 4);
+  if (s.CV > 256) return MDCV_EARG;
+  a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
+  const dim3 grid((unsigned)cdiv(M, s.PB) + 1);             // + the publishing workgroup
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MDCV_BF16) {
+    if (nch == 1) MDCV_LAUNCH((bn_act_fwd_xacc_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a, f);
+    else if (nch == 2) MDCV_LAUNCH((bn_act_fwd_xacc_kernel<bf16_t, 2>), grid, dim3(256), 0, st, a, f);
+    else MDCV_LAUNCH((bn_act_fwd_xacc_kernel<bf16_t, 4>), grid, dim3(256), 0, st, a, f);
+  } else {
+    if (nch == 1) MDCV_LAUNCH((bn_act_fwd_xacc_kernel<float, 1>), grid, dim3(256), 0, st, a, f);
+    else if (nch == 2) MDCV_LAUNCH((bn_act_fwd_xacc_kernel<float, 2>), grid, dim3(256), 0, st, a, f);
+    else MDCV_LAUNCH((bn_act_fwd_xacc_kernel<float, 4>), grid, dim3(256), 0, st, a, f);
+  }
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bn_fuse.h"
+#include "exact_acc.h"
 
 struct PwArgs {
   const void* in0; const void* in1; void* tout;      // forward: y, resid (or NULL), z out ; backward: dz, y, dy out
@@ -12,6 +13,7 @@ struct PwArgs {
   unsigned w_bytes;
   float slope;
   BnFuseArgs fuse;
+  XAccArgs xacc;       // forward statistics added to exact accumulators instead of written as rows (exact_acc.h; acc == NULL: off)
 };
 
 int mdcv_pw_tile_rows(int K);

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
         }
       }
       if constexpr (MODE == 0) {
-        if (a.stats) {
+        if (a.stats || a.xacc.acc) {
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
             float s = 0.f, qq = 0.f;
@@ -279,8 +279,14 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
             s += __shfl_xor(s, 32, 64); qq += __shfl_xor(qq, 32, 64);
             const int nn = nw0 + j * 16 + lane;
             if (lane < 16 && nn < a.N) {
-              a.stats[((size_t)tile * 2 + 0) * a.N + nn] = s;
-              a.stats[((size_t)tile * 2 + 1) * a.N + nn] = qq;
+              if (a.xacc.acc) {                             // fire-and-forget exact accumulation (exact_acc.h): no rows, no finalize launch
+                long long* xp = a.xacc.acc + (size_t)(tile & (a.xacc.reps - 1)) * (XACC_DIGITS * 2) * a.N + nn;
+                xacc_add(xp, 2 * (size_t)a.N, s);
+                xacc_add(xp + a.N, 2 * (size_t)a.N, qq);
+              } else {
+                a.stats[((size_t)tile * 2 + 0) * a.N + nn] = s;
+                a.stats[((size_t)tile * 2 + 1) * a.N + nn] = qq;
+              }
             }
           }
         }
@@ -464,6 +470,24 @@ int mdcv_pw_conv_fwd(int dtype, const void* y, int ldy, const float* scale, cons
   a.in0 = y; a.ld0 = ldy; a.in1 = resid; a.ld1 = ldr; a.tout = z_out; a.ldt = ldz;
   a.scale = scale; a.shift = shift; a.act = act; a.slope = act == 2 ? 0.f : slope;   // (ReLU = slope 0, as mdcv_bn_act_fwd)
   a.w = w_packed; a.w_bytes = (unsigned)((long long)N * K * 2); a.bias = bias; a.out = out; a.out_ldc = out_ldc; a.stats = stats_partial;
+  a.M = (int)M; a.K = K; a.N = N; a.ysplit = 1;
+  a.fuse = BnFuseArgs{};
+  return dispatch_pw<0, false>(a, (hipStream_t)stream);
+}
+
+/* the same with the output's statistics added to exact accumulators (exact_acc.h; [reps][3][2][N] 64-bit words, zero before the launch) instead
+ * of written as partial rows: the consumer (mdcv_bn_act_fwd_xstats) finishes them in its prologue, no finalize launch. */
+int mdcv_pw_conv_fwd_xstats(int dtype, const void* y, int ldy, const float* scale, const float* shift, const void* resid, int ldr, int act,
+                            float slope, void* z_out, int ldz, const void* w_packed, const float* bias, void* out, int out_ldc, void* xacc,
+                            int reps, long long M, int K, int N, void* stream) {
+  if (!y || !w_packed || !out || !xacc || reps < 1 || (reps & (reps - 1)) ||
+      !mdcv_pw_eligible(dtype, M, K, N, ldy, resid ? ldr : 8, z_out ? ldz : 8, out_ldc))
+    return MDCV_EARG;
+  PwArgs a{};
+  a.in0 = y; a.ld0 = ldy; a.in1 = resid; a.ld1 = ldr; a.tout = z_out; a.ldt = ldz;
+  a.scale = scale; a.shift = shift; a.act = act; a.slope = act == 2 ? 0.f : slope;
+  a.w = w_packed; a.w_bytes = (unsigned)((long long)N * K * 2); a.bias = bias; a.out = out; a.out_ldc = out_ldc; a.stats = nullptr;
+  a.xacc = XAccArgs{reinterpret_cast<long long*>(xacc), reps};
   a.M = (int)M; a.K = K; a.N = N; a.ysplit = 1;
   a.fuse = BnFuseArgs{};
   return dispatch_pw<0, false>(a, (hipStream_t)stream);

@@ -211,6 +211,7 @@ class Plan:
         self.dgrad_entries = {}            # grad buffer ptr -> backward-list entry of the data gradient that wrote it last
         self.fused_bn = 0                  # BatchNorm backward reductions folded into data-gradient store loops
         self._fold_candidates, self._fold_arena, self.stats_folded = [], None, 0
+        self._xacc_arena, self.stats_xfolded = None, 0
 
     # ------------------------------------------------------------------ buffers
     def new_act(self, B, H, W, C, zero=False):
@@ -491,6 +492,65 @@ class Plan:
             self.layer_marks = [m - 1 if m > i + 1 else m for m in self.layer_marks]
             done += 1
         self.stats_folded = done
+        return done
+
+    # ---- forward BatchNorm statistics through exact accumulators (csrc/exact_acc.h): the conv's epilogue ADDS its per-tile sums to 64-bit
+    # fixed-point words with fire-and-forget integer atomics (exact, order-independent: bit-reproducible), the BatchNorm-apply pass reads the
+    # totals in its prologue.  No partial rows, no finalize launch, and -- unlike stats_fold above -- no hand-off inside a launch.
+    stats_xacc = False                 # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
+    stats_xacc_words = 1 << 20         # 64-bit words of the accumulator arena (zeroed by one memset at the head of the forward list)
+    stats_xacc_chain = 1024            # most additions one word may see per launch (416^2 x 32, 43 264 rows on 32 replicas: +8 us on a 160 us launch -> keeps its rows)
+
+    def fold_forward_xstats(self):
+        """Rewrite conv (or 1x1 block) / finalize / apply triples into mdcv_conv2d_xstats (mdcv_pw_conv_fwd_xstats) + mdcv_bn_act_fwd_xstats."""
+        L, dt = self.L, self.dtype
+        if not self.stats_xacc or self._xacc_arena is None:
+            return 0
+        cands, self._fold_candidates = self._fold_candidates, []
+        arena = self._xacc_arena
+        used, done = 0, 0
+        for conv, fin, act, cs, x, y, bs, partial, rows, out, act_code, slope, resid in cands:
+            idx = [i for i, e in enumerate(self.fwd) if e is conv]
+            if len(idx) != 1:
+                continue
+            i = idx[0]
+            if i + 2 > len(self.fwd) - 1 or self.fwd[i + 1] is not fin or self.fwd[i + 2] is not act:
+                continue
+            if y.C > 1024:
+                continue
+            reps = int(L.xstats_reps(rows, y.C))
+            if rows > self.stats_xacc_chain * reps:           # same-address atomics retire at ~10-17 ns each: the launch would end on their queue
+                continue
+            need = int(L.xstats_words(reps, y.C))
+            if used + need > arena.numel():
+                continue
+            acc = arena[used:used + need]
+            used += need
+            bn = bs.bn
+            a = conv[1]
+            if conv[0] is L.pw_conv_fwd:                     # (dtype, y, ldy, scale, shift, resid, ldr, act, slope, z, ldz, w, bias, out, out_ldc, stats, M, K, N)
+                self.fwd[i] = (L.pw_conv_fwd_xstats, a[:15] + (acc.data_ptr(), reps) + a[16:])
+            elif conv[0] is L.conv2d:                        # (dtype, mode, in, in_ldc, w, out, out_ldc, bias, addsrc, add_ldc, stats, geometry...)
+                self.fwd[i] = (L.conv2d_xstats, (a[0],) + a[2:8] + (acc.data_ptr(), reps) + a[11:])
+            else:
+                used -= need
+                continue
+            self.fwd[i + 2] = (L.bn_act_fwd_xstats, (dt, y.ptr, y.ldc, acc.data_ptr(), reps, float(y.M), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                                                     bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), bs.invstd.data_ptr(),
+                                                     resid.ptr if resid is not None else None, resid.ldc if resid is not None else 0,
+                                                     out.ptr, out.ldc, out.M, out.C, act_code, slope))
+            del self.fwd[i + 1]
+            self.layer_marks = [m - 1 if m > i + 1 else m for m in self.layer_marks]
+            done += 1
+        # the head-of-list memset covers only what the layers took
+        for k, e in enumerate(self.fwd):
+            if len(e[1]) == 1 and e[1][0] is arena:
+                view = arena[:max(used, 1)]
+                self.keep.append(view)
+                self.fwd[k] = (e[0], (view,))
+                break
+        self.stats_xfolded = done
         return done
 
     # ---- 1x1 conv blocks with the neighbouring BatchNorm pass folded into the operand load (csrc/pw_block.hip).  Policy from same-box

@@ -663,6 +663,10 @@ class Darknet(FlatParamsMixin, nn.Module):
             plan._fold_arena = torch.zeros(plan.stats_fold_counters, dtype=torch.int32, device=device)
             plan.keep.append(plan._fold_arena)
             plan.call(plan.fwd, _zero_tensor, plan._fold_arena)
+        if bn_train and plan.stats_xacc:                          # exact accumulators of the forward statistics (engine.fold_forward_xstats): one memset per forward
+            plan._xacc_arena = torch.zeros(plan.stats_xacc_words, dtype=torch.int64, device=device)
+            plan.keep.append(plan._xacc_arena)
+            plan.call(plan.fwd, _zero_tensor, plan._xacc_arena)
         outs = [None] * n
         recs = []
         cur = xin
@@ -707,7 +711,9 @@ class Darknet(FlatParamsMixin, nn.Module):
                         rows = int(L.pw_rows(cur.act.M, cs.cin_pad))
                         partial = plan.f32(rows * 2 * y.C, zero=False)
                         plan.emit_pw_fwd(pw_lb, cs, cur.act, y, partial)
+                        fold_c = [plan.fwd[-1]]
                         plan.emit_bn_stats(bs, y, partial, rows)
+                        fold_c += [plan.fwd[-1], cs, cur.act, y, bs, partial, rows]
                         nbt.append(bn.num_batches_tracked)
                     elif bn_train:
                         rows = plan.stats_rows(cs, cur.act, y)
@@ -833,6 +839,8 @@ class Darknet(FlatParamsMixin, nn.Module):
                 outs[i] = cur
         if bn_train and nbt:
             plan.call(plan.fwd, _bump_counters, nbt)
+        if plan.stats_xacc:
+            plan.fold_forward_xstats()     # conv -> finalize -> apply triples that survived the peepholes become two launches (csrc/exact_acc.h)
         plan.fold_forward_stats()          # conv -> finalize -> apply triples that survived the peepholes become two launches (csrc/stats_fold.h)
         plan.finish_pack(0)
 

@@ -640,6 +640,19 @@ def test_pw_block_forward(case):
     assert float((z1[:, :K].float().cpu() - zf).abs().max()) <= 2 ** -7 * float(zf.abs().max())
     of = z1[:, :K].float().cpu() @ w.reshape(N, K).to(torch.bfloat16).float().t() + (bias[:N].cpu() if bias is not None else 0)
     assert float((o1[:, :N].float().cpu() - of).abs().max()) <= 1e-2 * float(of.abs().max())
+    # the same launch with its statistics added to exact accumulators (mdcv_pw_conv_fwd_xstats): out / z bit-identical, the digits hold the exact
+    # sum of the rows the launch above wrote (float64 of <= 2^17 fp32 rows is exact enough to compare at 1e-12 relative)
+    if N % 8 == 0:
+        reps = L.xstats_reps(rows1, N)
+        acc = torch.zeros(L.xstats_words(reps, N), dtype=torch.int64, device="cuda")
+        z2 = torch.zeros_like(z0); o2 = torch.zeros_like(o0)
+        L.check(L.pw_conv_fwd_xstats(BF16, y.data_ptr(), ldy, scale.data_ptr(), shift.data_ptr(), P(r), ldy, act, 0.1, z2.data_ptr(), ldz, wf.data_ptr(),
+                                     P(bias), o2.data_ptr(), ldo, acc.data_ptr(), reps, M, K, N, st()), "pw_conv_fwd_xstats")
+        torch.cuda.synchronize()
+        assert torch.equal(z2, z1) and torch.equal(o2, o1)
+        d = acc.reshape(reps, 3, 2, N).sum(0).double()
+        tot = d[0] * 2.0 ** -70 + d[1] * 2.0 ** -30 + d[2] * 2.0 ** 10
+        np.testing.assert_allclose(tot.cpu().numpy(), s1.double().sum(0).cpu().numpy(), rtol=1e-12, atol=1e-12)
 
 
 @pytest.mark.parametrize("fused", [False, True], ids=["plain", "bnsums"])
@@ -1149,6 +1162,121 @@ def test_conv_statsfold_without_finalize_launch(case, G):
         assert torch.equal(r[6], sup) and torch.equal(r[5], zb) and all(torch.equal(p, q) for p, q in zip(r[2], cb))
     assert L.conv2d_statsfold(dt, xb.data_ptr(), Ci, wf.data_ptr(), yb.data_ptr(), Co, None, sb.data_ptr(), sup.data_ptr(), runs[0][6].data_ptr(), 3, rows,
                               *geom, st()) != 0       # odd G
+
+
+@pytest.mark.parametrize("dt", [BF16, F32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("case", [(32, 128, 52, 52, 256, 3, 1), (32, 256, 26, 26, 512, 3, 1), (8, 512, 13, 13, 1024, 3, 1), (3, 64, 37, 41, 128, 3, 1),
+                                  (2, 32, 20, 24, 64, 3, 1), (4, 32, 104, 104, 64, 3, 1), (4, 8, 96, 96, 32, 3, 1), (4, 32, 64, 64, 64, 3, 2),
+                                  (8, 256, 26, 26, 128, 1, 1), (2, 64, 80, 80, 24, 1, 1), (2, 8, 33, 31, 40, 7, 2)], ids=str)
+def test_conv_xstats_exact_accumulators(case, dt):
+    """conv -> BatchNorm(batch statistics) -> LeakyReLU (+ residual) as TWO launches with no partial rows: mdcv_conv2d_xstats adds its per-tile sums to
+    exact accumulators (three 40-bit digits in 64-bit words, integer atomics: csrc/exact_acc.h), mdcv_bn_act_fwd_xstats forms the statistics in its
+    prologue -- against conv -> mdcv_bn_stats_finalize -> mdcv_bn_act_fwd on the same buffers, for every forward kernel family (3x3 shift kernel
+    in its 1-D / 2-D / narrow tilings, stride 2, 1x1, 7x7 stem; both dtypes).  Conv output bit-identical; the accumulators hold EXACTLY the sum of
+    the partial rows the three-launch form wrote (checked in float64 / integer arithmetic: the rows are fp32 values, their exact sum is
+    representable in the digits); scale / shift / mean / invstd / running statistics within fp32 rounding of the finalize's summation order;
+    activations equal up to one rounding of the storage type on a handful of elements.  Run three times with re-zeroed accumulators and with
+    1, 2 and the planned number of replicas: bit-identical every time (integer addition does not care about the order the atomics land in).
+    case = (B, Cin, H, W, Cout, k, stride)."""
+    L = _lib.lib()
+    B, Ci, H, W, Co, k, stride = case
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    gg = torch.Generator().manual_seed(B + Ci + W + k)
+    x = torch.randn(B, Ci, H, W, generator=gg)
+    w = torch.randn(Co, Ci, k, k, generator=gg) / (Ci * k * k) ** 0.5
+    Cip, Cop = (Ci + 7) // 8 * 8, (Co + 7) // 8 * 8
+    xb = to_nhwc(x, dt, Cip)
+    wf, _ = pack(dt, w, need_d=False)
+    res = to_nhwc(torch.randn(B, Co, Ho, Wo, generator=gg), dt, Cop)
+    M = B * Ho * Wo
+    gamma = (torch.rand(Cop, generator=gg) + 0.5).cuda(); beta = (torch.randn(Cop, generator=gg) * 0.3).cuda()
+    geom = (B, H, W, Cip, Ho, Wo, Cop, k, k, stride, pad, 1)
+    rows = L.conv2d_stats_rows_geom(dt, B, Ho, Wo, Cip, Cop, k, k, stride, pad, 1, Cip)
+    planned = L.xstats_reps(rows, Cop)
+    assert planned >= 1 and planned & (planned - 1) == 0
+
+    def three_launches():
+        y = torch.full((B, Ho, Wo, Cop), float("nan"), dtype=TD[dt], device="cuda")
+        stats = torch.zeros((rows, 2, Cop), device="cuda")
+        L.check(L.conv2d(dt, 0, xb.data_ptr(), Cip, wf.data_ptr(), y.data_ptr(), Cop, None, None, 0, stats.data_ptr(), *geom, st()), "conv")
+        co = [torch.zeros(Cop, device="cuda") for _ in range(4)]
+        rm, rv = torch.zeros(Cop, device="cuda"), torch.ones(Cop, device="cuda")
+        scratch = torch.zeros(3 * Cop, dtype=torch.float64, device="cuda")
+        stats_keep = stats.clone()
+        L.check(L.bn_stats_finalize(stats.data_ptr(), rows, scratch.data_ptr(), float(M), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                    0.1, 1e-5, *[c.data_ptr() for c in co], Cop, st()))
+        z = torch.full((B, Ho, Wo, Cop), float("nan"), dtype=TD[dt], device="cuda")
+        L.check(L.bn_act_fwd(dt, y.data_ptr(), Cop, co[0].data_ptr(), co[1].data_ptr(), None, 0, None, None, res.data_ptr(), Cop, z.data_ptr(), Cop, M, Cop,
+                             1, 0.1, st()))
+        torch.cuda.synchronize()
+        return y, stats_keep, co, rm, rv, z
+
+    def two_launches(reps):
+        y = torch.full((B, Ho, Wo, Cop), float("nan"), dtype=TD[dt], device="cuda")
+        acc = torch.zeros(L.xstats_words(reps, Cop), dtype=torch.int64, device="cuda")
+        L.check(L.conv2d_xstats(dt, xb.data_ptr(), Cip, wf.data_ptr(), y.data_ptr(), Cop, None, acc.data_ptr(), reps, *geom, st()), "conv + accumulate")
+        co = [torch.full((Cop,), float("nan"), device="cuda") for _ in range(4)]
+        rm, rv = torch.zeros(Cop, device="cuda"), torch.ones(Cop, device="cuda")
+        z = torch.full((B, Ho, Wo, Cop), float("nan"), dtype=TD[dt], device="cuda")
+        L.check(L.bn_act_fwd_xstats(dt, y.data_ptr(), Cop, acc.data_ptr(), reps, float(M), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                    0.1, 1e-5, *[c.data_ptr() for c in co], res.data_ptr(), Cop, z.data_ptr(), Cop, M, Cop, 1, 0.1, st()), "apply")
+        torch.cuda.synchronize()
+        return y, acc, co, rm, rv, z
+
+    ya, sa, ca, rma, rva, za = three_launches()
+    runs = [two_launches(planned) for _ in range(3)]
+    yb, acc, cb, rmb, rvb, zb = runs[0]
+    assert torch.equal(ya, yb)
+    # the digits, summed over the replicas, are exactly the sum of the fp32 partial rows: compare as integers in units of 2^-70 (python ints)
+    d = acc.reshape(planned, 3, 2, Cop).sum(0).cpu().numpy().astype(object)
+    tot = d[0] + d[1] * (1 << 40) + d[2] * (1 << 80)
+    rows_np = sa.cpu().numpy().astype(np.float64)
+    assert np.isfinite(rows_np).all()
+    import fractions
+    for which in range(2):
+        for c in (0, 1, Cop // 2, Cop - 1):
+            exact = sum(fractions.Fraction(float(v)) for v in rows_np[:, which, c])
+            # values below 2^-46 lose low bits (truncation toward zero): allow rows * 2^-70 of slack
+            assert abs(fractions.Fraction(int(tot[which, c]), 1 << 70) - exact) <= fractions.Fraction(rows, 1 << 70), (which, c)
+    for a_, b_, name in zip(ca, cb, ("scale", "shift", "mean", "invstd")):
+        np.testing.assert_allclose(b_.cpu().numpy(), a_.cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=name)
+    np.testing.assert_allclose(rmb.cpu().numpy(), rma.cpu().numpy(), rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(rvb.cpu().numpy(), rva.cpu().numpy(), rtol=2e-5, atol=2e-7)
+    diff = (za.float() != zb.float())
+    assert dt == F32 or float(diff.float().mean()) < 2e-3, float(diff.float().mean())      # (fp32 storage shows every last-bit difference of scale / shift)
+    torch.testing.assert_close(zb.float(), za.float(), rtol=1.6e-2 if dt == BF16 else 1e-4, atol=1e-3 if dt == BF16 else 1e-5)
+    for r in runs[1:]:
+        assert torch.equal(r[1], acc) and torch.equal(r[5], zb) and all(torch.equal(p, q) for p, q in zip(r[2], cb))
+    for reps in (1, 2, L.xstats_reps(1 << 30, Cop)):          # (the last one: the most replicas the consumer's prologue takes at this channel count)
+        if reps != planned and reps <= L.xstats_reps(1 << 30, Cop):
+            r = two_launches(reps)
+            assert torch.equal(r[5], zb) and all(torch.equal(p, q) for p, q in zip(r[2], cb)), reps
+    assert L.conv2d_xstats(dt, xb.data_ptr(), Cip, wf.data_ptr(), yb.data_ptr(), Cop, None, acc.data_ptr(), 3, *geom, st()) != 0       # not a power of two
+
+
+def test_xstats_nonfinite_poisons_the_channel():
+    """A non-finite conv output must still show as NaN coefficients (the rows + finalize form propagates it through its sums)."""
+    L = _lib.lib()
+    dt, B, Ci, H, W, Co = BF16, 2, 32, 20, 24, 64
+    gg = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Ci, H, W, generator=gg)
+    x[1, 3, 7, 9] = float("inf")
+    w = torch.randn(Co, Ci, 3, 3, generator=gg) / (Ci * 9) ** 0.5
+    xb = to_nhwc(x, dt)
+    wf, _ = pack(dt, w, need_d=False)
+    M = B * H * W
+    geom = (B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1)
+    y = torch.zeros((B, H, W, Co), dtype=TD[dt], device="cuda")
+    acc = torch.zeros(L.xstats_words(2, Co), dtype=torch.int64, device="cuda")
+    L.check(L.conv2d_xstats(dt, xb.data_ptr(), Ci, wf.data_ptr(), y.data_ptr(), Co, None, acc.data_ptr(), 2, *geom, st()))
+    co = [torch.zeros(Co, device="cuda") for _ in range(4)]
+    gamma, beta = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
+    z = torch.zeros((B, H, W, Co), dtype=TD[dt], device="cuda")
+    L.check(L.bn_act_fwd_xstats(dt, y.data_ptr(), Co, acc.data_ptr(), 2, float(M), gamma.data_ptr(), beta.data_ptr(), None, None, 0.1, 1e-5,
+                                *[c.data_ptr() for c in co], None, 0, z.data_ptr(), Co, M, Co, 1, 0.1, st()))
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(co[0]).all()) and bool(torch.isnan(z.float()).any())
 
 
 @pytest.mark.parametrize("case", [(2, 3, 33, 47, 3, 3, 1, 1, 1), (3, 3, 40, 40, 7, 7, 2, 3, 1), (2, 5, 21, 300, 3, 3, 2, 1, 1), (1, 8, 30, 26, 3, 3, 1, 2, 2),

@@ -1078,6 +1078,64 @@ def test_first_layer_weight_gradient_without_bn_apply(tmp_path):
             assert err < 1e-3, (n, err)
 
 
+def test_forward_statistics_through_exact_accumulators_match_the_finalize_launches(tmp_path):
+    """The full yolo_baseline (batch 4, bf16) with the forward BatchNorm statistics added to exact accumulators by the conv epilogues and finished in
+    the apply pass's prologue (Plan.stats_xacc; csrc/exact_acc.h) against the plan with partial rows + mdcv_bn_stats_finalize launches.  Kernel by
+    kernel the two agree to fp32 rounding of the finalize's summation order (tests/test_gpu_kernels.py::test_conv_xstats_exact_accumulators); in the
+    network that is fresh bf16 rounding noise: total loss within 2e-3, loss parts within 3 %, conv weight gradients of equal norm and aligned at the
+    bf16 mode's own noise level.  The plan is bit-reproducible run to run (integer atomics commute)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mdcv import engine
+    from mdcv.yolo.models import Darknet
+    cfg = bench.write_yolo_cfg(str(tmp_path))
+    saved = engine.Plan.stats_xacc
+
+    def run(on):
+        engine.Plan.stats_xacc = on
+        cwd = os.getcwd()
+        os.chdir(tmp_path)
+        try:
+            torch.manual_seed(0)
+            net = Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
+        finally:
+            os.chdir(cwd)
+        g = torch.Generator().manual_seed(1)
+        x = torch.rand(4, 3, 416, 416, generator=g).cuda()
+        tg = bench.synth_targets(4, 16, g).cuda()
+        outs = []
+        for _ in range(2):                                  # the same step twice (no optimizer): must be bit-identical
+            net.zero_grad()
+            out = net(x, tg)
+            out[0].sum().backward()
+            torch.cuda.synchronize()
+            outs.append(([float(o.detach().sum()) for o in out],
+                         {n: p.grad.detach().double().reshape(-1).cpu().clone() for n, p in net.named_parameters() if n.endswith("weight") and ".conv_" in n}))
+        plan = [p for p in net._plans.values() if p.has_bwd][0]
+        rstats = {n: b.detach().double().cpu().clone() for n, b in net.named_buffers() if "running" in n}
+        return outs, int(getattr(plan, "stats_xfolded", 0)), rstats
+    try:
+        (ra, na, sa), (rb, nb, sb) = run(True), run(False)
+    finally:
+        engine.Plan.stats_xacc = saved
+    assert na >= 40 and nb == 0, (na, nb)
+    (la, ga), (la2, ga2) = ra
+    assert la == la2 and all(bool((ga[n] == ga2[n]).all()) for n in ga)
+    lb, gb = rb[0]
+    assert abs(la[0] - lb[0]) <= 2e-3 * abs(lb[0]), (la, lb)
+    np.testing.assert_allclose(la[1:], lb[1:], rtol=3e-2)
+    for n in sa:
+        np.testing.assert_allclose(sa[n].numpy(), sb[n].numpy(), rtol=2e-2, atol=2e-3, err_msg=n)
+    lowest, worst = (1.0, None), (0.0, None)
+    for n in ga:
+        na_, nb_ = float(ga[n].norm()), float(gb[n].norm())
+        cos = float(ga[n] @ gb[n] / (na_ * nb_ + 1e-30))
+        lowest = min(lowest, (cos, n)); worst = max(worst, (abs(na_ - nb_) / nb_, n))
+    print("exact-accumulator statistics vs finalize launches: losses", la, lb, "lowest gradient cosine", lowest, "largest norm deviation", worst, "layers", na)
+    assert lowest[0] > 0.6 and worst[0] < 0.06, (lowest, worst)
+
+
 def test_forward_statistics_folded_in_launch_match_the_finalize_launches(tmp_path):
     """The full yolo_baseline (batch 4, bf16) with the forward BatchNorm statistics of the 3x3 stride-1 layers finished WITHOUT finalize launches
     (Plan.stats_fold: partial rows summed per group inside the conv launch, coefficients formed in the apply pass's prologue; csrc/stats_fold.h)
