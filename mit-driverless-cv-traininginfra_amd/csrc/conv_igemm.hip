@@ -1738,12 +1738,72 @@ struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, KK, Cout_pa
 // Tile = 16 output channels x up to 64 input channels x all taps, read from OIHW as contiguous runs (one run per output
 // channel), transposed through LDS and written as  wf[co][tap][ci .. ci+63]  (128-byte runs) and  wd[ci][tap][co .. co+15].
 // (A plain gather kernel read 17x the parameter bytes: rocprofv3 FETCH_SIZE 4.2 GB for 248 MB of weights.)
+// Full tiles of the layers that hold nearly all parameters (bf16, Cin and Cout multiples of 64 / 16, 3x3 or 1x1, 16-byte aligned OIHW rows):
+// the tap count is a compile-time constant, so no index of the tile needs a runtime division (the generic loops below spend ~100 of them per
+// thread and tile), the OIHW runs are read as float4 with a whole tile's loads in flight, and both packed forms leave as 16-byte stores.
+template <int KK>
+__device__ __forceinline__ void pack_tile_fast(const PackDesc& d, float* tile, int co0, int ci0) {
+  constexpr int PER = 64 * KK, CS = PER + 1, Q = PER / 4, NLD = (16 * Q + 255) / 256;
+  const float* __restrict__ w = d.w;
+  bf16_t* __restrict__ wf = reinterpret_cast<bf16_t*>(d.wf);
+  bf16_t* __restrict__ wd = reinterpret_cast<bf16_t*>(d.wd);
+  float4 v4[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < 16 * Q) {
+      const int co = i / Q, q = i - co * Q;
+      v4[k] = *reinterpret_cast<const float4*>(w + ((size_t)(co0 + co) * d.Cin + ci0) * KK + 4 * q);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < 16 * Q) {
+      const int co = i / Q, q = i - co * Q;
+      float* t = tile + co * CS + 4 * q;
+      t[0] = v4[k].x; t[1] = v4[k].y; t[2] = v4[k].z; t[3] = v4[k].w;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 16 * KK * 8; i += 256) {        // wf[co][tap][ci .. ci + 7]
+    const int cv = i & 7, r = i >> 3;
+    const int co = r / KK, t = r - co * KK;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[co * CS + (cv * 8 + e) * KK + t];
+    *reinterpret_cast<uint4*>(wf + ((size_t)(co0 + co) * KK + t) * d.Cin_pad + ci0 + cv * 8) = ET<bf16_t>::pack(v);
+  }
+  if (wd) {
+    for (int i = threadIdx.x; i < 2 * PER; i += 256) {          // wd[ci][tap][co .. co + 7]
+      const int cov = i & 1, r = i >> 1;
+      const int c = r / KK, t = r - c * KK;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[(cov * 8 + e) * CS + r];
+      *reinterpret_cast<uint4*>(wd + ((size_t)(ci0 + c) * KK + t) * d.Cout_pad + co0 + cov * 8) = ET<bf16_t>::pack(v);
+    }
+  }
+  __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* __restrict__ table) {
   extern __shared__ float tile[];
   const PackDesc d = table[blockIdx.y];
   if (blockIdx.x == 0 && d.bias)                          // the layer's fp32 bias parameter -> its padded operand buffer
     for (int i = threadIdx.x; i < d.Cout; i += 256) d.bias_pad[i] = d.bias[i];
+  if constexpr (sizeof(T) == 2) {
+    if ((d.KK == 9 || d.KK == 1) && d.Cin % 64 == 0 && d.Cin_pad == d.Cin && d.Cout % 16 == 0 && d.Cout_pad == d.Cout &&
+        (reinterpret_cast<uintptr_t>(d.w) & 15) == 0) {   // (uniform per layer)
+      const int tiles_ci = d.Cin / 64, ntiles = tiles_ci * (d.Cout / 16);
+      for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int co0 = (tl / tiles_ci) * 16, ci0 = (tl % tiles_ci) * 64;
+        if (d.KK == 9) pack_tile_fast<9>(d, tile, co0, ci0); else pack_tile_fast<1>(d, tile, co0, ci0);
+      }
+      return;
+    }
+  }
   const float* __restrict__ w = d.w;
   T* __restrict__ wf = reinterpret_cast<T*>(d.wf);
   T* __restrict__ wd = reinterpret_cast<T*>(d.wd);

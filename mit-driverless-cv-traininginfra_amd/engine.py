@@ -497,7 +497,7 @@ class Plan:
     # ---- forward BatchNorm statistics through exact accumulators (csrc/exact_acc.h): the conv's epilogue ADDS its per-tile sums to 64-bit
     # fixed-point words with fire-and-forget integer atomics (exact, order-independent: bit-reproducible), the BatchNorm-apply pass reads the
     # totals in its prologue.  No partial rows, no finalize launch, and -- unlike stats_fold above -- no hand-off inside a launch.
-    stats_xacc = False                 # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
+    stats_xacc = True                  # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
     stats_xacc_words = 1 << 20         # 64-bit words of the accumulator arena (zeroed by one memset at the head of the forward list)
     stats_xacc_chain = 1024            # most additions one word may see per launch (416^2 x 32, 43 264 rows on 32 replicas: +8 us on a 160 us launch -> keeps its rows)
 

@@ -333,8 +333,8 @@ class FlatParamsMixin:
             self._param_sync()                               # a pipelined optimizer step may still be updating the old buffers
         plist = [p for p in self.parameters()]
         dev = plist[0].device
-        total = sum(p.numel() for p in plist)
-        pflat = torch.empty(total, dtype=torch.float32, device=dev)
+        total = sum((p.numel() + 3) & ~3 for p in plist)           # every parameter starts on a 16-byte boundary (float4 rows in the pack kernel;
+        pflat = torch.zeros(total, dtype=torch.float32, device=dev)  # the 255-element head biases would misalign everything behind them); padding stays 0
         gflat = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
         self._goff = {}
@@ -344,7 +344,7 @@ class FlatParamsMixin:
                 pflat[off:off + n].copy_(p.data.reshape(-1))
                 p.data = pflat[off:off + n].view(p.shape)
                 self._goff[id(p)] = (off, n)
-                off += n
+                off += (n + 3) & ~3
         self._plist, self._pflat, self._gflat = plist, pflat, gflat
         self._flat_ptrs = [p.data_ptr() for p in plist]
         self._plans = {}

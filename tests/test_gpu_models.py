@@ -1149,7 +1149,8 @@ def test_forward_statistics_folded_in_launch_match_the_finalize_launches(tmp_pat
     from mdcv import engine
     from mdcv.yolo.models import Darknet
     cfg = bench.write_yolo_cfg(str(tmp_path))
-    saved = engine.Plan.stats_fold
+    saved, saved_x = engine.Plan.stats_fold, engine.Plan.stats_xacc
+    engine.Plan.stats_xacc = False                         # (the default form, exact accumulators, would take the candidates first)
 
     def run(on):
         engine.Plan.stats_fold = on
@@ -1176,7 +1177,7 @@ def test_forward_statistics_folded_in_launch_match_the_finalize_launches(tmp_pat
     try:
         (ra, na), (rb, nb) = run(True), run(False)
     finally:
-        engine.Plan.stats_fold = saved
+        engine.Plan.stats_fold, engine.Plan.stats_xacc = saved, saved_x
     assert na >= 15 and nb == 0, (na, nb)
     (la, ga), (la2, ga2) = ra
     assert la == la2 and all(bool((ga[n] == ga2[n]).all()) for n in ga)
