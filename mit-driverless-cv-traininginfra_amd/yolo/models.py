@@ -227,8 +227,8 @@ class _NetPlan(Plan):
         """Raises IndexError if the targets of the LAST forward through this plan held a centre coordinate >= 1.0 (the reference's
         build_targets indexes its [B,A,G,G] tensors with gi == G there and raises, utils/utils.py:262; the fused head drops the
         target and sets a flag).  The flags ride to a pinned host word with a non-blocking copy behind every forward and are
-        looked at (i) when the backward of that step starts -- waiting for the copy (one host wait per step, ~20 us of GPU idle between
-        forward and backward: a bad label then raises BEFORE optimizer.step(), like the reference) unless the model sets
+        looked at (i) at the end of that step's backward(), behind its queued launches -- waiting for the copy (one host wait per step
+        that the GPU does not see: a bad label then raises BEFORE optimizer.step(), like the reference) unless the model sets
         `strict_targets = False`, in which case the look is a query and a copy that has not landed stays pending --, (ii) at the
         start of the NEXT forward and (iii) when the plan is dropped."""
         ev = getattr(self, "_err_event", None)
@@ -460,10 +460,6 @@ class FlatParamsMixin:
 
     def _run_backward(self, plan, gout):
         self._last_train_plan = plan
-        # a label with cx / cy >= 1.0 (reference: IndexError inside build_targets, BEFORE any update, utils/utils.py:262): the flag copy
-        # recorded behind the forward has almost always landed by now, so raising here precedes optimizer.step()
-        if getattr(plan, "err_views", ()) and _CHECK_TARGETS:
-            plan.check_targets(block=getattr(self, "strict_targets", True))
         pl = self._plist
         keep = None
         if pl[0].grad is not None:                       # gradients were not reset to None: accumulate semantics
@@ -487,6 +483,12 @@ class FlatParamsMixin:
             elif p.grad.data_ptr() != v.data_ptr():      # foreign .grad tensor: fold ours in, then re-point
                 v.add_(p.grad)
                 p.grad = v
+        # a label with cx / cy >= 1.0 (reference: IndexError inside build_targets, BEFORE any update, utils/utils.py:262).  Looked at HERE, with
+        # the backward launches already queued: the host's wait for the flag copy behind the forward then costs the GPU nothing (at the head
+        # of the backward it left the GPU idle until the first backward launch arrived: 13.77 vs 13.65 ms per step), the heads dropped the
+        # bad target in the forward so the queued backward is well defined, and the error still leaves backward() -- before optimizer.step()
+        if getattr(plan, "err_views", ()) and _CHECK_TARGETS:
+            plan.check_targets(block=getattr(self, "strict_targets", True))
 
 
 class Darknet(FlatParamsMixin, nn.Module):
