@@ -125,6 +125,8 @@ def call_work(name, args):
     if name == "mdcv_conv2d_dgrad_bnsums":
         Bq, Hin, Win, Cin, Hout, Wout, Nout, KH, KW = args[8:17]
         return 2.0 * Bq * Hin * Win * Cin * KH * KW * Nout, 0.0
+    if name == "mdcv_pw_bwd":                # 1x1 data gradient + weight-gradient slabs in one launch: (dt, dy, ldy, x, ldx, wd, dx, lddx, add, ldadd, ws, slabs, fy, ..., M, Cin, Cout)
+        return 2.0 * 2.0 * args[20] * args[21] * args[22], 0.0
     if name == "conv2d_wgrad":               # info = (B, Hin, Win, Cin_pad, Hout, Wout, Cout_pad, k, stride, splits)
         B, Hin, Win, Cin, Hout, Wout, Cout, k = args[:8]
         return 2.0 * B * Hout * Wout * Cout * k * k * Cin, 0.0
@@ -188,6 +190,8 @@ def kernel_breakdown(model, plan, step_fn):
                 LAUNCH_DUMP.append((name, ms, [int(v) for v in args[8:20]] + [1]))
             elif name == "conv2d_wgrad":
                 LAUNCH_DUMP.append((name, ms, list(args), [(short_symbol(k), t) for k, t in kern]))
+            elif name == "mdcv_pw_bwd":
+                LAUNCH_DUMP.append((name, ms, [int(args[20]), int(args[21]), int(args[22]), int(args[11]), int(args[8] is not None), int(args[12] is not None)]))
             elif name.startswith("mdcv_bn_act") or name in ("mdcv_partial_reduce",):
                 LAUNCH_DUMP.append((name, ms, [int(v) for v in args if isinstance(v, int) and 0 < v < (1 << 31)][-6:]))
 

@@ -312,6 +312,20 @@ int mdcv_graph_destroy(void* graph_exec);
  *      (CVC-YOLOv3/models.py:48-72 + the shortcut of :322-327), the pair  mdcv_bn_act_fwd + mdcv_conv2d  (forward) and the pair
  *      mdcv_bn_act_bwd_apply + mdcv_conv2d / mdcv_conv2d_dgrad_bnsums  (backward) by one launch each, with identical results.
  *      K = channels of the transformed operand (multiple of 32, K/8 divides 512, <= 1024), N = output channels (multiple of 8). */
+/* ---- backward of a pointwise (1x1, stride 1) nn.Conv2d in ONE launch (CVC-YOLOv3/models.py:59-65, the 34 1x1 layers of yolo_baseline):
+ * dx = dy . W (+ addsrc) [M x Cin] AND the fp32 slab partials of dW = dy^T . x (ws[slabs][Cout][Cin]; one slab per run of pixels, summed in
+ * fixed order by mdcv_wgrad_reduce: bit-reproducible), a workgroup holding each dy / x pixel tile in LDS once for both products.  fy != NULL:
+ * also the BatchNorm-backward partial sums of the layer that produced this conv's input, [slabs][2][Cin] (as mdcv_conv2d_dgrad_bnsums).
+ * bf16 only; Cout (channels of dy, padded) in {64, 128, 256, 512}, Cin a multiple of 64.  mdcv_pw_bwd_slabs returns 0 for layers that do not
+ * take this form (then: mdcv_conv2d mode 1 + mdcv_conv2d_wgrad). */
+int mdcv_pw_bwd_slabs(int dtype, long long M, int Cin, int Cout, int ldy, int ldx, int lddx, int ldadd, int ldfy);
+int mdcv_pw_bwd(int dtype, const void* dy, int ldy, const void* x, int ldx, const void* wd_packed, void* dx, int lddx, const void* addsrc,
+                int ldadd, float* ws, int slabs, const void* fy, int ldfy, const float* fscale, const float* fshift, const float* fmean, int fact,
+                float fslope, float* fpartial, long long M, int Cin, int Cout, void* stream);
+/* sum of fp32 weight-gradient slabs ws[splits][Cout_pad][KK * Cin_pad] into the OIHW gradient [Cout][Cin][KK] (fixed split order) */
+int mdcv_wgrad_reduce(const float* ws, int splits, float* dw_oihw, int accumulate, int Cout_pad, int Cout, int Cin_pad, int Cin, int KK,
+                      void* stream);
+
 int mdcv_pw_rows(long long M, int K);          /* rows of stats_partial / fpartial the two entry points below write: one per pixel tile */
 int mdcv_pw_set_variant(int v);                /* tuning hook: 64 / 32 / 16 pixels per tile, 0 = heuristic */
 /* forward: z = act(y * scale + shift) (+ resid) -> z_out ; out = z . W^T (+ bias) ; stats_partial (may be NULL): [mdcv_pw_rows][2][N] */

@@ -2247,6 +2247,12 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, KH * KW, accumulate, st);
 }
 
+int mdcv_wgrad_reduce(const float* ws, int splits, float* dw_oihw, int accumulate, int Cout_pad, int Cout, int Cin_pad, int Cin, int KK,
+                      void* stream) {
+  if (!ws || !dw_oihw || splits < 1 || Cout < 1 || Cin < 1 || Cout > Cout_pad || Cin > Cin_pad || KK < 1) return MDCV_EARG;
+  return launch_wgrad_reduce(ws, dw_oihw, splits, Cout_pad, Cout, Cin_pad, Cin, KK, accumulate, (hipStream_t)stream);
+}
+
 int mdcv_pack_weights(int dtype, const float* w_oihw, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,
                       int Cout_pad, int Cin_pad, void* stream) {
   if (!w_oihw || !w_fwd) return MDCV_EARG;

@@ -715,6 +715,95 @@ def test_pw_block_backward(case, fused):
             np.testing.assert_allclose(an, bn_, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(bn_).max())), err_msg=name)
 
 
+PWB_CASES = [  # (M, Cout = channels of dy, real Cout, Cin = channels of x / dx, extra channel stride, addsrc)
+    (32 * 21 + 17, 256, 256, 512, 0, True), (5408, 512, 512, 1024, 0, True), (3000, 128, 128, 256, 8, False), (2703, 256, 255, 256, 0, False),
+    (700, 64, 64, 128, 16, True), (86528, 128, 128, 256, 0, True), (1100, 256, 256, 768, 8, True), (96, 128, 128, 64, 0, False)]
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["plain", "bnsums"])
+@pytest.mark.parametrize("case", PWB_CASES, ids=[str(c) for c in PWB_CASES])
+def test_pw_bwd_one_launch(case, fused):
+    """mdcv_pw_bwd (data gradient + weight-gradient slabs of a 1x1 conv in one launch, optional addsrc and fused BatchNorm-backward sums of the
+    producer layer) + mdcv_wgrad_reduce against F.conv2d autograd on the bf16-rounded operands (dx: bf16 output rounding, 2e-2 of the
+    largest element; dW: fp32 accumulation, 1e-4 of the largest element) and against the launches it replaces (mdcv_conv2d mode 1,
+    mdcv_conv2d_wgrad); ragged Cout (255 of 256), channel strides wider than the tensors, ragged last tiles and slabs."""
+    L = _lib.lib()
+    M, K, Kr, N, xs, with_add = case
+    g = torch.Generator().manual_seed(M + K + N + 7)
+    ldk, ldn = K + xs, N + xs
+    dyf = torch.randn(M, ldk, generator=g)
+    dyf[:, Kr:] = 0.0                                                # pad lanes of the activations are exact zeros (DESIGN 3)
+    dy = dyf.to(torch.bfloat16).cuda()
+    x = torch.randn(M, ldn, generator=g).to(torch.bfloat16).cuda()
+    w = torch.randn(Kr, N, 1, 1, generator=g) / K ** 0.5             # the layer's weight [Cout][Cin]
+    _, wd = pack(BF16, w)
+    add = torch.randn(M, ldn, generator=g).to(torch.bfloat16).cuda() if with_add else None
+    fy = (torch.randn(M, ldn, generator=g) * 1.3 + 0.2).to(torch.bfloat16).cuda()
+    fsc = (torch.rand(N, generator=g) + 0.5).cuda(); fsh = (torch.randn(N, generator=g) * 0.3).cuda()
+    fmean = (torch.randn(N, generator=g) * 0.2 + 0.2).cuda(); finv = (torch.rand(N, generator=g) + 0.5).cuda(); gamma = (torch.rand(N, generator=g) + 0.5).cuda()
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    slabs = L.pw_bwd_slabs(BF16, M, N, K, ldk, ldn, ldn, ldn if with_add else 8, ldn if fused else 8)
+    assert slabs >= 1
+    ws = torch.full((slabs, K, N), float("nan"), device="cuda")
+    part = torch.full((slabs, 2, N), float("nan"), device="cuda")
+    dx1 = torch.zeros(M, ldn, dtype=torch.bfloat16, device="cuda")
+    dw1 = torch.full((Kr, N, 1, 1), 7.0, device="cuda")
+    L.check(L.pw_bwd(BF16, dy.data_ptr(), ldk, x.data_ptr(), ldn, wd.data_ptr(), dx1.data_ptr(), ldn, P(add), ldn, ws.data_ptr(), slabs,
+                     fy.data_ptr() if fused else None, ldn, fsc.data_ptr(), fsh.data_ptr(), fmean.data_ptr(), 1, 0.1, part.data_ptr(), M, N, K, st()), "pw_bwd")
+    L.check(L.wgrad_reduce(ws.data_ptr(), slabs, dw1.data_ptr(), 0, K, Kr, N, N, 1, st()), "wgrad_reduce")
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(ws).any())
+    # the launches it replaces
+    dx0 = torch.zeros(M, ldn, dtype=torch.bfloat16, device="cuda")
+    L.check(L.conv2d(BF16, 1, dy.data_ptr(), ldk, wd.data_ptr(), dx0.data_ptr(), ldn, None, P(add), ldn, None, 1, M, 1, K, M, 1, N, 1, 1, 1, 0, 1, st()))
+    splits = L.conv2d_wgrad_splits_geom(BF16, 1, M, 1, N, M, 1, K, 1, 1, 1, 0, 1, ldk, ldn)
+    ws0 = torch.empty(splits * K * N, device="cuda")
+    dw0 = torch.zeros(Kr, N, 1, 1, device="cuda")
+    L.check(L.conv2d_wgrad(BF16, dy.data_ptr(), ldk, x.data_ptr(), ldn, ws0.data_ptr(), splits, dw0.data_ptr(), 0, 1, M, 1, N, N, M, 1, K, Kr, 1, 1, 1, 0, 1, st()))
+    torch.cuda.synchronize()
+    # torch autograd on the same (bf16-rounded) operands
+    xt = x[:, :N].float().cpu().t().reshape(1, N, 1, M)
+    wt = w.to(torch.bfloat16).float().requires_grad_(True)
+    xt.requires_grad_(True)
+    F.conv2d(xt, wt).backward(dy[:, :Kr].float().cpu().t().reshape(1, Kr, 1, M))
+    dxf = xt.grad.reshape(N, M).t() + (add[:, :N].float().cpu() if with_add else 0)
+    wz = torch.zeros(Kr, N, 1, 1, requires_grad=True)
+    F.conv2d(xt.detach(), wz).backward(dy[:, :Kr].float().cpu().t().reshape(1, Kr, 1, M))
+    assert float((dx1[:, :N].float().cpu() - dxf).abs().max()) <= 2e-2 * float(dxf.abs().max())
+    assert float((dx1[:, :N].float() - dx0[:, :N].float()).abs().max()) <= 2 ** -7 * float(dxf.abs().max())      # (one bf16 rounding step apart at most)
+    if xs:
+        assert float(dx1[:, N:].float().abs().max()) == 0.0                          # nothing written between the rows
+    ref = wz.grad.numpy()
+    tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(dw1.cpu().numpy(), ref, rtol=0, atol=tol)
+    np.testing.assert_allclose(dw1.cpu().numpy(), dw0.cpu().numpy(), rtol=0, atol=tol)
+    if fused:
+        assert not bool(torch.isnan(part).any())
+        # the sums over the rows as stored: g = dz * act'(scale * y + shift) ; sum g, sum g (y - mean), in float64 on the host
+        dz = dx1[:, :N].double().cpu(); yv = fy[:, :N].double().cpu()
+        pre = fy[:, :N].float().cpu() * fsc.cpu() + fsh.cpu()                       # (fp32, as the kernel forms it)
+        gg = dz * torch.where(pre > 0, torch.ones_like(dz), torch.full_like(dz, float(np.float32(0.1))))
+        s_g, s_x = gg.sum(0), (gg * (yv - fmean.double().cpu())).sum(0)
+        got_g, got_x = part[:, 0].double().sum(0).cpu(), part[:, 1].double().sum(0).cpu()
+        scale_g = float(gg.abs().sum(0).max())
+        assert float((got_g - s_g).abs().max()) <= 2e-6 * scale_g and float((got_x - s_x).abs().max()) <= 4e-6 * scale_g * 3
+        if N <= 512:                                                                 # ... and through the finalize, against the stand-alone reduce pass
+            acc = torch.zeros(3 * N, dtype=torch.float64, device="cuda")
+            pws = torch.empty(L.bn_act_bwd_reduce_ws_floats(BF16, M, N, 2), device="cuda")
+            dxc = dx1[:, :N].contiguous(); fyc = fy[:, :N].contiguous()
+            L.check(L.bn_act_bwd_reduce(BF16, dxc.data_ptr(), N, fyc.data_ptr(), N, fsc.data_ptr(), fsh.data_ptr(), fmean.data_ptr(), finv.data_ptr(),
+                                        None, 0, None, None, None, None, acc.data_ptr(), pws.data_ptr(), M, N, 1, 0.1, st()))
+            refc = [torch.zeros(N, device="cuda") for _ in range(5)]
+            L.check(L.bn_bwd_finalize(acc.data_ptr(), 1, 2, 1, float(M), gamma.data_ptr(), fmean.data_ptr(), finv.data_ptr(), *[b.data_ptr() for b in refc], N, st()))
+            got = [torch.zeros(N, device="cuda") for _ in range(5)]
+            L.check(L.bn_bwd_finalize_rows(part.data_ptr(), slabs, N, float(M), gamma.data_ptr(), fmean.data_ptr(), finv.data_ptr(),
+                                           *[b.data_ptr() for b in got], st()))
+            torch.cuda.synchronize()
+            for a_, b_, name in zip(got, refc, ("dgamma", "dbeta", "cA", "cB", "cC")):
+                an, bn_ = a_.cpu().numpy(), b_.cpu().numpy()
+                np.testing.assert_allclose(an, bn_, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(bn_).max())), err_msg=name)
+
+
 WGRAD_SHIFT_CASES = [(2, 128, 13, 13, 128), (3, 128, 26, 20, 256), (1, 256, 52, 52, 128), (5, 128, 9, 8, 128), (32, 128, 13, 13, 256),
                      (8, 128, 80, 80, 128)]
 
