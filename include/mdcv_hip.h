@@ -294,6 +294,10 @@ int mdcv_event_destroy(void* ev);
 /* everything enqueued on `from` so far happens before what is enqueued on `to` afterwards (one event record + one stream wait on a
  * ring event without timing; device_scope != 0: the record releases to device scope, all a consumer on the same GPU needs) */
 int mdcv_stream_fork(void* from, void* to, int device_scope);
+/* the same ordering without a marker packet in the producer's queue: the next kernel this library launches (exactly one, on `from`) carries
+ * the event as its dispatch packet's stop event; mdcv_stream_fork_wait(to, ev) then makes `to` wait for it */
+int mdcv_stream_fork_arm(void* from, int device_scope, void** ev_out);
+int mdcv_stream_fork_wait(void* to, void* ev);
 /* In-library kernel profiler: between _begin and _stop EVERY kernel this library launches carries a start / stop HIP event pair bound
  * to its own dispatch on the stream it is launched on (hipExtLaunchKernel: no extra packets, the durations are the kernel's own).  _count = launches recorded so far (lets a host attribute them to its own calls); _stop ends recording,
  * waits for the events and returns the record count; _read(i) -> duration in ms and the kernel symbol as rocprofv3 prints it.

@@ -19,6 +19,7 @@
 #include <vector>
 
 int mdcv_g_prof = 0;
+hipEvent_t mdcv_g_arm = nullptr;
 
 namespace {
 struct Rec { const void* fn; hipEvent_t e0, e1; };

@@ -26,7 +26,7 @@ BUILD_DEFAULTS = dict(pw_fuse=engine.Plan.pw_fuse, fuse_skip=engine.Plan.fuse_sk
 
 def apply(codes):
     for c in codes:
-        if not c or c[0] in "PFSRAXTYB":
+        if not c or c[0] in "PFSRAXTYBK":
             continue
         {"c": L.cdll.mdcv_conv2d_set_variant, "w": L.cdll.mdcv_conv2d_wgrad_set_variant, "p": L.cdll.mdcv_pw_set_variant, "b": L.cdll.mdcv_bn_act_fwd_statsfold_blocks}[c[0]](int(c[1:]))
 
@@ -37,7 +37,12 @@ def apply_build(codes):
     engine.Plan.stats_fold = BUILD_DEFAULTS["sf"]
     engine.Plan.stats_xacc = BUILD_DEFAULTS["sx"]
     engine.Plan.pw_bwd1 = BUILD_DEFAULTS["pb"]
+    from mdcv.yolo import models as _ym0
+    _ym0._NetPlan.fork_on_dispatch = True
     for c in codes:
+        if c and c[0] == "K":          # K0 / K1: side-stream forks as event records on the main queue / carried by the producing kernel's dispatch packet
+            from mdcv.yolo import models as _ym
+            _ym._NetPlan.fork_on_dispatch = bool(int(c[1:]))
         if c and c[0] == "B":          # B0 / B1: 1x1 layers' backward as data gradient + weight gradient + reduce / in one launch (csrc/pw_bwd.hip)
             engine.Plan.pw_bwd1 = bool(int(c[1:]))
         if c and c[0] == "Y":          # Y0 / Y1: forward statistics as partial rows + finalize launch / through exact accumulators (csrc/exact_acc.h)
