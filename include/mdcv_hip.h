@@ -50,45 +50,10 @@ int mdcv_conv2d_dgrad_bnsums(int dtype, const void* in, int in_ldc, const void* 
                              int add_ldc, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
                              int pad, int dil, const void* y, int ldy, const float* scale, const float* shift, const float* mean, int act,
                              float slope, float* partial, void* stream);
-/* The same launch storing g = dz * act'(scale*y + shift) in place of dz (the sums are those of g either way).  Only the stride-2 form of the
- * 3x3 shift kernel carries it (_masked_ok() = 1: bf16, 3x3 / stride 2 / pad 1, Hout = 2 Hin, 32 or 64 output channels); anything else is
- * MDCV_EARG.  Consumer: a first layer (no data gradient of its own) whose weight gradient is assembled from correlations of g, y and 1 with
- * the layer input -- mdcv_conv_tap_sums / mdcv_first_layer_wgrad_combine below -- so that its BatchNorm-apply pass never runs
- * (reference: autograd of layer 0, CVC-YOLOv3/models.py:57-71). */
-int mdcv_conv2d_dgrad_masked_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
-                                int pad, int dil, int in_ldc);
-int mdcv_conv2d_dgrad_bnsums_masked(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const void* addsrc,
-                                    int add_ldc, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
-                                    int pad, int dil, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
-                                    int act, float slope, float* partial, void* stream);
-/* X1[kh*KW + kw][c] (c < 8, fp32) = sum over images and output positions of x[b][oh*stride - pad + kh*dil][ow*stride - pad + kw*dil][c]
- * (zero outside the image): the column sums of the layer's im2col matrix.  x: bf16 NHWC, 8 padded channels; KH, KW <= 7; ws: _ws_floats() floats. */
-long long mdcv_conv_tap_sums_ws_floats(int B, int H, int W, int KH, int KW);
-int mdcv_conv_tap_sums(int dtype, const void* x, int ldc, int B, int H, int W, int Hout, int Wout, int KH, int KW, int stride, int pad, int dil,
-                       float* ws, float* out, void* stream);
-/* dw[co][ci][t] = cA[co]*G[co][ci][t] + cB[co]*Y[co][ci][t] + cC[co]*X1[t][ci]: the weight gradient of conv -> BatchNorm -> act with
- * dy = cA*g + cB*y + cC never formed.  G, Y: mdcv_conv2d_wgrad of g and of the forward output y against the layer input (OIHW fp32, real
- * channel counts); cA, cB, cC: mdcv_bn_bwd_finalize_rows.  Cin <= 8. */
-int mdcv_first_layer_wgrad_combine(const float* G, const float* Y, const float* X1, const float* cA, const float* cB, const float* cC,
-                                   float* dw, int Cout, int Cin, int KK, void* stream);
-/* Forward statistics WITHOUT a finalize launch.  mdcv_conv2d_statsfold = mdcv_conv2d(mode 0) with stats_partial, and additionally the
- * workgroup that completes a group of G consecutive partial rows (G even) sums them in row order into super[group][2][Nout]
- * (ceil(rows / G) groups; rows = mdcv_conv2d_stats_rows_geom of the geometry).  counters: ceil(rows / G) * (Nout / 32 + 1) 32-bit words, ZERO
- * before the launch.  _ok() = 1 where the forward kernel of the geometry carries it (bf16, 3x3 / stride 1 / pad 1 shift kernel); else MDCV_EARG.
- * Consumer: mdcv_bn_act_fwd_statsfold -- BatchNorm(batch statistics) + activation (+ residual) whose prologue finishes the statistics from
- * the super rows (ngroups * ceil(C / 256) <= 16) and writes scale / shift / mean / invstd / running statistics as mdcv_bn_stats_finalize does (C <= 1024).
- * Replaces conv -> mdcv_bn_stats_finalize -> mdcv_bn_act_fwd of the reference's nn.Sequential(conv, BatchNorm2d, LeakyReLU)
- * (CVC-YOLOv3/models.py:57-71) by two launches. */
-int mdcv_conv2d_statsfold_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride, int pad,
-                             int dil, int in_ldc);
-int mdcv_conv2d_statsfold(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const float* bias,
-                          float* stats_partial, float* super, void* counters, int G, int rows, int B, int Hin, int Win, int Cin, int Hout,
-                          int Wout, int Nout, int KH, int KW, int stride, int pad, int dil, void* stream);
-int mdcv_bn_act_fwd_statsfold(int dtype, const void* y, int ldy, const float* super, int ngroups, double count, const float* gamma,
-                              const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale,
-                              float* shift, float* mean, float* invstd, const void* resid, int ldr, void* out, int ldo, int M, int C,
-                              int act, float slope, void* stream);
-int mdcv_bn_act_fwd_statsfold_blocks(int n);   /* tuning hook: workgroup target of mdcv_bn_act_fwd_statsfold (default 512) */
+/* 1 when the data gradient of this geometry runs as the stride-2 form of the 3x3 shift kernel (bf16, 3x3 / stride 2 / pad 1, Hout = 2 Hin, 32 or 64
+ * output channels): its store loop writes whole output rows from LDS and carries the fused sums at every size (one partial row per 8 x 31 tile). */
+int mdcv_conv2d_dgrad_s2_form_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
+                                 int pad, int dil, int in_ldc);
 /* Forward statistics through EXACT ACCUMULATORS (csrc/exact_acc.h): the conv's epilogue adds its per-tile sums (per output channel: sum, sum of
  * squares) to xacc = [reps][3][2][Nout] signed 64-bit words (mdcv_xstats_words; ZERO before the launch) with fire-and-forget integer atomics --
  * three 40-bit digits of a fixed-point number with quantum 2^-70, so every addition is exact and the totals do not depend on the order the
@@ -313,9 +278,15 @@ int mdcv_graph_destroy(void* graph_exec);
 
 /* ---- 1x1 convolution blocks with the neighbouring BatchNorm pass folded into the operand load (csrc/pw_block.hip; bf16 only).
  *      Replaces, for a 1x1 conv whose input is the output of a conv -> BatchNorm -> activation (-> shortcut add) block
- *      (CVC-YOLOv3/models.py:48-72 + the shortcut of :322-327), the pair  mdcv_bn_act_fwd + mdcv_conv2d  (forward) and the pair
- *      mdcv_bn_act_bwd_apply + mdcv_conv2d / mdcv_conv2d_dgrad_bnsums  (backward) by one launch each, with identical results.
- *      K = channels of the transformed operand (multiple of 32, K/8 divides 512, <= 1024), N = output channels (multiple of 8). */
+ *      (CVC-YOLOv3/models.py:48-72 + the shortcut of :322-327), the pair  mdcv_bn_act_fwd + mdcv_conv2d  by one launch with identical results.
+ *      K = channels of the transformed operand (multiple of 32, K/8 divides 256, 64 <= K <= 1024), N = output channels (multiple of 8). */
+int mdcv_pw_rows(long long M, int K);          /* rows of stats_partial the entry points below write: one per pixel tile */
+int mdcv_pw_set_variant(int v);                /* tuning hook: 64 / 32 / 16 pixels per tile, 0 = heuristic */
+/* forward: z = act(y * scale + shift) (+ resid) -> z_out ; out = z . W^T (+ bias) ; stats_partial (may be NULL): [mdcv_pw_rows][2][N] */
+int mdcv_pw_conv_fwd(int dtype, const void* y, int ldy, const float* scale, const float* shift, const void* resid, int ldr, int act,
+                     float slope, void* z_out, int ldz, const void* w_packed, const float* bias, void* out, int out_ldc,
+                     float* stats_partial, long long M, int K, int N, void* stream);
+
 /* ---- backward of a pointwise (1x1, stride 1) nn.Conv2d in ONE launch (CVC-YOLOv3/models.py:59-65, the 34 1x1 layers of yolo_baseline):
  * dx = dy . W (+ addsrc) [M x Cin] AND the fp32 slab partials of dW = dy^T . x (ws[slabs][Cout][Cin]; one slab per run of pixels, summed in
  * fixed order by mdcv_wgrad_reduce: bit-reproducible), a workgroup holding each dy / x pixel tile in LDS once for both products.  fy != NULL:
@@ -329,19 +300,6 @@ int mdcv_pw_bwd(int dtype, const void* dy, int ldy, const void* x, int ldx, cons
 /* sum of fp32 weight-gradient slabs ws[splits][Cout_pad][KK * Cin_pad] into the OIHW gradient [Cout][Cin][KK] (fixed split order) */
 int mdcv_wgrad_reduce(const float* ws, int splits, float* dw_oihw, int accumulate, int Cout_pad, int Cout, int Cin_pad, int Cin, int KK,
                       void* stream);
-
-int mdcv_pw_rows(long long M, int K);          /* rows of stats_partial / fpartial the two entry points below write: one per pixel tile */
-int mdcv_pw_set_variant(int v);                /* tuning hook: 64 / 32 / 16 pixels per tile, 0 = heuristic */
-/* forward: z = act(y * scale + shift) (+ resid) -> z_out ; out = z . W^T (+ bias) ; stats_partial (may be NULL): [mdcv_pw_rows][2][N] */
-int mdcv_pw_conv_fwd(int dtype, const void* y, int ldy, const float* scale, const float* shift, const void* resid, int ldr, int act,
-                     float slope, void* z_out, int ldz, const void* w_packed, const float* bias, void* out, int out_ldc,
-                     float* stats_partial, long long M, int K, int N, void* stream);
-/* backward: dy = cA*g + cB*y + cC with g = dz * act'(y*scale + shift) -> dy_out ; dx = dy . W (+ addsrc) ; fy != NULL: also the
- * BatchNorm-backward partial sums of the layer that produced this conv's input, [mdcv_pw_rows][2][N] (as mdcv_conv2d_dgrad_bnsums). */
-int mdcv_pw_conv_bwd(int dtype, const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* cA,
-                     const float* cB, const float* cC, int act, float slope, void* dy_out, int lddy, const void* wd_packed, void* dx,
-                     int dx_ldc, const void* addsrc, int add_ldc, const void* fy, int ldfy, const float* fscale, const float* fshift,
-                     const float* fmean, int fact, float fslope, float* fpartial, long long M, int K, int N, void* stream);
 
 /* ---- the one exchange step of the data-parallel path, for hosts that do not go through torch.distributed:
  *      nn.DataParallel's gradient reduction (CVC-YOLOv3/train.py:193-195 with `losses[0].sum().backward()`, train.py:70) as an RCCL

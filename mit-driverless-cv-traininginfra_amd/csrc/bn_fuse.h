@@ -18,8 +18,6 @@ struct BnFuseArgs {
   float* partial;           // [rows][2][C] fp32
   int ldy, act, row_base;   // act: 0 none, 1 leaky, 2 relu (slope 0)
   float slope;
-  int store_g;              // 1: the launch stores g = dz * act'(scale * y + shift) instead of dz (stride-2 form of the shift kernel only:
-                            // mdcv_conv2d_dgrad_bnsums_masked, the first layer's backward without its BatchNorm-apply pass)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for every global store the thread
@@ -70,21 +68,6 @@ struct BnFuseAcc {
       sg[e] += g;
       sx[e] += g * (yv[e] - fm[e]);
     }
-  }
-  // The masked form: returns g (rounded to T) for the caller to store in place of dz; the sums see g as stored.
-  __device__ __forceinline__ uint4 add_store_g(const BnFuseArgs& f, const float (&dv)[VEC], const uint4& yq) {
-    float yv[VEC], g[VEC];
-    ET<T>::unpack(yq, yv);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float pre = yv[e] * fs[e] + fb[e];
-      g[e] = (f.act != 0 && !(pre > 0.f)) ? dv[e] * f.slope : dv[e];
-    }
-    const uint4 q = ET<T>::pack(g);
-    ET<T>::unpack(q, g);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { sg[e] += g[e]; sx[e] += g[e] * (yv[e] - fm[e]); }
-    return q;
   }
   // ---- bf16 form (VEC = 8, 16 values per thread): no barrier inside the store loop.
   // The lanes that share a channel vector sit VPRO apart.  Two rounds of gfx950 row swaps fold the four 16-lane rows AND halve the

@@ -1894,9 +1894,9 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
                        const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
                        int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
                        int KH, int KW, int stride, int pad, int dil, const BnFuseArgs* fuse, void* stream, const EpiArgs* epi = nullptr,
-                       const StatsFoldArgs* fold = nullptr, const XAccArgs* xacc = nullptr) {
+                       const XAccArgs* xacc = nullptr) {
   if (!in || !w_packed || !out) return MDCV_EARG;
-  if (xacc && (mode != 0 || stats_partial || fuse || epi || fold || !xacc->acc || xacc->reps < 1 || (xacc->reps & (xacc->reps - 1)))) return MDCV_EARG;
+  if (xacc && (mode != 0 || stats_partial || fuse || epi || !xacc->acc || xacc->reps < 1 || (xacc->reps & (xacc->reps - 1)))) return MDCV_EARG;
   if (epi && (mode != 0 || stats_partial || fuse)) return MDCV_EARG;        // the inference epilogue is a forward-only, statistics-free path
   if ((Cin & 7) || (Nout & 7) || (in_ldc & 7) || (out_ldc & 7) || (addsrc && (add_ldc & 7))) return MDCV_EARG;
   if (stride != 1 && stride != 2) return MDCV_EARG;
@@ -1954,8 +1954,7 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   // 3x3 / stride 1 / pad 1 on wide layers: nine shifted GEMMs over one LDS-resident activation chunk (conv_shift.hip)
   const bool shift_ok = Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc);
   if (shift_ok && (g_conv_variant < 0 || fuse))
-    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st, epi, dil, fold, xacc);
-  if (fold) return MDCV_EARG;                     // (only the kernels above fold their statistics rows: mdcv_conv2d_statsfold_ok)
+    return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st, epi, dil, xacc);
   if (fuse) {                                     // the fused store loop lives in the LDS-DMA kernels: never fall back to the staged ones
     if (!small) return MDCV_EARG;
     const int keep = g_conv_variant;
@@ -1984,24 +1983,7 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
                      KH, KW, stride, pad, dil, nullptr, stream);
 }
 
-// Forward conv with BatchNorm statistics whose partial rows are summed per group of G rows INSIDE the launch (stats_fold.h): the consumer
-// (mdcv_bn_act_fwd_statsfold) finishes the statistics in its prologue and no finalize launch runs between the two.
 int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, int in_ldc);
-int mdcv_conv2d_statsfold_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride, int pad,
-                             int dil, int in_ldc) {
-  return dtype == MDCV_BF16 && g_conv_variant < 0 && Hin == Hout && Win == Wout &&
-         mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc);
-}
-int mdcv_conv2d_statsfold(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const float* bias,
-                          float* stats_partial, float* super, void* counters, int G, int rows, int B, int Hin, int Win, int Cin, int Hout,
-                          int Wout, int Nout, int KH, int KW, int stride, int pad, int dil, void* stream) {
-  if (!stats_partial || !super || !counters || G < 2 || (G & 1) || rows < 1) return MDCV_EARG;
-  if (!mdcv_conv2d_statsfold_ok(dtype, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW, stride, pad, dil, in_ldc)) return MDCV_EARG;
-  if (rows != mdcv_conv2d_stats_rows_geom(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc)) return MDCV_EARG;
-  const StatsFoldArgs f{super, reinterpret_cast<unsigned*>(counters), G, rows};
-  return conv2d_impl(dtype, 0, in, in_ldc, w_packed, out, out_ldc, bias, nullptr, 0, stats_partial, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW,
-                     stride, pad, dil, nullptr, stream, nullptr, &f);
-}
 
 // Forward conv whose BatchNorm statistics (per output channel: sum, sum of squares) are ADDED to exact accumulators (exact_acc.h:
 // [reps][3][2][Nout] 64-bit words, zero before the launch; mdcv_xstats_words) instead of written as partial rows.  Every forward kernel takes
@@ -2012,7 +1994,7 @@ int mdcv_conv2d_xstats(int dtype, const void* in, int in_ldc, const void* w_pack
                        void* stream) {
   const XAccArgs x{reinterpret_cast<long long*>(xacc), reps};
   return conv2d_impl(dtype, 0, in, in_ldc, w_packed, out, out_ldc, bias, nullptr, 0, nullptr, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW,
-                     stride, pad, dil, nullptr, stream, nullptr, nullptr, &x);
+                     stride, pad, dil, nullptr, stream, nullptr, &x);
 }
 
 // Data gradient (mode 1 of mdcv_conv2d, same geometry arguments) that ALSO writes the BatchNorm-backward partial sums of the
@@ -2061,32 +2043,17 @@ int mdcv_conv2d_dgrad_bnsums(int dtype, const void* in, int in_ldc, const void* 
   BnFuseArgs f;
   f.y = y; f.scale = scale; f.shift = shift; f.mean = mean; f.partial = partial; f.ldy = ldy; f.act = act; f.row_base = 0;
   f.slope = act == 2 ? 0.f : slope;
-  f.store_g = 0;
   return conv2d_impl(dtype, 1, in, in_ldc, w_packed, out, out_ldc, nullptr, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Hout, Wout, Nout,
                      KH, KW, stride, pad, dil, &f, stream);
 }
 
-// The same launch storing g = dz * act'(scale * y + shift) in place of dz (the BatchNorm-backward sums are those of g either way).  Only the
-// stride-2 form of the shift kernel carries it (mdcv_conv2d_dgrad_masked_ok); the consumer is a first layer whose weight gradient is then
-// assembled from three correlations with the layer input without a BatchNorm-apply pass (mdcv_first_layer_wgrad_combine).
-int mdcv_conv2d_dgrad_masked_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
-                                int pad, int dil, int in_ldc) {
+// 1 when the data gradient of this geometry runs as the stride-2 form of the 3x3 shift kernel (conv_shift.hip MODE 3: whole output rows from LDS,
+// one partial row of fused sums per 8 x 31 tile): the plan fuses the BatchNorm-backward sums into it at every size.
+int mdcv_conv2d_dgrad_s2_form_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
+                                 int pad, int dil, int in_ldc) {
   return dtype == MDCV_BF16 && stride == 2 && dil == 1 && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win &&
          g_conv_variant < 0 && (long long)B * Hin * Win * in_ldc * 2 < (1LL << 31) &&
          mdcv_shift_s2_dgrad_eligible(dtype, B, Hin, Win, Cin, Nout, in_ldc);
-}
-int mdcv_conv2d_dgrad_bnsums_masked(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const void* addsrc,
-                                    int add_ldc, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
-                                    int pad, int dil, const void* y, int ldy, const float* scale, const float* shift, const float* mean,
-                                    int act, float slope, float* partial, void* stream) {
-  if (!y || !scale || !shift || !mean || !partial || (ldy & 7)) return MDCV_EARG;
-  if (!mdcv_conv2d_dgrad_masked_ok(dtype, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW, stride, pad, dil, in_ldc)) return MDCV_EARG;
-  BnFuseArgs f;
-  f.y = y; f.scale = scale; f.shift = shift; f.mean = mean; f.partial = partial; f.ldy = ldy; f.act = act; f.row_base = 0;
-  f.slope = act == 2 ? 0.f : slope;
-  f.store_g = 1;
-  return conv2d_impl(dtype, 1, in, in_ldc, w_packed, out, out_ldc, nullptr, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Hout, Wout, Nout,
-                     KH, KW, stride, pad, dil, &f, stream);
 }
 
 // number of rows of the [rows][2][Nout] BatchNorm partial-statistics buffer mdcv_conv2d writes (one per 128 output pixels)

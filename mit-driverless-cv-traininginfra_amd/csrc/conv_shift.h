@@ -2,7 +2,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bn_fuse.h"
-#include "stats_fold.h"
 #include "exact_acc.h"
 
 struct ShiftArgs {
@@ -17,7 +16,6 @@ struct ShiftArgs {
   EpiArgs epi;                          // inference epilogue (oscale == NULL and act == 0: off)
   int t2d, tiles_x, tiles_y, TH;        // 2-D pixel tiles (wide images): TH rows x (Wq - 2) columns per tile, Wq = tile width incl. its halo columns
   int nchunks, wrow, nca;               // Cin/32 ; 9*Cin elements per weight row ; KiB-chunks per activation chunk
-  StatsFoldArgs fold;                   // forward statistics folded per row group (stats_fold.h; fold.super == NULL: off)
   XAccArgs xacc;                        // forward statistics added to exact accumulators instead of written as rows (exact_acc.h; acc == NULL: off)
 };
 
@@ -26,7 +24,7 @@ int mdcv_shift_stats_rows(int B, int H, int W, int dil = 1, int Nout = 128);    
 int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil = 1);  // partial rows of the forward statistics (depends on the tile plan)
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
                     int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st,
-                    const EpiArgs* epi = nullptr, int dil = 1, const StatsFoldArgs* fold = nullptr, const XAccArgs* xacc = nullptr);
+                    const EpiArgs* epi = nullptr, int dil = 1, const XAccArgs* xacc = nullptr);
 void mdcv_shift_set_ring(int ring);
 int mdcv_shift_s2_rows(int B, int H, int W);   // partial rows of mode 3's fused BatchNorm-backward sums (H, W = dY's)
 bool mdcv_shift_s2_dgrad_eligible(int dtype, int B, int H, int W, int Cin, int Nout, long long in_ldc);   // mode 3 of mdcv_shift_conv: H, W = dY's

@@ -49,8 +49,6 @@ int g_shift_loop = 2;   // K-loop form of the FORWARD launches (set_variant(-30 
                         // DMAs) ; 2 (default) ping-pong for grids of at most one workgroup per CU, where no second workgroup fills the
                         // read phase (13^2 512->1024 forward 52.5 -> 48.9 us), and 384-row ping-pong tiles where they make ONE round of
                         // 193..256 workgroups (26^2 256->512 forward 44.6 -> 42.4 us).  Denser grids: +1..2 % alone, data gradients -5..+3 %.
-int g_shift_c8 = 0;   // 8-channel inputs (YOLOv3's first layer: 3 -> 8 padded channels) as one quarter-filled 32-channel chunk: correct (tested) and
-                      // SLOWER than the im2col kernel, 240 vs 159 us at 416^2 (4x the MFMAs, 23 296 tiles of 9 K steps): off (set_variant(-61) off / (-62) on)
 int g_shift_2d = 1;   // images wider than the 1-D stream takes (below) run as 2-D pixel tiles of 8 x 30 outputs (set_variant(-27) off / (-28) on)
 int g_shift_big = 0;   // A/B: 384 forces the 384-row ping-pong tiles on every forward launch they fit
 int g_shift_n64_wide = 1;   // data gradients with few positions and > 64 channels on 256 x 64 tiles (see mdcv_shift_launch_dgrad)
@@ -66,7 +64,6 @@ extern int g_shift_plan, g_shift_n64_wide;
 extern int g_shift_loop;
 extern int g_shift_big;
 extern int g_shift_2d;
-extern int g_shift_c8;
 #endif
 int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes);   // defined by part 1
 
@@ -421,8 +418,7 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
             if constexpr (FUSE) ET<bf16_t>::unpack(d, x);   // the sums see dz as stored
           }
           if constexpr (FUSE) {
-            if (a.fuse.store_g) d = fz3.add_store_g(a.fuse, x, yq[k]);      // the first layer's backward: g = dz * act' goes to HBM, dz does not
-            else fz3.add(a.fuse, x, yq[k]);
+            fz3.add(a.fuse, x, yq[k]);
           }
           *reinterpret_cast<uint4*>(out3 + pixv[k] * a.out_ldc + n) = d;
         }
@@ -529,7 +525,6 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
       }
   __syncthreads();
   constexpr int GR = (BM == 128 || BM == 256) ? 128 : BM;   // stream positions per partial-statistics row (192- / 384-row tiles: one row per tile)
-  constexpr bool kFold = MODE == 0 && !FUSE && !EPI;         // forward launches with statistics: the rows may be folded per group inside the launch (stats_fold.h)
   constexpr int G = BM / GR, WPG = WM / G;                 // rows per tile; waves (in M) per row
   if (want_stats && tid < BN * G) {
     const int g = tid / BN, col = tid - g * BN;
@@ -544,9 +539,6 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
           long long* xp = a.xacc.acc + (size_t)(srow & (size_t)(a.xacc.reps - 1)) * (XACC_DIGITS * 2) * a.Nout + n;
           xacc_add(xp, 2 * (size_t)a.Nout, s);
           xacc_add(xp + a.Nout, 2 * (size_t)a.Nout, qq);
-        } else if (kFold && a.fold.super) {                        // write-through: another workgroup may sum these rows inside this launch (stats_fold.h)
-          sf_store(a.stats + (srow * 2 + 0) * a.Nout + n, s);
-          sf_store(a.stats + (srow * 2 + 1) * a.Nout + n, qq);
         } else {
           a.stats[(srow * 2 + 0) * a.Nout + n] = s;         // (an unguarded second row of the last 256-row tile wrote 2*Nout floats past
           a.stats[(srow * 2 + 1) * a.Nout + n] = qq;        //  the buffer whenever ceil(Mq/128) was odd, e.g. batch 32 at 52/26/13)
@@ -572,16 +564,6 @@ __global__ __launch_bounds__(WM * WN * 64) void mdcv_conv3x3_shift_kernel(ShiftA
           d = ET<bf16_t>::pack(x);
         }
         *reinterpret_cast<uint4*>(out + ((size_t)pix * a.out_ldc + n)) = d;
-      }
-    }
-    if constexpr (kFold) {
-      if (a.stats && a.fold.super) {                        // (uniform) behind the store loop, so that the write-through of the rows and the counter's
-        const int srow0 = p0 / GR;                          // round trip cost this workgroup nothing while it still has stores to issue
-        int nr = 0;
-#pragma unroll
-        for (int g = 0; g < G; ++g) nr += (size_t)(srow0 + g) * GR < (size_t)a.Mq;
-        const int grp = sf_arrive(a.fold, srow0, nr, tile_n, a.tiles_n, reinterpret_cast<volatile int*>(smem + STAT_OFF), tid);
-        if (grp >= 0) sf_fold<NW * 64>(a.fold, a.stats, grp, tile_n * BN, BN, a.Nout, tid, reinterpret_cast<float*>(smem));   // this tile completed its row group
       }
     }
   } else {
@@ -814,7 +796,7 @@ bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int 
   // dilation 2 pays where the halo-heavy chunk is amortised over >= 2 channel chunks and two workgroups still fit a CU (narrow tiles):
   // RektNet data gradient 128->64 412 -> 332 us, 64->32 193 -> 183 us; forward 64->128 (128-wide tile, one workgroup per CU) 281 -> 360 us
   if (dil == 2 && g_shift_dil2 == 1 && !(Nout <= 64 && Cin >= 64)) return false;
-  if (((Cin & 31) && !(Cin == 8 && g_shift_c8 && dil == 1)) || ((Nout & 127) && !(Nout == 64 && g_shift_n64) && !(Nout == 32 && g_shift_n64 == 2))) return false;   // 128-wide tiles, or one 64-wide tile column
+  if ((Cin & 31) || ((Nout & 127) && !(Nout == 64 && g_shift_n64) && !(Nout == 32 && g_shift_n64 == 2))) return false;   // 128-wide tiles, or one 64-wide tile column
   if (H < 8 || W < 8) return false;
   if (!shift_fits_1d(W, Nout) && !(g_shift_2d && dil == 1)) return false;   // wider rows: 2-D pixel tiles (dilation 1 only), or not at all
   if ((long long)B * (H + dil) * (W + dil) + 1024 >= (1LL << 30) || shift_2d_positions(B, H, W) >= (1LL << 30)) return false;
@@ -849,12 +831,10 @@ int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil) {
 
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
                     int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st,
-                    const EpiArgs* epi, int dil, const StatsFoldArgs* fold, const XAccArgs* xacc) {
+                    const EpiArgs* epi, int dil, const XAccArgs* xacc) {
   ShiftArgs a;
   a.xacc = XAccArgs{nullptr, 1};
-  if (xacc) { if (mode != 0 || stats || epi || fold || !xacc->acc || xacc->reps < 1 || (xacc->reps & (xacc->reps - 1))) return MDCV_EARG; a.xacc = *xacc; }
-  if (fold && mode == 0 && stats && !epi) a.fold = *fold; else a.fold = StatsFoldArgs{nullptr, nullptr, 0, 0};
-  if (fold && !a.fold.super) return MDCV_EARG;
+  if (xacc) { if (mode != 0 || stats || epi || !xacc->acc || xacc->reps < 1 || (xacc->reps & (xacc->reps - 1))) return MDCV_EARG; a.xacc = *xacc; }
   if (fuse) a.fuse = *fuse; else a.fuse = BnFuseArgs{};
   if (epi) a.epi = *epi; else a.epi = EpiArgs{nullptr, 0, 0.f};
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addsrc = addsrc; a.stats = stats;
@@ -884,7 +864,7 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   return launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring == 63 || ring == 64) { g_shift_n64_wide = ring - 63; return; } if (ring == 61 || ring == 62) { g_shift_c8 = ring - 61; return; } if (ring == 29 || ring == 60) { g_shift_s2 = ring == 60; return; } if (ring == 27 || ring == 28) { g_shift_2d = ring - 27; return; } if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
+void mdcv_shift_set_ring(int ring) { if (ring == 63 || ring == 64) { g_shift_n64_wide = ring - 63; return; } if (ring == 29 || ring == 60) { g_shift_s2 = ring == 60; return; } if (ring == 27 || ring == 28) { g_shift_2d = ring - 27; return; } if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

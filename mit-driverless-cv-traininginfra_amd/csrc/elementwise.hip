@@ -236,103 +236,6 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs a) {
   }
 }
 
-// The same pass with the statistics finalize in its prologue (stats_fold.h): every workgroup sums the layer's few super rows
-// [ngroups][2][C] and forms scale / shift for all C channels in LDS -- the arithmetic of bn_colfinal_kernel<0>, redundantly per workgroup, no
-// hand-off; workgroup 0 also publishes scale / shift / mean / invstd for the backward and updates the running statistics.
-struct BnFoldArgs {
-  const float* super; int ngroups; double count;
-  const float* gamma; const float* beta; float* rm; float* rv; float momentum, eps;
-  float* scale; float* shift; float* mean; float* invstd;
-};
-// NCH = channels per thread of the prologue (C <= 256 * NCH); ngroups * NCH <= 16, so a thread's 2 * ngroups * NCH super-row values are all in
-// flight at once (one memory round trip), and the first strip of y is requested BEFORE the statistics arithmetic and the barrier.
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void bn_act_fwd_fold_kernel(BnActArgs a, BnFoldArgs f) {
-  constexpr int VEC = ET<T>::VEC;
-  constexpr int NG = 16 / NCH;
-  __shared__ float cs[1024], cb[1024];
-  const int tid = threadIdx.x;
-  float u0[NCH][NG], u1[NCH][NG];
-#pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    const int c = tid + 256 * k;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const bool ok = c < a.C && g < f.ngroups;
-      u0[k][g] = ok ? f.super[((size_t)g * 2 + 0) * a.C + c] : 0.f;
-      u1[k][g] = ok ? f.super[((size_t)g * 2 + 1) * a.C + c] : 0.f;
-    }
-  }
-  const bool active = tid < a.PPI * a.CV;
-  const int cv = active ? tid % a.CV : 0, pi = active ? tid / a.CV : 0;
-  const long long p0 = (long long)blockIdx.x * a.PB;
-  const long long p1 = min((long long)a.M, p0 + a.PB);
-  const T* y1 = reinterpret_cast<const T*>(a.y1);
-  const T* rs = reinterpret_cast<const T*>(a.resid);
-  T* out = reinterpret_cast<T*>(a.out);
-  uint4 q1[4], qr[4];
-  long long pb = p0 + pi;
-  auto request = [&]() {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long long p = pb + (long long)u * a.PPI;
-      if (active && p < p1) {
-        q1[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
-        if (rs) qr[u] = *reinterpret_cast<const uint4*>(rs + p * a.ldr + cv * VEC);
-      }
-    }
-  };
-  request();
-#pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    const int c = tid + 256 * k;
-    if (c < a.C) {
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-      for (int g = 0; g < NG; ++g) { s0 += (double)u0[k][g]; s1 += (double)u1[k][g]; }
-      const double mean = s0 / f.count;
-      double var = s1 / f.count - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
-      const float g = f.gamma[c], b = f.beta[c];
-      const float sc = g * invstd, sh = b - (float)mean * g * invstd;
-      cs[c] = sc; cb[c] = sh;
-      if (blockIdx.x == 0) {
-        f.scale[c] = sc; f.shift[c] = sh; f.mean[c] = (float)mean; f.invstd[c] = invstd;
-        if (f.rm) {
-          const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
-          f.rm[c] = (1.f - f.momentum) * f.rm[c] + f.momentum * (float)mean;
-          f.rv[c] = (1.f - f.momentum) * f.rv[c] + f.momentum * (float)unbiased;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (!active) return;
-  float s1[VEC], b1[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) { s1[e] = cs[cv * VEC + e]; b1[e] = cb[cv * VEC + e]; }
-  for (; pb < p1; pb += 4 * a.PPI) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long long p = pb + (long long)u * a.PPI;
-      if (p >= p1) break;
-      float v[VEC], w[VEC];
-      ET<T>::unpack(q1[u], v);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = act_fwd(v[e] * s1[e] + b1[e], a.act, a.slope);
-      if (rs) {
-        ET<T>::unpack(qr[u], w);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] += w[e];
-      }
-      *reinterpret_cast<uint4*>(out + p * a.ldo + cv * VEC) = ET<T>::pack(v);
-    }
-    pb += 4 * a.PPI;
-    if (pb < p1) request();
-    pb -= 4 * a.PPI;
-  }
-}
 
 // The same pass with the statistics read from exact accumulators (exact_acc.h): the conv ADDED its per-tile sums to [reps][3][2][C] 64-bit
 // words with fire-and-forget integer atomics; every workgroup here adds the replicas (integers: exact, any order), converts and forms
@@ -404,16 +307,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       if (rsd) qr[u] = *reinterpret_cast<const uint4*>(rsd + p * a.ldr + cv * VEC);
     }
   }
+  // A non-finite partial sum poisoned the top digit of ITS replica (atomic max with INT64_MAX, exact_acc.h).  The poison is looked for per
+  // replica BEFORE the replicas are added: two poisoned words sum to -2, thirty-two to -32 -- finite garbage.  A poisoned
+  // channel keeps XACC_POISON through both additions and xacc_value turns it into NaN.
   long long t[NCH][6];
 #pragma unroll
-  for (int k = 0; k < NCH; ++k)
+  for (int k = 0; k < NCH; ++k) {
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < RPMAX; ++j) bad = bad || xacc_poisoned(w[k][j][4]) || xacc_poisoned(w[k][j][5]);
 #pragma unroll
     for (int e = 0; e < 6; ++e) {
       long long x = 0;
 #pragma unroll
-      for (int j = 0; j < RPMAX; ++j) x += w[k][j][e];
-      t[k][e] = x;
+      for (int j = 0; j < RPMAX; ++j) x += (e >= 4 && xacc_poisoned(w[k][j][e])) ? 0 : w[k][j][e];
+      t[k][e] = (e >= 4 && bad) ? XACC_POISON : x;
     }
+  }
   if constexpr (NCH == 1) {
     if (f.Cp < 256) {                                                  // (uniform) the replica groups meet
 #pragma unroll
@@ -421,12 +331,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       __syncthreads();
       if (g == 0) {
         const int ng = 256 / f.Cp;
+        bool bad = false;
 #pragma unroll
         for (int e = 0; e < 6; ++e) {
           long long x = 0;
-          for (int gg = 0; gg < ng; ++gg) x += sd[e * 256 + gg * f.Cp + cl];
+          for (int gg = 0; gg < ng; ++gg) {
+            const long long v = sd[e * 256 + gg * f.Cp + cl];
+            if (e >= 4 && xacc_poisoned(v)) bad = true; else x += v;
+          }
           t[0][e] = x;
         }
+        if (bad) { t[0][4] = XACC_POISON; t[0][5] = XACC_POISON; }
       }
     }
   }
@@ -1121,7 +1036,7 @@ int mdcv_bn_stats_finalize(const float* partial, int rows, double* accum, double
 // BatchNorm(batch statistics) + activation (+ residual) with the statistics taken from the exact accumulators mdcv_conv2d_xstats /
 // mdcv_pw_conv_fwd_xstats added to (`count` positions; [reps][3][2][C] words).  Writes scale / shift / mean / invstd and updates the running
 // statistics as mdcv_bn_stats_finalize does.  C <= 1024.  mdcv_xstats_reps: the replica count to use for a layer with `rows` additions per word.
-extern int g_fold_blocks;
+constexpr int kXaccBlocks = 512;      // fewer, longer strips than mdcv_bn_act_fwd: every workgroup pays the prologue
 int mdcv_xstats_reps(int rows, int C) {
   int cp = 32; while (cp < C && cp < 256) cp <<= 1;
   const int cap = C <= 256 ? 1024 / cp : (C <= 512 ? 2 : 1);
@@ -1144,7 +1059,7 @@ int mdcv_bn_act_fwd_xstats(int dtype, const void* y, int ldy, const void* xacc, 
     f.Cp = cp; f.rp = reps / (256 / cp) > 0 ? reps / (256 / cp) : 1;
   }
   if (nch * f.rp > 4) return MDCV_EARG;                    // (the prologue keeps a thread's words in registers: mdcv_xstats_reps stays inside)
-  const Strip s = dtype == MDCV_BF16 ? make_strip<bf16_t>(M, C, g_fold_blocks, 4) : make_strip<float>(M, C, g_fold_blocks, 4);
+  const Strip s = dtype == MDCV_BF16 ? make_strip<bf16_t>(M, C, kXaccBlocks, 4) : make_strip<float>(M, C, kXaccBlocks, 4);
   if (s.CV > 256) return MDCV_EARG;
   a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
   const dim3 grid((unsigned)cdiv(M, s.PB) + 1);             // + the publishing workgroup
@@ -1195,34 +1110,6 @@ int mdcv_bn_act_fwd(int dtype, const void* y1, int ld1, const float* s1, const f
     a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
     MDCV_LAUNCH(bn_act_fwd_kernel<float>, dim3((unsigned)cdiv(M, s.PB)), dim3(256), 0, st, a);
   } else return MDCV_EARG;
-  MDCV_CHECK_LAUNCH();
-  return MDCV_OK;
-}
-
-// BatchNorm(batch statistics) + activation (+ residual) with the statistics finalize in the prologue: `super` = the [ngroups][2][C] group sums
-// mdcv_conv2d_statsfold left (sum, sum of squares over `count` positions).  Writes scale / shift / mean / invstd and updates the running
-// statistics exactly as mdcv_bn_stats_finalize does.  bf16, C <= 1024.
-int g_fold_blocks = 512;
-int mdcv_bn_act_fwd_statsfold_blocks(int n) { g_fold_blocks = n > 0 ? n : 512; return 0; }   /* tuning hook */
-int mdcv_bn_act_fwd_statsfold(int dtype, const void* y, int ldy, const float* super, int ngroups, double count, const float* gamma,
-                              const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* scale,
-                              float* shift, float* mean, float* invstd, const void* resid, int ldr, void* out, int ldo, int M, int C,
-                              int act, float slope, void* stream) {
-  if (dtype != MDCV_BF16 || !y || !out || !super || !gamma || !beta || !scale || !shift || !mean || !invstd || ngroups < 1 || ngroups > 16 ||
-      (C & 7) || C > 1024 || (ldy & 7) || (ldo & 7))
-    return MDCV_EARG;
-  BnActArgs a;
-  a.y1 = y; a.y2 = nullptr; a.resid = resid; a.out = out; a.s1 = nullptr; a.b1 = nullptr; a.s2 = nullptr; a.b2 = nullptr;
-  a.ld1 = ldy; a.ld2 = 0; a.ldr = ldr; a.ldo = ldo; a.M = M; a.C = C; a.act = act; a.slope = act == 2 ? 0.f : slope;
-  BnFoldArgs f{super, ngroups, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd};
-  Strip s = make_strip<bf16_t>(M, C, g_fold_blocks, 4); if (s.CV > 256) return MDCV_EARG;   // fewer, longer strips than mdcv_bn_act_fwd: every workgroup pays the prologue
-  a.PB = s.PB; a.CV = s.CV; a.PPI = s.PPI;
-  const dim3 grid((unsigned)cdiv(M, s.PB));
-  const int nch = (C + 255) / 256 <= 1 ? 1 : ((C + 255) / 256 <= 2 ? 2 : 4);
-  if (ngroups * nch > 16) return MDCV_EARG;                 // (the prologue keeps a thread's super-row values in registers)
-  if (nch == 1) MDCV_LAUNCH((bn_act_fwd_fold_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, a, f);
-  else if (nch == 2) MDCV_LAUNCH((bn_act_fwd_fold_kernel<bf16_t, 2>), grid, dim3(256), 0, (hipStream_t)stream, a, f);
-  else MDCV_LAUNCH((bn_act_fwd_fold_kernel<bf16_t, 4>), grid, dim3(256), 0, (hipStream_t)stream, a, f);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

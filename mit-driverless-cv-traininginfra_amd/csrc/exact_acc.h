@@ -2,7 +2,7 @@
 //
 // A conv kernel used to write one partial row [2][Nout] (sum, sum of squares) per 128 output positions and mdcv_bn_stats_finalize summed the
 // rows in a launch of its own between the conv and the BatchNorm-apply pass: a 6 us kernel that costs 10-12 us of critical path, 72 times per
-// YOLOv3 forward (what-if timing).  An in-launch fold of the rows (stats_fold.h) paid the same as a hand-off.  Here the
+// YOLOv3 forward (what-if timing).  An in-launch fold of the rows (round 4, removed) paid the same as a hand-off.  Here the
 // epilogue ADDS its partial sums to a per-layer accumulator with fire-and-forget agent-scope integer atomics: nobody waits, nobody polls, and
 // the consumer kernel (after the kernel boundary) reads the totals in its prologue.
 //
@@ -51,8 +51,13 @@ __device__ __forceinline__ void xacc_add(long long* p, size_t ds, float v) {
   if (hi) __hip_atomic_fetch_add(p + (size_t)(k + 1) * ds, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (k + 1 <= 2: s <= 95 keeps w >> 40 inside digit 2 when k == 2 -> hi == 0 there)
 }
 
-// the digits of one element (already summed over the replicas) -> double
+// A top-digit word of ONE replica that a non-finite value poisoned.  Consumers must look at every replica's word with this BEFORE adding
+// the replicas (INT64_MAX + INT64_MAX wraps to -2: a finite-looking sum) and carry XACC_POISON instead of the sum.
+#define XACC_POISON 0x7fffffffffffffffLL
+__device__ __forceinline__ bool xacc_poisoned(long long d2) { return d2 > (1LL << 60) || d2 < -(1LL << 60); }
+
+// the digits of one element (replicas added by the caller, poison carried as XACC_POISON) -> double
 __device__ __forceinline__ double xacc_value(long long d0, long long d1, long long d2) {
-  if (d2 > (1LL << 60) || d2 < -(1LL << 60)) return __builtin_nan("");
+  if (xacc_poisoned(d2)) return __builtin_nan("");
   return (double)d0 * 0x1p-70 + (double)d1 * 0x1p-30 + (double)d2 * 0x1p10;
 }

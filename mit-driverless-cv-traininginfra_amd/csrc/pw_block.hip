@@ -6,9 +6,11 @@
 // element exactly once per output-channel tile:
 //
 //   forward   z = act(y * scale + shift) (+ resid)   ;   y_out = z . W^T       (bn_act_fwd + mdcv_conv2d 1x1   -> ONE launch)
-//   backward  dy = cA*g + cB*y + cC, g = dz*act'(.)  ;   dx = dy . W (+ addsrc) (bn_act_bwd_apply + 1x1 data gradient -> ONE launch)
 //
-// z / dy are still written to HBM (the shortcut, routes, the weight gradient and the BatchNorm backward read them), but they are not read
+// (Round 4 also built the backward counterpart -- bn_act_bwd_apply + 1x1 data gradient in one launch -- and measured it level at 52^2 and
+// slower elsewhere; round 5 removed it: the 1x1 backward is csrc/pw_bwd.hip now.)
+//
+// z is still written to HBM (the shortcut, routes, the weight gradient and the BatchNorm backward read it), but it is not read
 // back by the 1x1 conv: a workgroup builds its [BMP pixels x K channels] operand tile ONCE in LDS (global -> registers -> transform ->
 // LDS, all loads of the tile in flight together), keeps it resident, and streams only the weight tiles (LDS-DMA ring) through the K loop
 // for every 128-wide slice of output channels.  Per 1x1 layer this removes one launch, one dependent launch boundary and one full read
@@ -18,8 +20,9 @@
 // (slot q of row r holds logical k-vector q ^ swz(r)), so the MFMA fragment reads are the conflict-free ds_read_b128 pattern of
 // conv_shift.hip.  Weight tiles [128 n][32 k] arrive lane-linear by buffer_load ... lds with the swizzle on the source address.
 #include "common.h"
-#include "bn_fuse.h"
 #include "pw_block.h"
+
+#include <mutex>
 
 namespace {
 
@@ -31,7 +34,6 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 2; }
 __device__ __forceinline__ float act_fwd(float v, int act, float slope) { return act == 0 ? v : (v > 0.f ? v : v * slope); }
-__device__ __forceinline__ float act_grad(float pre, int act, float slope) { return act == 0 ? 1.f : (pre > 0.f ? 1.f : slope); }
 
 __device__ __forceinline__ void ld8(const float* __restrict__ p, int c0, int C, float (&o)[8], float dflt) {
 #pragma unroll
@@ -43,13 +45,12 @@ __device__ __forceinline__ void ld8(const float* __restrict__ p, int c0, int C, 
 // swizzled image, to LDS buffer (i+1)&1.  Waves 0..3 CONSUME tile i: each owns FNW*16 output channels of the current slice, gets ITS
 // weight rows either once (WRES: the layer's whole weight matrix stays in LDS for the life of the workgroup -- K*N*2 <= 64 KiB, the 52^2
 // and larger layers) or through a private LDS-DMA ring (own vmcnt, no barrier in the K loop), multiplies them with the resident operand
-// tile, and runs a wave-local epilogue (statistics / fused BatchNorm-backward sums / 16-byte stores).  The two halves meet once per pixel
+// tile, and runs a wave-local epilogue (statistics / 16-byte stores).  The two halves meet once per pixel
 // tile.  vmcnt is per wave, so the producers' long HBM loads and the consumers' counted DMA waits do not see each other -- in one
 // instruction stream a wait for a young DMA would drain the older prefetch loads; with WRES the consumers' K loop has no memory wait at
-// all, so the epilogue's own loads (addsrc, y of the fused sums) are issued BEFORE the K loop and land under it.
-// MODE 0: forward (operand = BatchNorm-apply + activation (+ residual) of y, written out as z; epilogue: bias, BatchNorm partial statistics)
-// MODE 1: data gradient (operand = BatchNorm-backward apply of (dz, y), written out as dy; epilogue: + addsrc, fused BatchNorm-backward sums)
-template <int BMP, int FNW, int MODE, bool FUSE, int NV, bool HASR, bool WRES>
+// all.
+// Operand = BatchNorm-apply + activation (+ residual) of y, written out as z; epilogue: bias, BatchNorm partial statistics.
+template <int BMP, int FNW, int NV, bool HASR, bool WRES>
 __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
   constexpr int FM = BMP / 16, FN = FNW;
   constexpr int NCH = NCW * FNW * 16;                   // output channels per slice (128 or 256)
@@ -80,9 +81,8 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
     bf16_t* __restrict__ tout = reinterpret_cast<bf16_t*>(a.tout);
     constexpr int UN = NV / 2;                             // 16-byte vectors per producer thread and HALF tile (NV = BMP * K / 2048 per tile)
     static_assert(NV >= 2 && NV % 2 == 0, "the producers pipeline over half tiles");
-    float s1[8], b1[8], A1[8], B1[8], C1[8];
+    float s1[8], b1[8];
     ld8(a.scale, c0, K, s1, 1.f); ld8(a.scale ? a.shift : nullptr, c0, K, b1, 0.f);
-    if constexpr (MODE == 1) { ld8(a.cA, c0, K, A1, 0.f); ld8(a.cB, c0, K, B1, 0.f); ld8(a.cC, c0, K, C1, 0.f); }
     const int mytiles = (ntiles - first + stride - 1) / stride, nitems = 2 * mytiles;
     // item j of this workgroup = half (j & 1) of its tile (j >> 1); loads past the last item are clamped to it (never used)
 #define PW_LOAD(Q0, Q1, ITEM)                                                                                             \
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
       long long p = p0__ + prow + u * pstep;                                                                            \
       p = p < a.M ? p : (long long)a.M - 1;                                                                             \
       Q0[u] = *reinterpret_cast<const uint4*>(src0 + p * a.ld0 + c0);                                                   \
-      if constexpr (MODE == 1 || HASR) Q1[u] = *reinterpret_cast<const uint4*>(src1 + p * a.ld1 + c0);                  \
+      if constexpr (HASR) Q1[u] = *reinterpret_cast<const uint4*>(src1 + p * a.ld1 + c0);                               \
     }                                                                                                                   \
   } while (0)
 #define PW_EMIT(Q0, Q1, ITEM)                                                                                             \
@@ -108,19 +108,10 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
       if (p < a.M) {                                                                                                    \
         float v[8], w[8];                                                                                               \
         ET<bf16_t>::unpack(Q0[u], v);                                                                                   \
-        if constexpr (MODE == 0) {                                                                                      \
-          _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e] * s1[e] + b1[e], a.act, a.slope);           \
-          if constexpr (HASR) {                                                                                         \
-            ET<bf16_t>::unpack(Q1[u], w);                                                                               \
-            _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] += w[e];                                                 \
-          }                                                                                                             \
-        } else {                                                                                                        \
-          ET<bf16_t>::unpack(Q1[u], w);                      /* v = dz, w = y */                                         \
-          _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                               \
-            const float pre = w[e] * s1[e] + b1[e];                                                                     \
-            const float g = v[e] * act_grad(pre, a.act, a.slope);                                                       \
-            v[e] = A1[e] * g + B1[e] * w[e] + C1[e];                                                                    \
-          }                                                                                                             \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] = act_fwd(v[e] * s1[e] + b1[e], a.act, a.slope);             \
+        if constexpr (HASR) {                                                                                           \
+          ET<bf16_t>::unpack(Q1[u], w);                                                                                 \
+          _Pragma("unroll") for (int e = 0; e < 8; ++e) v[e] += w[e];                                                   \
         }                                                                                                               \
         o = ET<bf16_t>::pack(v);                                                                                        \
         if (tout) *reinterpret_cast<uint4*>(tout + p * a.ldt + c0) = o;                                                 \
@@ -186,8 +177,6 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
   const int offB = r16 * 64 + ((q ^ swz(r16)) << 4);
   unsigned char* const stg = smem + STAGE + cw * (BMP * SROWW);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
-  const bf16_t* __restrict__ addsrc = reinterpret_cast<const bf16_t*>(a.addsrc);
-  const bf16_t* __restrict__ fy = reinterpret_cast<const bf16_t*>(a.fuse.y);
   constexpr int RPP = 64 / VPW;                               // rows per pass of the wave's store loop
   constexpr int PASSES = BMP / RPP;
   const int cvv = lane % VPW, rl = lane / VPW;
@@ -200,23 +189,6 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
     for (int ch = 0; ch < nchunks; ++ch) {
       const int nw0 = ch * NCH + cw * FNW * 16;
       const int n = nw0 + cvv * 8;
-      // the epilogue's global operands: with WRES nothing in the K loop waits on vmcnt, so they are fetched under it
-      long long pv[PASSES]; uint4 aq[PASSES], yq[PASSES];
-      if constexpr (MODE == 1) {
-#pragma unroll
-        for (int u = 0; u < PASSES; ++u) {
-          const long long p = p0 + u * RPP + rl;
-          pv[u] = (p < a.M && n < a.N) ? p : -1;
-        }
-        if constexpr (WRES) {
-#pragma unroll
-          for (int u = 0; u < PASSES; ++u) {
-            const long long pc = pv[u] >= 0 ? pv[u] : 0;
-            if (addsrc) aq[u] = *reinterpret_cast<const uint4*>(addsrc + pc * a.add_ldc + (n < a.N ? n : 0));
-            if constexpr (FUSE) yq[u] = *reinterpret_cast<const uint4*>(fy + pc * a.fuse.ldy + (n < a.N ? n : 0));
-          }
-        }
-      }
       f32x4_t acc[FM][FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -262,7 +234,7 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
             for (int rr = 0; rr < 4; ++rr) acc[i][j][rr] += bv;
         }
       }
-      if constexpr (MODE == 0) {
+      {
         if (a.stats || a.xacc.acc) {
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
@@ -303,72 +275,12 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
             reinterpret_cast<bf16_t*>(stg + (row + 1) * SROWW)[col] = (bf16_t)(pk >> 16);
           }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the wave's own staging writes (LDS serves one wave's requests in order)
-      if constexpr (MODE == 0) {
 #pragma unroll
-        for (int u = 0; u < PASSES; ++u) {
-          const int row = u * RPP + rl;
-          const long long p = p0 + row;
-          if (p < a.M && n < a.N)
-            *reinterpret_cast<uint4*>(out + p * a.out_ldc + n) = *reinterpret_cast<const uint4*>(stg + row * SROWW + cvv * 16);
-        }
-      } else {
-        if constexpr (!WRES) {
-#pragma unroll
-          for (int u = 0; u < PASSES; ++u) {
-            if (pv[u] >= 0) {
-              if (addsrc) aq[u] = *reinterpret_cast<const uint4*>(addsrc + pv[u] * a.add_ldc + n);
-              if constexpr (FUSE) yq[u] = *reinterpret_cast<const uint4*>(fy + pv[u] * a.fuse.ldy + n);
-            }
-          }
-        }
-        // (fused) BatchNorm-backward sums of the producer layer: g = dz * act'(y*scale + shift); sum g, sum g*(y - mean)
-        float fs[8], fb2[8], fm[8], sg[8], sx[8];
-        if constexpr (FUSE) {
-          ld8(a.fuse.scale, n, a.N, fs, 0.f); ld8(a.fuse.shift, n, a.N, fb2, 0.f); ld8(a.fuse.mean, n, a.N, fm, 0.f);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { sg[e] = 0.f; sx[e] = 0.f; }
-        }
-#pragma unroll
-        for (int u = 0; u < PASSES; ++u) {
-          if (pv[u] >= 0) {
-            float x[8];
-            uint4 d = *reinterpret_cast<const uint4*>(stg + (u * RPP + rl) * SROWW + cvv * 16);
-            if (addsrc) {
-              float y[8];
-              ET<bf16_t>::unpack(d, x);
-              ET<bf16_t>::unpack(aq[u], y);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) x[e] += y[e];
-              d = ET<bf16_t>::pack(x);
-            }
-            *reinterpret_cast<uint4*>(out + pv[u] * a.out_ldc + n) = d;
-            if constexpr (FUSE) {
-              float yv[8];
-              ET<bf16_t>::unpack(d, x);                       // the sums see dz as stored
-              ET<bf16_t>::unpack(yq[u], yv);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float pre = yv[e] * fs[e] + fb2[e];
-                const float g = (a.fuse.act != 0 && !(pre > 0.f)) ? x[e] * a.fuse.slope : x[e];
-                sg[e] += g;
-                sx[e] += g * (yv[e] - fm[e]);
-              }
-            }
-          }
-        }
-        if constexpr (FUSE) {
-          // lanes that share a channel vector sit VPW apart
-#pragma unroll
-          for (int off = 32; off >= VPW; off >>= 1) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { sg[e] += __shfl_xor(sg[e], off, 64); sx[e] += __shfl_xor(sx[e], off, 64); }
-          }
-          if (lane < VPW && n < a.N) {
-            float* prow = a.fuse.partial + (size_t)(a.fuse.row_base + tile) * 2 * a.N;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { prow[n + e] = sg[e]; prow[a.N + n + e] = sx[e]; }
-          }
-        }
+      for (int u = 0; u < PASSES; ++u) {
+        const int row = u * RPP + rl;
+        const long long p = p0 + row;
+        if (p < a.M && n < a.N)
+          *reinterpret_cast<uint4*>(out + p * a.out_ldc + n) = *reinterpret_cast<const uint4*>(stg + row * SROWW + cvv * 16);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // staging reads done before the next slice's writes
     }
@@ -378,24 +290,33 @@ __global__ __launch_bounds__(NT) void pw_block_kernel(PwArgs a) {
 #undef ISSUE_B
 }
 
-template <int BMP, int FNW, int MODE, bool FUSE, int NV, bool HASR, bool WRES>
+template <int BMP, int FNW, int NV, bool HASR, bool WRES>
 int launch_pw3(PwArgs a, hipStream_t st) {
   const int tiles_m = (int)(((long long)a.M + BMP - 1) / BMP);
   const int nslot = WRES ? a.K / 32 : BRING;
   const int lds = 2 * BMP * a.K * 2 + NCW * nslot * FNW * 1024 + NCW * BMP * (FNW * 32 + 16);
-  static int attr_lds = 0;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return MDCV_EARG;
-    hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return MDCV_EARG;
-    ncu = pr.multiProcessorCount;
-  }
+  // per DEVICE: hipFuncSetAttribute applies to the function on the current device, and the CU count is that device's (a process
+  // that used a second GPU never got the attribute there)
+  static int attr_lds[64] = {};
+  static int ncus[64] = {};
+  static std::mutex mu;
+  int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MDCV_EARG;
   if (lds > 160 * 1024) return MDCV_EARG;
-  auto kern = pw_block_kernel<BMP, FNW, MODE, FUSE, NV, HASR, WRES>;
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_lds = lds;
+  auto kern = pw_block_kernel<BMP, FNW, NV, HASR, WRES>;
+  int ncu;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    if (!ncus[dev]) {
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) return MDCV_EARG;
+      ncus[dev] = n;
+    }
+    ncu = ncus[dev];
+    if (lds > attr_lds[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      attr_lds[dev] = lds;
+    }
   }
   const int grid = tiles_m < ncu ? tiles_m : ncu;               // persistent: one workgroup per CU walks tiles first, first + grid, ...
   MDCV_LAUNCH(kern, dim3((unsigned)grid), dim3(NT), lds, st, a);
@@ -406,33 +327,31 @@ int launch_pw3(PwArgs a, hipStream_t st) {
 int g_pw_bmp = 0;    // tuning hooks (mdcv_pw_set_variant): forced pixels per tile, 0 = heuristic
 int g_pw_wres = 1;   // weights resident in LDS where they fit
 
-template <int BMP, int FNW, int MODE, bool FUSE, int NV, bool HASR>
+template <int BMP, int FNW, int NV, bool HASR>
 int launch_pw2(PwArgs a, hipStream_t st) {
   const int nchunks = (a.N + NCW * FNW * 16 - 1) / (NCW * FNW * 16);
   const int lds_res = 2 * BMP * a.K * 2 + NCW * (a.K / 32) * FNW * 1024 + NCW * BMP * (FNW * 32 + 16);
-  if (g_pw_wres && nchunks == 1 && lds_res <= 160 * 1024) return launch_pw3<BMP, FNW, MODE, FUSE, NV, HASR, true>(a, st);
-  return launch_pw3<BMP, FNW, MODE, FUSE, NV, HASR, false>(a, st);
+  if (g_pw_wres && nchunks == 1 && lds_res <= 160 * 1024) return launch_pw3<BMP, FNW, NV, HASR, true>(a, st);
+  return launch_pw3<BMP, FNW, NV, HASR, false>(a, st);
 }
 
-template <int BMP, int FNW, int MODE, bool FUSE>
+template <int BMP, int FNW>
 int launch_pw(PwArgs a, hipStream_t st) {
   const int nv = BMP * a.K / 2048;                               // 16-byte vectors of a tile per producer thread
-  constexpr bool R1 = MODE == 1;
-  if (nv == 8) return (R1 || a.in1) ? launch_pw2<BMP, FNW, MODE, FUSE, 8, true>(a, st) : launch_pw2<BMP, FNW, MODE, FUSE, 8, R1>(a, st);
+  if (nv == 8) return a.in1 ? launch_pw2<BMP, FNW, 8, true>(a, st) : launch_pw2<BMP, FNW, 8, false>(a, st);
   if constexpr (BMP == 64) {                                       // (K = 128 / 64 operands come with 64-pixel tiles only)
-    if (nv == 4) return (R1 || a.in1) ? launch_pw2<BMP, FNW, MODE, FUSE, 4, true>(a, st) : launch_pw2<BMP, FNW, MODE, FUSE, 4, R1>(a, st);
-    if (nv == 2) return (R1 || a.in1) ? launch_pw2<BMP, FNW, MODE, FUSE, 2, true>(a, st) : launch_pw2<BMP, FNW, MODE, FUSE, 2, R1>(a, st);
+    if (nv == 4) return a.in1 ? launch_pw2<BMP, FNW, 4, true>(a, st) : launch_pw2<BMP, FNW, 4, false>(a, st);
+    if (nv == 2) return a.in1 ? launch_pw2<BMP, FNW, 2, true>(a, st) : launch_pw2<BMP, FNW, 2, false>(a, st);
   }
   return MDCV_EARG;
 }
 
-template <int MODE, bool FUSE>
 int dispatch_pw(PwArgs a, hipStream_t st) {
   const int bmp = mdcv_pw_tile_rows(a.K);
   const bool wide = a.N > 128;                                  // 256-channel slices (64 per consumer wave) when there are that many
-  if (bmp == 64) return wide ? launch_pw<64, 4, MODE, FUSE>(a, st) : launch_pw<64, 2, MODE, FUSE>(a, st);
-  if (bmp == 32) return wide ? launch_pw<32, 4, MODE, FUSE>(a, st) : launch_pw<32, 2, MODE, FUSE>(a, st);
-  return wide ? launch_pw<16, 4, MODE, FUSE>(a, st) : launch_pw<16, 2, MODE, FUSE>(a, st);
+  if (bmp == 64) return wide ? launch_pw<64, 4>(a, st) : launch_pw<64, 2>(a, st);
+  if (bmp == 32) return wide ? launch_pw<32, 4>(a, st) : launch_pw<32, 2>(a, st);
+  return wide ? launch_pw<16, 4>(a, st) : launch_pw<16, 2>(a, st);
 }
 
 }  // namespace
@@ -471,8 +390,7 @@ int mdcv_pw_conv_fwd(int dtype, const void* y, int ldy, const float* scale, cons
   a.scale = scale; a.shift = shift; a.act = act; a.slope = act == 2 ? 0.f : slope;   // (ReLU = slope 0, as mdcv_bn_act_fwd)
   a.w = w_packed; a.w_bytes = (unsigned)((long long)N * K * 2); a.bias = bias; a.out = out; a.out_ldc = out_ldc; a.stats = stats_partial;
   a.M = (int)M; a.K = K; a.N = N; a.ysplit = 1;
-  a.fuse = BnFuseArgs{};
-  return dispatch_pw<0, false>(a, (hipStream_t)stream);
+  return dispatch_pw(a, (hipStream_t)stream);
 }
 
 /* the same with the output's statistics added to exact accumulators (exact_acc.h; [reps][3][2][N] 64-bit words, zero before the launch) instead
@@ -489,32 +407,7 @@ int mdcv_pw_conv_fwd_xstats(int dtype, const void* y, int ldy, const float* scal
   a.w = w_packed; a.w_bytes = (unsigned)((long long)N * K * 2); a.bias = bias; a.out = out; a.out_ldc = out_ldc; a.stats = nullptr;
   a.xacc = XAccArgs{reinterpret_cast<long long*>(xacc), reps};
   a.M = (int)M; a.K = K; a.N = N; a.ysplit = 1;
-  a.fuse = BnFuseArgs{};
-  return dispatch_pw<0, false>(a, (hipStream_t)stream);
-}
-
-/* data gradient of a 1x1 conv -> BatchNorm -> activation layer from (dz, y): dy = cA*g + cB*y + cC (written to dy_out) ; dx = dy . W (+ addsrc);
- * fy != NULL: also the BatchNorm-backward partial sums of the layer that produced this conv's input ([mdcv_pw_rows][2][N]). */
-int mdcv_pw_conv_bwd(int dtype, const void* dz, int lddz, const void* y, int ldy, const float* scale, const float* shift, const float* cA,
-                     const float* cB, const float* cC, int act, float slope, void* dy_out, int lddy, const void* wd_packed, void* dx, int dx_ldc,
-                     const void* addsrc, int add_ldc, const void* fy, int ldfy, const float* fscale, const float* fshift, const float* fmean,
-                     int fact, float fslope, float* fpartial, long long M, int K, int N, void* stream) {
-  if (!dz || !y || !wd_packed || !dx || !scale || !shift || !cA || !cB || !cC) return MDCV_EARG;
-  if (!mdcv_pw_eligible(dtype, M, K, N, lddz, ldy, dy_out ? lddy : 8, dx_ldc) || (addsrc && (add_ldc & 7))) return MDCV_EARG;
-  PwArgs a{};
-  a.in0 = dz; a.ld0 = lddz; a.in1 = y; a.ld1 = ldy; a.tout = dy_out; a.ldt = lddy;
-  a.scale = scale; a.shift = shift; a.cA = cA; a.cB = cB; a.cC = cC; a.act = act; a.slope = act == 2 ? 0.f : slope;
-  a.w = wd_packed; a.w_bytes = (unsigned)((long long)N * K * 2); a.bias = nullptr; a.out = dx; a.out_ldc = dx_ldc;
-  a.addsrc = addsrc; a.add_ldc = add_ldc; a.stats = nullptr;
-  a.M = (int)M; a.K = K; a.N = N; a.ysplit = 1;
-  a.fuse = BnFuseArgs{};
-  if (fy) {
-    if (!fscale || !fshift || !fmean || !fpartial || (ldfy & 7)) return MDCV_EARG;
-    a.fuse.y = fy; a.fuse.ldy = ldfy; a.fuse.scale = fscale; a.fuse.shift = fshift; a.fuse.mean = fmean; a.fuse.partial = fpartial;
-    a.fuse.act = fact; a.fuse.slope = fact == 2 ? 0.f : fslope; a.fuse.row_base = 0;
-    return dispatch_pw<1, true>(a, (hipStream_t)stream);
-  }
-  return dispatch_pw<1, false>(a, (hipStream_t)stream);
+  return dispatch_pw(a, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -210,7 +210,7 @@ class Plan:
         self.on_ready = None               # set per backward by the data-parallel reducer
         self.dgrad_entries = {}            # grad buffer ptr -> backward-list entry of the data gradient that wrote it last
         self.fused_bn = 0                  # BatchNorm backward reductions folded into data-gradient store loops
-        self._fold_candidates, self._fold_arena, self.stats_folded = [], None, 0
+        self._fold_candidates = []
         self._xacc_arena, self.stats_xfolded = None, 0
 
     # ------------------------------------------------------------------ buffers
@@ -475,67 +475,14 @@ class Plan:
                   resid.ptr if resid is not None else None, resid.ldc if resid is not None else 0,
                   out.ptr, out.ldc, out.M, out.C, act, float(slope))
 
-    # ---- forward BatchNorm statistics without a finalize launch (csrc/stats_fold.h).  What-if timing of the YOLOv3 step without its 72
-    # mdcv_bn_stats_finalize launches (scripts/ab_step.py "Xbn_stats_finalize"): 13.79 -> 12.94 ms -- 6 us kernels, 12 us of critical path each.
-    # Built for the 3x3 shift kernel + mdcv_bn_act_fwd consumers (22 layers of YOLOv3), correct and bit-reproducible, and OFF: the hand-off
-    # costs what the launch cost.  Consumer alone (scripts/fold_ab.py): 13^2 x 1024 8.9 us against 14.8 for finalize + apply, 26^2 x 512 12.6 vs
-    # 15.7, 52^2 x 256 22.8 vs 19.8 (every workgroup re-derives all channels' coefficients); the producer's tail (drain of its stores, counter
-    # round trip, the completing workgroup's fold) takes the rest back: step 13.90 -> 13.99 ms (same-box A/B, "T0;T1").
-    stats_fold = False                 # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
-    stats_fold_counters = 1 << 16      # 32-bit words of the counter arena (zeroed by one memset at the head of the forward list)
-
     def note_stats_fold(self, conv, fin, act, cs, x, y, bs, partial, rows, out, act_code, slope, resid):
         """Remember one conv -> statistics finalize -> BatchNorm-apply triple of the forward list (the three list entries themselves) for
-        fold_forward_stats, which runs after the whole list is built: a later peephole may still replace the apply entry."""
+        fold_forward_xstats, which runs after the whole list is built: a later peephole may still replace the apply entry."""
         self._fold_candidates.append((conv, fin, act, cs, x, y, bs, partial, rows, out, act_code, float(slope), resid))
-
-    def fold_forward_stats(self):
-        """Rewrite conv / finalize / apply triples into mdcv_conv2d_statsfold + mdcv_bn_act_fwd_statsfold where the library can."""
-        L, dt = self.L, self.dtype
-        cands, self._fold_candidates = self._fold_candidates, []
-        if not self.stats_fold or dt != BF16 or not cands:
-            return 0
-        arena = self._fold_arena
-        if arena is None:
-            return 0
-        used, done = 0, 0
-        for conv, fin, act, cs, x, y, bs, partial, rows, out, act_code, slope, resid in cands:
-            idx = [i for i, e in enumerate(self.fwd) if e is conv]
-            if len(idx) != 1:
-                continue
-            i = idx[0]
-            if i + 2 > len(self.fwd) - 1 or self.fwd[i + 1] is not fin or self.fwd[i + 2] is not act:
-                continue
-            geom = (x.B, x.H, x.W, cs.cin_pad, y.H, y.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
-            if y.C > 1024 or rows < 4 or not int(L.conv2d_statsfold_ok(dt, *geom, x.ldc)):
-                continue
-            ng = 16 // (1 if y.C <= 256 else (2 if y.C <= 512 else 4))      # (the consumer's prologue holds ngroups * ceil(C / 256) <= 16 value pairs per thread)
-            G = 2 * ((rows + 2 * ng - 1) // (2 * ng))
-            ngroups = (rows + G - 1) // G
-            need = ngroups * (cs.cout_pad // 32 + 1)
-            if used + need > arena.numel():
-                continue
-            cnt = arena[used:used + need]
-            used += need
-            sup = self.f32(ngroups * 2 * y.C, zero=False)
-            bn = bs.bn
-            self.fwd[i] = (L.conv2d_statsfold, (dt, x.ptr, x.ldc, cs.wf.data_ptr(), y.ptr, y.ldc,
-                                                cs.bias_pad.data_ptr() if cs.bias_pad is not None else None, partial.data_ptr(), sup.data_ptr(),
-                                                cnt.data_ptr(), G, rows, *geom))
-            self.fwd[i + 2] = (L.bn_act_fwd_statsfold, (dt, y.ptr, y.ldc, sup.data_ptr(), ngroups, float(y.M), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
-                                                        bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), bs.invstd.data_ptr(),
-                                                        resid.ptr if resid is not None else None, resid.ldc if resid is not None else 0,
-                                                        out.ptr, out.ldc, out.M, out.C, act_code, slope))
-            del self.fwd[i + 1]
-            self.layer_marks = [m - 1 if m > i + 1 else m for m in self.layer_marks]
-            done += 1
-        self.stats_folded = done
-        return done
 
     # ---- forward BatchNorm statistics through exact accumulators (csrc/exact_acc.h): the conv's epilogue ADDS its per-tile sums to 64-bit
     # fixed-point words with fire-and-forget integer atomics (exact, order-independent: bit-reproducible), the BatchNorm-apply pass reads the
-    # totals in its prologue.  No partial rows, no finalize launch, and -- unlike stats_fold above -- no hand-off inside a launch.
+    # totals in its prologue.  No partial rows, no finalize launch, no hand-off inside a launch.
     stats_xacc = True                  # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
     stats_xacc_words = 1 << 20         # 64-bit words of the accumulator arena (zeroed by one memset at the head of the forward list)
     stats_xacc_chain = 1024            # most additions one word may see per launch (416^2 x 32, 43 264 rows on 32 replicas: +8 us on a 160 us launch -> keeps its rows)
@@ -600,17 +547,16 @@ class Plan:
     # layers are HBM-bound and the fold removes one tensor read of four to seven, so the gain is bounded by that ratio.
     pw_fuse = True                     # (tests / A-B scripts flip the class attribute; no environment knob)
     pw_fwd_px = (50000, 1 << 30)       # pixels M of the layers that take the forward form
-    pw_bwd_px = (0, 0)                 # ... the backward form: off (tests and A/B runs set (50000, 150000))
 
-    def _pw_ok(self, mode, cs, M, K, N, *lds):
+    def _pw_ok(self, cs, M, K, N, *lds):
         if not self.pw_fuse or self.dtype != BF16 or not self.training:
             return False
         if (cs.kh, cs.kw, cs.stride, cs.pad) != (1, 1, 1, 0):
             return False
-        lo, hi = self.pw_fwd_px if mode == 0 else self.pw_bwd_px
+        lo, hi = self.pw_fwd_px
         if not (lo <= M < hi) or N < 64:
             return False
-        if mode == 0 and K > 512 or mode == 1 and K > 256:
+        if K > 512:
             return False
         if K < 64 or K % 32 or 256 % (K // 8) or N % 8 or any(v % 8 for v in lds):
             return False
@@ -628,7 +574,7 @@ class Plan:
             pass
         c = _S(); c.kh, c.kw, c.stride, c.pad = kh, kw, stride, pad
         r = lb["resid"]
-        if not self._pw_ok(0, c, x.M, x.C, pad8(cout), lb["y"].ldc, x.ldc, r.ldc if r is not None else 8):
+        if not self._pw_ok(c, x.M, x.C, pad8(cout), lb["y"].ldc, x.ldc, r.ldc if r is not None else 8):
             return None
         return lb
 
@@ -644,32 +590,7 @@ class Plan:
                   stats_partial.data_ptr() if stats_partial is not None else None, x.M, cs.cin_pad, cs.cout_pad)
         self.pw_fwd_count = getattr(self, "pw_fwd_count", 0) + 1
 
-    def emit_pw_bwd(self, dout, y, bs, act, slope, cs, xnode):
-        """Backward of  conv1x1(cs) -> BatchNorm(bs) -> activation  from dout = d(activation output): the statistics part of the
-        BatchNorm backward as usual (fused into the producer of dout or the stand-alone reduce), then ONE launch that forms
-        dy = cA*g + cB*y + cC in its operand load, writes it for the weight gradient and computes dx = dy . W (+ the other gradient
-        contributions of x); then the weight gradient.  Returns False (nothing emitted) when the layer does not take this form."""
-        x = xnode.act
-        if not xnode.needs_grad or cs.wd is None:
-            return False
-        if not self._pw_ok(1, cs, y.M, y.C, cs.cin_pad, dout.ldc, y.ldc, x.ldc):
-            return False
-        L, dt = self.L, self.dtype
-        dy = self.emit_bn_act_bwd(dout, y, bs, act, slope, apply=False)
-        out, add = self.grad_target(xnode)
-        n = lambda t: t.data_ptr()  # noqa: E731
-        args = [dt, dout.ptr, dout.ldc, y.ptr, y.ldc, n(bs.scale), n(bs.shift), n(bs.cA), n(bs.cB), n(bs.cC), act, float(slope),
-                dy.ptr, dy.ldc, cs.wd.data_ptr(), out.ptr, out.ldc, add.ptr if add is not None else None, add.ldc if add is not None else 0,
-                None, 0, None, None, None, 0, 0.0, None, y.M, cs.cout_pad, cs.cin_pad]
-        self.dgrad_entries[out.ptr] = dict(
-            idx=len(self.bwd), out=out, used=False, pw=args,
-            geom=(x.B, y.H, y.W, cs.cout_pad, x.H, x.W, cs.cin_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil), head=(dy.ptr, dy.ldc))
-        self.call(self.bwd, L.pw_conv_bwd, *args)
-        self._emit_wgrad_single(cs, x, dy, cs.cin_pad)
-        self.pw_bwd_count = getattr(self, "pw_bwd_count", 0) + 1
-        return True
-
-    def emit_bn_act_bwd(self, dout, y1, bs1, act, slope, y2=None, bs2=None, apply=True):
+    def emit_bn_act_bwd(self, dout, y1, bs1, act, slope, y2=None, bs2=None):
         """Returns the gradient(s) of the raw conv output(s): dy1 [, dy2]."""
         L, dt = self.L, self.dtype
         dy1 = self._alloc_like(y1)
@@ -689,9 +610,6 @@ class Plan:
                       bs1.bn.weight.data_ptr(), g1.data_ptr(), b1.data_ptr(), n(bs1.cA), n(bs1.cB), n(bs1.cC),
                       bs2.bn.weight.data_ptr() if bs2 else None, n(g2), n(b2), n(bs2.cA) if bs2 else None, n(bs2.cB) if bs2 else None,
                       n(bs2.cC) if bs2 else None)
-        if not apply:                  # the consumer forms dy itself and writes it to dy1 (emit_pw_bwd)
-            assert y2 is None
-            return dy1
         self.call(self.bwd, L.bn_act_bwd_apply, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.cA),
                   n(bs1.cB), n(bs1.cC), dy1.ptr, dy1.ldc,
                   y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
@@ -699,89 +617,6 @@ class Plan:
                   n(bs2.cB) if bs2 else None, n(bs2.cC) if bs2 else None,
                   dy2.ptr if dy2 is not None else None, dy2.ldc if dy2 is not None else 0, y1.M, y1.C, act, float(slope))
         return (dy1, dy2) if y2 is not None else dy1
-
-    # ------------------------------------------------------------------ first layer: weight gradient without the BatchNorm-apply pass
-    # OFF by default: correct, tested and more accurate (dy is never rounded to bf16), but step-neutral at best.  YOLOv3 416^2 batch 32, same-box
-    # A/B (scripts/ab_step.py "A0;A1"): the tail of the backward gets 0.2 ms shorter (measured with the forward-only terms skipped) and those
-    # terms -- wgrad(y, x) 130 us alone / 260 us beside the forward, the tap sums 85 us -- cost 0.15 .. 0.3 ms wherever they are put (side stream
-    # under the 52^2 layers, behind layer 1, at the end of the forward; inline on the main stream): 13.95 -> 13.99 .. 14.11 ms.
-    # With those terms at the tail of the backward instead (first_layer_place = 1: x read twice there, no forward cost): 13.57 -> 13.49 ms on
-    # one box, 13.60 -> 13.65 on the next -- level.
-    first_layer_algebra = False        # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
-    first_layer_place = 0              # 0: the forward-only terms under the forward pass; 1: at the tail of the backward, beside the data gradient above
-
-    fwd_mid_layer = None               # first packed layer whose input has shrunk to 1/8 of the image (set by the model's lowering): from there on
-                                       # the forward is MFMA- / latency-bound and leaves HBM to a side stream
-
-    def emit_first_layer_bwd(self, dout, y, bs, act, slope, cs, xnode):
-        """Backward of conv -> BatchNorm -> activation for a layer whose input needs no gradient (csrc/first_layer.hip): dy = cA g + cB y + cC
-        exists for the weight gradient alone and the correlation with the input patches is linear in it, so
-            dW = cA * wgrad(g, x) + cB * wgrad(y, x) + cC * tapsums(x)
-        with g = dz * act' stored by the data gradient that produced dz (its fused BatchNorm sums are those of g anyway).  wgrad(y, x) and the
-        tap sums depend on forward data only: they are launched from the FORWARD list in front of layer `fwd_mid_layer`, on the side stream when the plan has one
-        (both backward queues are full; the forward's side queue is empty).  The apply pass (read dz, y; write dy: 1.06 GB at YOLOv3 416^2
-        batch 32, at the HBM-bound tail of the backward) never runs, and dy is never rounded to bf16: against float64 the result is 4e-7
-        off where apply + wgrad is 0.3 % .. 3.6 % off (tests/test_gpu_kernels.py::test_first_layer_wgrad_without_bn_apply).
-        Returns False when the layer does not qualify."""
-        L, dt = self.L, self.dtype
-        x = xnode.act
-        if (not self.first_layer_algebra or xnode.needs_grad or dt != BF16 or x.C != 8 or cs.cin_pad != 8 or cs.kw > 7 or cs.kh > 7 or cs.bias is not None):
-            return False
-        g1, b1 = self.param_grad(bs.bn.weight), self.param_grad(bs.bn.bias)
-        if not self._fuse_bn_sums(dout, y, bs, act, slope, g1, b1, masked=True):
-            return False
-        gw = self.param_grad(cs.weight)
-        kk = cs.kh * cs.kw
-        G, Y = self.f32(cs.cout * cs.cin * kk, zero=False), self.f32(cs.cout * cs.cin * kk, zero=False)
-        X1 = self.f32(kk * 8, zero=False)
-        tws = self.f32(int(L.conv_tap_sums_ws_floats(x.B, x.H, x.W, cs.kh, cs.kw)), zero=False)
-        splits = int(L.conv2d_wgrad_splits_geom(dt, x.B, x.H, x.W, 8, y.H, y.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil, y.ldc, x.ldc))
-        self.ws_floats = max(self.ws_floats, splits * cs.cout_pad * kk * 8)
-        plan = self
-
-        def corr(dy, out, stream):
-            return L.conv2d_wgrad(dt, dy.ptr, dy.ldc, x.ptr, x.ldc, plan.wgrad_ws(stream).data_ptr(), splits, out.data_ptr(), 0,
-                                  x.B, x.H, x.W, 8, cs.cin, y.H, y.W, cs.cout_pad, cs.cout, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil, stream)
-
-        def forward_terms(stream):             # Y and X1: forward data only
-            side = None
-            if getattr(plan, "overlap_wgrad", False) and not plan.use_graph and "run" not in plan.__dict__ and hasattr(plan, "side"):
-                side = plan.side().cuda_stream       # the stream the backward's weight gradients use: gradient_term is ordered behind this
-                L.check(L.stream_fork(stream, side, plan.fork_device_scope), "stream_fork")
-            s = side if side is not None else stream
-            rc = L.conv_tap_sums(dt, x.ptr, x.ldc, x.B, x.H, x.W, y.H, y.W, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil, tws.data_ptr(),
-                                 X1.data_ptr(), s)
-            return rc or corr(y, Y, s)
-
-        def gradient_term(stream):             # G from the stored g, then the three terms with the coefficients the finalize just wrote
-            rc = corr(dout, G, stream)
-            return rc or L.first_layer_wgrad_combine(G.data_ptr(), Y.data_ptr(), X1.data_ptr(), bs.cA.data_ptr(), bs.cB.data_ptr(),
-                                                     bs.cC.data_ptr(), gw.data_ptr(), cs.cout, cs.cin, kk, stream)
-        forward_terms.__name__ = "first_layer_forward_terms"
-        gradient_term.__name__ = "conv2d_wgrad"                                # (side stream, run_bwd_list)
-        gradient_term.info = (x.B, x.H, x.W, 8, y.H, y.W, cs.cout_pad, cs.kh, cs.stride, splits)
-        if self.first_layer_place == 1:
-            # in the backward list in FRONT of the data gradient that writes g: the side stream takes them behind the weight gradient of the
-            # layer above, beside that data gradient -- no forward cost, x is read twice at the tail instead of dy0 written and read
-            def tail_terms(stream):
-                rc = L.conv_tap_sums(dt, x.ptr, x.ldc, x.B, x.H, x.W, y.H, y.W, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil, tws.data_ptr(),
-                                     X1.data_ptr(), stream)
-                return rc or corr(y, Y, stream)
-            tail_terms.__name__ = "conv2d_wgrad"
-            tail_terms.info = gradient_term.info
-            self.bwd.insert(self.dgrad_entries[dout.ptr]["idx"], (tail_terms, ()))
-            for e in self.dgrad_entries.values():
-                if e["idx"] >= self.dgrad_entries[dout.ptr]["idx"] and e["out"].ptr != dout.ptr:
-                    e["idx"] += 1
-            self.dgrad_entries[dout.ptr]["idx"] += 1
-        else:
-            k = self.fwd_mid_layer
-            pos = self.layer_marks[k] if k is not None and k < len(self.layer_marks) else len(self.fwd)
-            self.fwd.insert(pos, (forward_terms, ()))
-            self.layer_marks = [m + 1 if m >= pos else m for m in self.layer_marks]
-        self.bwd.append((gradient_term, ()))
-        self.first_layer_fused = True
-        return True
 
     # On by default (Plan.fuse_bn = False restores the two-pass form).  YOLOv3 416^2 B=32: it removes 0.95 ms of stand-alone reduce kernels
     # per step and adds ~1.1 ms to the 66 data gradients' store loops (the y loads are HBM misses whose latency is exposed once per
@@ -832,7 +667,7 @@ class Plan:
             return not (k & 128)
         return True
 
-    def _fuse_bn_sums(self, dout, y, bs, act, slope, dgamma, dbeta, masked=False):
+    def _fuse_bn_sums(self, dout, y, bs, act, slope, dgamma, dbeta):
         """Fold the BatchNorm-backward reduction over (dout, y) into the store loop of the data gradient that wrote `dout`.
 
         Legal when that launch is the LAST writer of the buffer (nothing between it and this point of the backward list mentions
@@ -851,48 +686,31 @@ class Plan:
             if dout.ptr in args:
                 return False
         L, dt = self.L, self.dtype
-        pw = e.get("pw")
         pwb = e.get("pwb")
         g = e["geom"]
         if pwb is not None:            # the one-launch 1x1 backward (_emit_pw_bwd1): y of the sums rides in its DMA ring, one partial row per slab
-            if masked:
-                return False
             rows = int(pwb[11])
             partial = self.f32(rows * 2 * y.C, zero=False)
             a2 = list(pwb)
             a2[12:20] = [y.ptr, y.ldc, bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope), partial.data_ptr()]
             assert self.bwd[e["idx"]][0] is L.pw_bwd
             self.bwd[e["idx"]] = (L.pw_bwd, tuple(a2))
-            e["used"] = True
-            self.call(self.bwd, L.bn_bwd_finalize_rows, partial.data_ptr(), rows, y.C, float(y.M), bs.bn.weight.data_ptr(),
-                      bs.mean.data_ptr(), bs.invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bs.cA.data_ptr(), bs.cB.data_ptr(),
-                      bs.cC.data_ptr())
-            self.fused_bn += 1
-            return True
-        s2_shift = pw is None and bool(L.conv2d_dgrad_masked_ok(dt, *g, e["head"][1]))    # the shift kernel's stride-2 form (csrc/conv_shift.hip MODE 3): its
-        # store loop writes whole output rows from LDS and takes the y loads of the sums in its stride -- 208 -> 416: stand-alone reduce
-        # 180 us in the step against +70 us in the data gradient, at the HBM-bound tail of the backward; one row per 8 x 31 tile.
-        # (It pays at every size: the pixel classes of _fuse_pays describe the per-class im2col launches.)
-        if not s2_shift and not self._fuse_pays(g):
-            return False
-        rows = int(L.pw_rows(o.M, g[3])) if pw is not None else int(L.conv2d_dgrad_bnsums_rows(dt, *g, e["head"][1]))
-        if rows <= 0 or rows > (self.fuse_max_rows_s2 if s2_shift else self.fuse_max_rows):
-            return False
-        if masked and not s2_shift:    # (emit_first_layer_bwd: the launch stores g, not dz; only that form can)
-            return False
-        fn0, _ = self.bwd[e["idx"]]
-        partial = self.f32(rows * 2 * y.C, zero=False)
-        if pw is not None:             # the 1x1 block launch (emit_pw_bwd) carries the sums in its own store loop
-            assert fn0 is L.pw_conv_bwd
-            a2 = list(pw)
-            a2[19:27] = [y.ptr, y.ldc, bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope), partial.data_ptr()]
-            self.bwd[e["idx"]] = (L.pw_conv_bwd, tuple(a2))
         else:
-            assert fn0 is L.conv2d
+            s2_shift = bool(L.conv2d_dgrad_s2_form_ok(dt, *g, e["head"][1]))    # the shift kernel's stride-2 form (csrc/conv_shift.hip MODE 3): its
+            # store loop writes whole output rows from LDS and takes the y loads of the sums in its stride -- 208 -> 416: stand-alone reduce
+            # 180 us in the step against +70 us in the data gradient, at the HBM-bound tail of the backward; one row per 8 x 31 tile.
+            # (It pays at every size: the pixel classes of _fuse_pays describe the per-class im2col launches.)
+            if not s2_shift and not self._fuse_pays(g):
+                return False
+            rows = int(L.conv2d_dgrad_bnsums_rows(dt, *g, e["head"][1]))
+            if rows <= 0 or rows > (self.fuse_max_rows_s2 if s2_shift else self.fuse_max_rows):
+                return False
+            assert self.bwd[e["idx"]][0] is L.conv2d
+            partial = self.f32(rows * 2 * y.C, zero=False)
             h = e["head"]
-            self.bwd[e["idx"]] = (L.conv2d_dgrad_bnsums_masked if masked else L.conv2d_dgrad_bnsums,
-                                  (dt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], *e["geom"], y.ptr, y.ldc,
-                                   bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope), partial.data_ptr()))
+            self.bwd[e["idx"]] = (L.conv2d_dgrad_bnsums, (dt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], *e["geom"], y.ptr, y.ldc,
+                                                          bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope),
+                                                          partial.data_ptr()))
         e["used"] = True
         self.call(self.bwd, L.bn_bwd_finalize_rows, partial.data_ptr(), rows, y.C, float(y.M), bs.bn.weight.data_ptr(),
                   bs.mean.data_ptr(), bs.invstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), bs.cA.data_ptr(), bs.cB.data_ptr(),

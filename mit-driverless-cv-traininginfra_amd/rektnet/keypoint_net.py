@@ -12,6 +12,8 @@ twice and discards the first result, keypoint_net.py:64,68 — same values).  No
 """
 import os
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -87,18 +89,19 @@ class KeypointNet(FlatParamsMixin, nn.Module):
         return out
 
     def _initialize_weights(self):
-        """kaiming-normal (fan_out, relu) conv weights, zero biases, BN weight 1 / bias 0 (reference :33-44)."""
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
-            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
-                nn.init.constant_(m.weight, 1)
-                nn.init.constant_(m.bias, 0)
-            elif isinstance(m, nn.Linear):
-                nn.init.normal_(m.weight, 0, 0.01)
-                nn.init.constant_(m.bias, 0)
+        """Initial parameters of the two module kinds this network holds (what the reference's loop at keypoint_net.py:33-44 does to them):
+        conv weights He-normal over the fan-OUT (std = sqrt(2 / (Cout * kh * kw)), the ReLU gain), conv biases zero; BatchNorm affine =
+        identity.  One normal draw per conv in module order, so a seeded construction gives the reference's weights."""
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    kh, kw = m.kernel_size
+                    m.weight.normal_(0.0, math.sqrt(2.0 / (m.out_channels * kh * kw)))
+                    if m.bias is not None:
+                        m.bias.zero_()
+                elif isinstance(m, nn.BatchNorm2d):
+                    m.weight.fill_(1.0)
+                    m.bias.zero_()
 
     def _flatten(self):
         import weakref

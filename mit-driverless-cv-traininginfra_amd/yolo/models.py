@@ -692,10 +692,6 @@ class Darknet(FlatParamsMixin, nn.Module):
             return plan.new_act(B, h_, w_, c_)
 
         plan.call(plan.fwd, _zero_tensor, plan.out7)
-        if bn_train and plan.stats_fold and dt == _lib.BF16:      # counters of the in-launch statistics folds (engine.fold_forward_stats): one memset per forward
-            plan._fold_arena = torch.zeros(plan.stats_fold_counters, dtype=torch.int32, device=device)
-            plan.keep.append(plan._fold_arena)
-            plan.call(plan.fwd, _zero_tensor, plan._fold_arena)
         if bn_train and plan.stats_xacc:                          # exact accumulators of the forward statistics (engine.fold_forward_xstats): one memset per forward
             plan._xacc_arena = torch.zeros(plan.stats_xacc_words, dtype=torch.int64, device=device)
             plan.keep.append(plan._xacc_arena)
@@ -729,8 +725,6 @@ class Darknet(FlatParamsMixin, nn.Module):
                     if pw_lb is not None:
                         plan.fwd.pop()                       # that bn_act_fwd entry is replaced by the fused launch below
                 cs = ConvSpec(plan, conv.weight, conv.bias, conv.stride[0], conv.padding[0], 1, cin_pad=cur.act.C)
-                if plan.fwd_mid_layer is None and cur.act.H * 8 <= xin.act.H:
-                    plan.fwd_mid_layer = len(plan.pack_list)          # (the first layer's forward-only gradient terms start here on the side stream)
                 plan.emit_pack(cs, need_dgrad=with_targets and cur.needs_grad)
                 ho, wo = shp[i][1], shp[i][2]
                 fold_c = None
@@ -874,7 +868,6 @@ class Darknet(FlatParamsMixin, nn.Module):
             plan.call(plan.fwd, _bump_counters, nbt)
         if plan.stats_xacc:
             plan.fold_forward_xstats()     # conv -> finalize -> apply triples that survived the peepholes become two launches (csrc/exact_acc.h)
-        plan.fold_forward_stats()          # conv -> finalize -> apply triples that survived the peepholes become two launches (csrc/stats_fold.h)
         plan.finish_pack(0)
 
         # ---- backward list: mirror of the records, consumers before producers
@@ -900,11 +893,8 @@ class Darknet(FlatParamsMixin, nn.Module):
                         continue
                     if rnode is not None:
                         plan.grad_identity(rnode, z.grad)
-                    if rnode is None and z.gstate == "own" and plan.emit_first_layer_bwd(z.grad, y, bs, act_code, slope, cs, xn):
-                        pass                   # (z.grad is this layer's alone: the data gradient that wrote it may store g = dz * act' instead)
-                    elif not plan.emit_pw_bwd(z.grad, y, bs, act_code, slope, cs, xn):
-                        dy = plan.emit_bn_act_bwd(z.grad, y, bs, act_code, slope)
-                        plan.emit_conv_bwd(cs, xn, y, dy)
+                    dy = plan.emit_bn_act_bwd(z.grad, y, bs, act_code, slope)
+                    plan.emit_conv_bwd(cs, xn, y, dy)
                 elif kind == "shortcut":
                     _, a, b, z = r
                     if z.gstate == "none":

@@ -2,7 +2,7 @@
 (plan-build-time switches need their own plan).
 usage: ab_step.py "c-30;c-31;c-31,w30005;P0" [rounds] [steps] [yolo|rektnet]
   c<n> = mdcv_conv2d_set_variant(n), w<n> = mdcv_conv2d_wgrad_set_variant(n), p<n> = mdcv_pw_set_variant(n)   (applied before every timing block)
-  P0 / P1 = engine.Plan.pw_fuse off / on, F<mask> = engine.Plan.fuse_skip, R<n> = engine.Plan.fuse_max_rows, A0 / A1 = engine.Plan.first_layer_algebra, T0 / T1 = engine.Plan.stats_fold, Y0 / Y1 = engine.Plan.stats_xacc, B0 / B1 = engine.Plan.pw_bwd1, X<substr> = what-if timing without the launches whose name contains it, S0 = model.strict_targets off                                      (applied when the model is built)
+  P0 / P1 = engine.Plan.pw_fuse off / on, F<mask> = engine.Plan.fuse_skip, R<n> = engine.Plan.fuse_max_rows, Y0 / Y1 = engine.Plan.stats_xacc, B0 / B1 = engine.Plan.pw_bwd1, X<substr> = what-if timing without the launches whose name contains it, S0 = model.strict_targets off                                      (applied when the model is built)
 Every setting is applied on top of the first one (the baseline), which is re-applied in front of each."""
 import os, sys, tempfile, time, statistics
 import torch
@@ -21,20 +21,18 @@ workload = sys.argv[4] if len(sys.argv) > 4 else "yolo"
 
 
 from mdcv import engine
-BUILD_DEFAULTS = dict(pw_fuse=engine.Plan.pw_fuse, fuse_skip=engine.Plan.fuse_skip, fuse_max_rows=engine.Plan.fuse_max_rows, fla=engine.Plan.first_layer_algebra, sf=engine.Plan.stats_fold, sx=engine.Plan.stats_xacc, pb=engine.Plan.pw_bwd1)
+BUILD_DEFAULTS = dict(pw_fuse=engine.Plan.pw_fuse, fuse_skip=engine.Plan.fuse_skip, fuse_max_rows=engine.Plan.fuse_max_rows, sx=engine.Plan.stats_xacc, pb=engine.Plan.pw_bwd1)
 
 
 def apply(codes):
     for c in codes:
-        if not c or c[0] in "PFSRAXTYBK":
+        if not c or c[0] in "PFSRXYBK":
             continue
-        {"c": L.cdll.mdcv_conv2d_set_variant, "w": L.cdll.mdcv_conv2d_wgrad_set_variant, "p": L.cdll.mdcv_pw_set_variant, "b": L.cdll.mdcv_bn_act_fwd_statsfold_blocks}[c[0]](int(c[1:]))
+        {"c": L.cdll.mdcv_conv2d_set_variant, "w": L.cdll.mdcv_conv2d_wgrad_set_variant, "p": L.cdll.mdcv_pw_set_variant}[c[0]](int(c[1:]))
 
 
 def apply_build(codes):
     engine.Plan.pw_fuse, engine.Plan.fuse_skip, engine.Plan.fuse_max_rows = BUILD_DEFAULTS["pw_fuse"], BUILD_DEFAULTS["fuse_skip"], BUILD_DEFAULTS["fuse_max_rows"]
-    engine.Plan.first_layer_algebra = BUILD_DEFAULTS["fla"]
-    engine.Plan.stats_fold = BUILD_DEFAULTS["sf"]
     engine.Plan.stats_xacc = BUILD_DEFAULTS["sx"]
     engine.Plan.pw_bwd1 = BUILD_DEFAULTS["pb"]
     from mdcv.yolo import models as _ym0
@@ -47,11 +45,6 @@ def apply_build(codes):
             engine.Plan.pw_bwd1 = bool(int(c[1:]))
         if c and c[0] == "Y":          # Y0 / Y1: forward statistics as partial rows + finalize launch / through exact accumulators (csrc/exact_acc.h)
             engine.Plan.stats_xacc = bool(int(c[1:]))
-        if c and c[0] == "T":          # T0 / T1: forward statistics finalized by a launch / folded inside the conv + consumer prologue
-            engine.Plan.stats_fold = bool(int(c[1:]))
-        if c and c[0] == "A":          # A0 / A1: the first layer's weight gradient with / without its BatchNorm-apply pass
-            engine.Plan.first_layer_algebra = bool(int(c[1:]) & 1)      # A3: with the forward-only terms at the tail of the backward
-            engine.Plan.first_layer_place = int(c[1:]) >> 1
         if c and c[0] == "P":
             engine.Plan.pw_fuse = bool(int(c[1:]))
         if c and c[0] == "F":

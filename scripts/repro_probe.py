@@ -14,11 +14,6 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 if os.environ.get("PROBE_NOFUSE"):
     from mdcv import engine
     engine.Plan.fuse_bn = False
-if os.environ.get("PROBE_FOLD"):          # the off-by-default forms: in-launch statistics fold (stats_fold.h), first-layer algebra
-    from mdcv import engine
-    engine.Plan.stats_fold = True
-    engine.Plan.first_layer_algebra = True
-    engine.Plan.first_layer_place = int(os.environ["PROBE_FOLD"]) - 1
 tmp = tempfile.mkdtemp(); cfg = bench.write_yolo_cfg(tmp)
 os.chdir(tmp)
 from mdcv import engine as _eng

@@ -37,12 +37,10 @@ for (M, C) in [(5408, 1024), (21632, 512), (86528, 256), (86528, 128), (346112, 
         if reps > L.xstats_reps(1 << 30, C):
             continue
         acc = torch.randint(0, 1 << 30, (L.xstats_words(reps, C),), dtype=torch.int64, device="cuda")
-        for blocks in (2048, 512):
-            L.bn_act_fwd_statsfold_blocks(blocks)
+        for blocks in (512,):
             f = lambda: L.bn_act_fwd_xstats(BF16, y.data_ptr(), C, acc.data_ptr(), reps, float(M), gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                                             0.1, 1e-5, *[c.data_ptr() for c in co], None, 0, z.data_ptr(), C, M, C, 1, 0.1, st())
             res.append(" x%d@%d %6.1f" % (reps, blocks, bench(f)))
-    L.bn_act_fwd_statsfold_blocks(512)
     print("".join(res), flush=True)
 
 print()
