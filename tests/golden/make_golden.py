@@ -6,6 +6,8 @@ Run in the build container only (needs /root/reference, which never travels):
     python tests/golden/make_golden.py yolo
     python tests/golden/make_golden.py rektnet
     python tests/golden/make_golden.py post
+    python tests/golden/make_golden.py autocast            (reference Darknet fp32 vs torch.autocast(cpu, bfloat16): per-layer gradient cosine)
+    python tests/golden/make_golden.py rektnet_autocast    (reference KeypointNet fp32 vs autocast at batch 256: key-point deviation)
 
 Two invocations because CVC-YOLOv3/utils is a package and RektNet/utils.py a module
 (SURVEY.md §8c).  Writes tests/golden/*.npz (+ the mini cfg's .weights / train.csv).
@@ -178,6 +180,46 @@ def gen_yolo():
                   "module_list.11.conv_11.bias", "module_list.3.batch_norm_3.weight"):
             out[f"{opt_name}::" + n] = sd[n]
     npz("mini_darknet.npz", **out)
+
+    # ---------------- the two cfg features mini.cfg does not reach: max-pools (both forms of yolo_baseline_tiny.cfg, models.py:74-84) and
+    # conv_activation=ReLU (models.py:70-71).  Same recipe: seeded init, non-trivial BatchNorm state, .weights round trip, one train step
+    # (losses, every gradient norm, first / middle / last conv gradients, running statistics) and the eval output.
+    for tag, cfg_name, seed in (("mini_tiny", "mini_tiny.cfg", 777), ("mini_relu", "mini_relu.cfg", 778)):
+        torch.manual_seed(seed)
+        tn = ref_models.Darknet(cfg_name, 2.0, 1.6, 25.0, 0.1, False)
+        with torch.no_grad():
+            for m in tn.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.75, 1.25)
+                    m.bias.uniform_(-0.1, 0.1)
+                    m.running_mean.uniform_(-0.05, 0.05)
+                    m.running_var.uniform_(0.8, 1.2)
+        tn.header_info = np.zeros(5, np.int32)
+        tn.save_weights(tag + ".weights")
+        tn2 = ref_models.Darknet(cfg_name, 2.0, 1.6, 25.0, 0.1, False)
+        tn2.load_weights(tag + ".weights", tn2.get_start_weight_dim())
+        for (k1, v1), (k2, v2) in zip(tn.state_dict().items(), tn2.state_dict().items()):
+            assert k1 == k2 and torch.equal(v1, v2), k1
+        tg_ = torch.Generator().manual_seed(seed + 1)
+        tx = torch.rand(3, 3, 64, 64, generator=tg_)
+        tt = synth_targets(3, 4, tg_)
+        tn.train()
+        tl = tn(tx, tt)
+        tl[0].sum().backward()
+        tgr = {n: p.grad.clone() for n, p in tn.named_parameters()}
+        convs = [n for n in tgr if n.endswith("weight") and ".conv_" in n]
+        tout = dict(x=tx, targets=tt, losses=torch.stack([l.detach() for l in tl]), param_names=np.array(list(tn.state_dict().keys())),
+                    grad_names=np.array(list(tgr.keys())), grad_norm=np.array([float(tgr[n].double().norm()) for n in tgr]),
+                    layer_kinds=np.array([type(m).__name__ for seq in tn.module_list for m in seq]))
+        for n in (convs[0], convs[len(convs) // 2], convs[-1]):
+            tout["grad::" + n] = tgr[n]
+        for n, b in tn.named_buffers():
+            if "running" in n:
+                tout["run::" + n] = b.clone()
+        tn.eval()
+        with torch.no_grad():
+            tout["eval_out"] = tn(tx)
+        npz(tag + "_darknet.npz", **tout)
 
     # data-parallel semantics: B=8 as 2x4 and 4x2 shards (per-shard loss; sum-of-shard grads)
     gg = torch.Generator().manual_seed(7)
@@ -650,6 +692,57 @@ def gen_autocast():
         json.dump(out, f, indent=1)
 
 
+def gen_rektnet_autocast():
+    """What bf16 does to RektNet's key points ON THE REFERENCE'S OWN ARITHMETIC: the reference KeypointNet (RektNet/keypoint_net.py:58-70) on
+    BASELINE config 2's batch (256 crops of 80x80; the seed-5 init and seed-77 batch of tests/test_gpu_models.py::test_keypointnet_batch256...),
+    train mode, once in fp32 and once under torch.autocast("cpu", bfloat16); stored: the distribution of |key point(bf16) - key point(fp32)|
+    over the 256 x 7 x 2 coordinates.  The HIP bf16 mode is held to this curve (+ a stated margin), not to a hand-picked bound."""
+    import json
+    sys.path.insert(0, os.path.join(REF, "RektNet"))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from keypoint_net import KeypointNet                    # reference
+    from oracle import rektnet_oracle as ro
+    B = 256
+    sd = ro.init_state(5)
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(B, 3, 80, 80, generator=g)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+
+    def run(mode, impl):
+        if impl == "reference":
+            net = KeypointNet(7, (80, 80))
+            full = net.state_dict()
+            full.update({k: v.detach().clone() for k, v in ro.init_state(5).items()})
+            net.load_state_dict(full)
+            net.train()
+            f = lambda: net(x)                                                     # noqa: E731
+        else:
+            st = ro.init_state(5)
+            f = lambda: ro.keypoint_forward(x, st, train=True)                      # noqa: E731
+        with torch.no_grad():
+            if mode == "bf16":
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    out = f()
+            else:
+                out = f()
+        return out[1].float()
+    res = {}
+    for impl in ("reference", "oracle"):
+        p32, p16 = run("fp32", impl), run("bf16", impl)
+        d = (p16 - p32).abs().numpy().reshape(-1)
+        res[impl] = {"max": float(d.max()), "p999": float(np.quantile(d, 0.999)), "p99": float(np.quantile(d, 0.99)), "mean": float(d.mean())}
+        if impl == "reference":
+            ref32 = p32
+        else:
+            res["fp32_max_abs_difference_reference_vs_oracle"] = float((p32 - ref32).abs().max())
+        print(impl, res[impl], flush=True)
+    out = {"what": "|key point under torch.autocast(cpu, bfloat16) - key point in fp32| of the REFERENCE's KeypointNet (train mode, batch 256, 3584 "
+                   "coordinates in [0, 1]); 'oracle' = the same for oracle/rektnet_oracle.py", "generator": "tests/golden/make_golden.py rektnet_autocast",
+           "batch": B, "init_seed": 5, "data_seed": 77, "torch": torch.__version__, **res}
+    with open(os.path.join(HERE, "rektnet_autocast_bf16_pts.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
     which = sys.argv[1]
-    {"yolo": gen_yolo, "rektnet": gen_rektnet, "post": gen_post, "autocast": gen_autocast}[which]()
+    {"yolo": gen_yolo, "rektnet": gen_rektnet, "post": gen_post, "autocast": gen_autocast, "rektnet_autocast": gen_rektnet_autocast}[which]()

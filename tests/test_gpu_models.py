@@ -141,6 +141,61 @@ def test_mini_darknet_train_step_vs_reference(precision):
         assert relerr(ev.cpu(), z["eval_out"]) < 5e-2
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag", ["mini_tiny", "mini_relu"])
+def test_maxpool_and_relu_cfgs_train_step_vs_reference(tag, precision, tmp_path):
+    """HIP path against vectors the REFERENCE produced for the cfg features mini.cfg does not reach (VERDICT r4 missing 3): mini_tiny.cfg =
+    yolo_baseline_tiny.cfg at toy width, both max-pool forms (models.py:74-84); mini_relu.cfg = conv_activation=ReLU (models.py:70-71).
+    state_dict keys, .weights round trip byte for byte, losses / gradient norms / three conv gradients / running statistics after one
+    train step, eval output.  fp32 kernels: 1e-4 losses, 1e-3 gradients; bf16: statistical bars of the mini.cfg test."""
+    from mdcv.yolo.models import Darknet
+    z = load(tag + "_darknet.npz")
+    cwd = os.getcwd()
+    os.chdir(os.path.join(G, "mini"))
+    try:
+        net = Darknet(tag + ".cfg", 2.0, 1.6, 25.0, 0.1, False, precision=precision)
+        net.load_weights(tag + ".weights", net.get_start_weight_dim())
+    finally:
+        os.chdir(cwd)
+    net = net.cuda()
+    assert list(net.state_dict().keys()) == [str(k) for k in z["param_names"]]
+    assert [type(m).__name__ for seq in net.module_list for m in seq] == [str(k) for k in z["layer_kinds"]]
+    p = tmp_path / "rt.weights"
+    net.save_weights(str(p))
+    assert open(p, "rb").read() == open(os.path.join(G, "mini", tag + ".weights"), "rb").read()
+    net.train()
+    x, tg = T(z["x"]).cuda(), T(z["targets"]).cuda()
+    losses = net(x, tg)
+    losses[0].sum().backward()
+    got = torch.stack([l.detach() for l in losses]).cpu().numpy()
+    f32 = precision == "fp32"
+    close(got, z["losses"], rtol=1e-4 if f32 else 3e-2, atol=0 if f32 else 1e-3)
+    params = dict(net.named_parameters())
+    for n, gn in zip([str(n) for n in z["grad_names"]], z["grad_norm"]):
+        mine = float(params[n].grad.double().norm())
+        assert abs(mine - gn) <= (1e-3 if f32 else 2.5e-1) * max(gn, 1e-3), (n, mine, gn)
+    for k in z.files:
+        if k.startswith("grad::"):
+            mine = params[k[6:]].grad.cpu()
+            if f32:
+                e = relerr(mine, z[k])
+                assert e < 1e-3, (k, e)
+            else:
+                a, b = mine.double().flatten(), T(z[k]).double().flatten()
+                cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+                assert cos > 0.9, (k, cos)
+        if k.startswith("run::"):
+            close(net.state_dict()[k[5:]].cpu(), z[k], rtol=1e-4 if f32 else 2e-2, atol=1e-6 if f32 else 2e-3, msg=k)
+    net.eval()
+    with torch.no_grad():
+        ev = net(x)
+    assert tuple(ev.shape) == z["eval_out"].shape
+    if f32:
+        close(ev.cpu(), z["eval_out"], rtol=1e-3, atol=1e-3)
+    else:
+        assert relerr(ev.cpu(), z["eval_out"]) < 5e-2
+
+
 @pytest.mark.parametrize("opt_name", ["adam", "sgd"])
 def test_mini_darknet_optimizer_step(opt_name):
     """train.py:67-72 sequence with the stock torch optimizers and with the fused flat-buffer ones."""
@@ -282,10 +337,13 @@ def test_keypointnet_vs_reference(precision):
 def test_keypointnet_batch256_bf16_train_step_vs_fp32_oracle():
     """BASELINE config 2 at its real size (RektNet 80x80, batch 256, bf16, l1_softargmax + geo) against the fp32 CPU oracle
     (RektNet/train_eval.py:59-79: forward -> CrossRatioLoss -> backward): total loss within 5e-3, every parameter gradient's norm within
-    10 % (20 % for the few tensors whose gradient is tiny), gradient direction of the big layers aligned, key points: 99.9 % of the 3584
-    coordinates within 0.06 (SURVEY 8d's bound, derived at batch 4), mean deviation below 0.01, none beyond 0.08.  The tail is what bf16
-    does to this random-init network on the reference's own arithmetic: the oracle under torch.autocast("cpu", bfloat16) on this very batch
-    deviates from its fp32 self by max 0.0602 / p99.9 0.0553 / mean 0.0072 (HIP bf16 mode, measured: 0.0651 / 0.0539 / 0.0068)."""
+    10 % (20 % for the few tensors whose gradient is tiny), gradient direction of the big layers aligned.  Key points: held to what bf16 does
+    to this network ON THE REFERENCE'S OWN ARITHMETIC -- tests/golden/rektnet_autocast_bf16_pts.json, produced by the reference KeypointNet
+    under torch.autocast("cpu", bfloat16) on this very batch and these weights (make_golden.py rektnet_autocast: max 0.0608 / p99.9 0.0557 /
+    mean 0.0073 over the 3584 coordinates) -- plus 0.005 (max, p99.9) / 0.001 (mean); HIP bf16 mode, measured: 0.0651 / 0.0539 / 0.0068.
+    SURVEY 8d's |d| <= 0.06 was derived at batch 4; at batch 256 the reference itself exceeds it."""
+    import json
+    ref_bf16 = json.load(open(os.path.join(G, "rektnet_autocast_bf16_pts.json")))["reference"]
     from oracle import rektnet_oracle as ro
     from mdcv.rektnet.keypoint_net import KeypointNet
     from mdcv.rektnet.cross_ratio_loss import CrossRatioLoss
@@ -313,7 +371,8 @@ def test_keypointnet_batch256_bf16_train_step_vs_fp32_oracle():
     assert tuple(pts.shape) == (B, 7, 2)
     dpts = np.abs(pts.detach().cpu().numpy() - pts_o.detach().numpy())
     print('pts diff max %.4f p99.9 %.4f mean %.5f; loss %.6f vs %.6f' % (dpts.max(), np.quantile(dpts, 0.999), dpts.mean(), float(tot), float(tot_o)))
-    assert np.quantile(dpts, 0.999) < 0.06 and dpts.mean() < 0.01 and dpts.max() < 0.08
+    assert np.quantile(dpts, 0.999) <= ref_bf16["p999"] + 0.005, (np.quantile(dpts, 0.999), ref_bf16)
+    assert dpts.max() <= ref_bf16["max"] + 0.005 and dpts.mean() <= ref_bf16["mean"] + 0.001, (dpts.max(), dpts.mean(), ref_bf16)
     assert abs(float(tot) - float(tot_o)) <= 5e-3 * abs(float(tot_o)), (float(tot), float(tot_o))
     assert abs(float(loc) - float(loc_o)) <= 5e-3 * abs(float(loc_o)) and abs(float(geo) - float(geo_o)) <= 5e-2 * abs(float(geo_o)) + 1e-5
     params = dict(net.named_parameters())

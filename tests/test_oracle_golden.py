@@ -109,6 +109,44 @@ def test_mini_darknet_loss_grads_running(mini):
         net.params[k] = v
 
 
+@pytest.mark.parametrize("tag", ["mini_tiny", "mini_relu"])
+def test_maxpool_and_relu_cfgs_loss_grads_running_eval(tag, tmp_path):
+    """The cfg features mini.cfg does not reach, against vectors the REFERENCE produced (make_golden.py yolo): mini_tiny.cfg = yolo_baseline_tiny.cfg
+    at toy width with both max-pool forms (MaxPool2d(2, 2); ZeroPad2d((0, 1, 0, 1)) + MaxPool2d(2, 1), models.py:74-84), mini_relu.cfg =
+    conv_activation=ReLU (models.py:70-71).  Same bars as mini.cfg; plus the .weights round trip byte for byte."""
+    z = load(tag + "_darknet.npz")
+    cwd = os.getcwd()
+    os.chdir(os.path.join(G, "mini"))
+    try:
+        net = yo.DarknetOracle(tag + ".cfg", anchors=yo.read_anchor_row("dataset/train.csv"))
+        net.load_weights(tag + ".weights", [18, 18])
+    finally:
+        os.chdir(cwd)
+    p = tmp_path / "rt.weights"
+    net.save_weights(str(p))
+    assert open(p, "rb").read() == open(os.path.join(G, "mini", tag + ".weights"), "rb").read()
+    base = {k: v.clone() for k, v in net.params.items()}
+    for k in net.trainable():
+        net.params[k] = base[k].clone().requires_grad_(True)
+    losses = net.forward(T(z["x"]), T(z["targets"]), bn_train=True)
+    losses[0].sum().backward()
+    np.testing.assert_allclose(torch.stack([l.detach() for l in losses]).numpy(), z["losses"], rtol=2e-5)
+    for n, gn in zip([str(n) for n in z["grad_names"]], z["grad_norm"]):
+        g = net.params[ref_key_to_oracle(n)].grad
+        np.testing.assert_allclose(float(g.double().norm()), gn, rtol=2e-4, atol=1e-7, err_msg=n)
+    for k in z.files:
+        if k.startswith("grad::"):
+            np.testing.assert_allclose(net.params[ref_key_to_oracle(k[6:])].grad.numpy(), z[k], rtol=1e-3, atol=2e-6, err_msg=k)
+        if k.startswith("run::"):
+            np.testing.assert_allclose(net.params[ref_key_to_oracle(k[5:])].detach().numpy(), z[k], rtol=1e-5, atol=1e-7, err_msg=k)
+    for k, v in base.items():
+        if "running" not in k:
+            net.params[k] = v
+    with torch.no_grad():
+        ev = net.forward(T(z["x"]), None, bn_train=False)
+    np.testing.assert_allclose(ev.numpy(), z["eval_out"], rtol=1e-4, atol=1e-5)
+
+
 def test_mini_weights_roundtrip(mini, tmp_path):
     p = tmp_path / "rt.weights"
     mini.save_weights(str(p))
@@ -362,3 +400,17 @@ def test_autocast_bf16_cosine_curve_is_reference_output_and_the_oracle_agrees():
     assert max(abs(d["cos"][k] - d["cos_oracle"][k]) for k in d["cos"]) <= 1.5e-3
     assert abs(d["loss"]["fp32"] - d["loss_oracle"]["fp32"]) <= 1e-4 * abs(d["loss"]["fp32"])
     assert d["max_rel_fp32_gradient_difference_reference_vs_oracle"] < 1e-3
+
+
+def test_rektnet_autocast_fixture_is_reference_output_and_the_oracle_agrees():
+    """tests/golden/rektnet_autocast_bf16_pts.json (make_golden.py rektnet_autocast): the key-point deviation of the REFERENCE KeypointNet under
+    torch.autocast(cpu, bfloat16) at batch 256 -- the bar of the HIP bf16 test -- with the oracle's own curve beside it: identical in fp32, and the
+    two bf16 curves within 1e-3 of each other at every quantile stored."""
+    import json
+    z = json.load(open(os.path.join(G, "rektnet_autocast_bf16_pts.json")))
+    assert z["generator"].endswith("rektnet_autocast") and z["batch"] == 256 and z["init_seed"] == 5 and z["data_seed"] == 77
+    assert z["fp32_max_abs_difference_reference_vs_oracle"] <= 1e-6
+    for k in ("max", "p999", "p99", "mean"):
+        assert abs(z["reference"][k] - z["oracle"][k]) <= 1e-3, (k, z["reference"][k], z["oracle"][k])
+    assert 0.05 < z["reference"]["max"] < 0.07 and z["reference"]["mean"] < 0.01
+
