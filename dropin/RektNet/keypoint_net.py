@@ -9,6 +9,13 @@ _REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _REPO not in sys.path:
     sys.path.append(_REPO)             # appended, not prepended: nothing of the reference's own tree is shadowed
 
+# Under `python -m torch.distributed.run --nproc-per-node N <script> ...` this import is the first thing the script does with the model code, and
+# it happens before any torch.cuda call: pin this rank to its GPU (so the script's `torch.cuda.device_count() > 1` -> nn.DataParallel branch,
+# CVC-YOLOv3/train.py:193-195, is not taken), join the process group, and let the models shard batches / all-reduce gradients themselves
+# (mdcv/parallel.py: enable_auto_data_parallel).  A plain single-process run is untouched.
+from mdcv.parallel import enable_auto_data_parallel  # noqa: E402
+enable_auto_data_parallel()
+
 from mdcv.rektnet.keypoint_net import KeypointNet  # noqa: E402,F401
 
 __all__ = ["KeypointNet"]

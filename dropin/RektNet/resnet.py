@@ -9,6 +9,9 @@ _REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _REPO not in sys.path:
     sys.path.append(_REPO)             # appended, not prepended: nothing of the reference's own tree is shadowed
 
+from mdcv.parallel import enable_auto_data_parallel  # noqa: E402  (see keypoint_net.py: torchrun on the unchanged train_eval.py)
+enable_auto_data_parallel()
+
 from mdcv.rektnet.resnet import ResNet  # noqa: E402,F401
 
 __all__ = ["ResNet"]

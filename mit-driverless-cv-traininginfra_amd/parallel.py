@@ -171,3 +171,69 @@ def shard_batch(t, rank, world):
     """Rank r's contiguous shard of the batch dimension (DataParallel's scatter on dim 0)."""
     per = t.shape[0] // world
     return t[rank * per:(rank + 1) * per]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# torchrun-transparent data parallel: `python -m torch.distributed.run --nproc-per-node N train.py ...` on the UNCHANGED reference script.
+#
+# The reference's only multi-GPU path is `if torch.cuda.device_count() > 1: model = nn.DataParallel(model)` (CVC-YOLOv3/train.py:193-195): one
+# process, the module tree replicated onto every GPU per forward.  The MI355X-native path is one process per GPU, so under torchrun the
+# drop-in modules (dropin/CVC-YOLOv3/models.py, dropin/RektNet/*.py) call enable_auto_data_parallel() when they are imported -- i.e. before
+# the script touches a device:
+#   * the process is pinned to ITS GPU by HIP_VISIBLE_DEVICES, so torch.cuda.device_count() == 1 and train.py:193 does not wrap the model;
+#   * the process group is initialised from torchrun's environment (backend MDCV_DP_BACKEND, default "nccl" == RCCL);
+#   * the model takes rank r's shard of each (imgs, targets) batch inside forward() -- DataParallel's scatter on dim 0 (train.py:68) --,
+#     attaches the overlapped gradient all-reduce (SUM, like `losses[0].sum().backward()` over the replicas' losses, train.py:70) on its
+#     first training step and joins the comm stream at the END of backward(), so the script's stock `optimizer.step()` (train.py:72) reads
+#     reduced gradients.
+# MDCV_AUTO_DP=0 switches all of it off; MDCV_DP_DEVICE=<index> overrides the device choice (tests: several ranks on one GPU over gloo).
+_AUTO = None
+
+
+def enable_auto_data_parallel():
+    """-> {"rank", "world", "local_rank"} when this process is one of several torchrun ranks (and MDCV_AUTO_DP != 0), else None.  Idempotent."""
+    global _AUTO
+    import os
+    if _AUTO is not None:
+        return _AUTO or None
+    world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    if world <= 1 or "LOCAL_RANK" not in os.environ or "RANK" not in os.environ or os.environ.get("MDCV_AUTO_DP", "1") == "0":
+        _AUTO = False
+        return None
+    rank, local = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+    if not torch.cuda.is_initialized():
+        override = os.environ.get("MDCV_DP_DEVICE")
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+        devs = [d for d in vis.split(",") if d.strip()] if vis else None
+        choice = override if override is not None else (devs[local] if devs and local < len(devs) else str(local))
+        os.environ["HIP_VISIBLE_DEVICES"] = choice              # one visible device: train.py:193 sees device_count() == 1
+        os.environ.pop("CUDA_VISIBLE_DEVICES", None)            # (both filters would apply one after the other)
+    else:
+        import warnings
+        warnings.warn("mdcv: the GPU runtime was initialised before the drop-in modules were imported; this rank cannot hide the other GPUs "
+                      "any more (import `models` / `keypoint_net` before the first torch.cuda call)", RuntimeWarning, stacklevel=2)
+        if torch.cuda.device_count() > local:
+            torch.cuda.set_device(local)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # RCCL across processes needs dmabuf IPC on this driver (DESIGN 7)
+    if not dist.is_initialized():
+        dist.init_process_group(os.environ.get("MDCV_DP_BACKEND", "nccl"), rank=rank, world_size=world)
+    _AUTO = {"rank": rank, "world": world, "local_rank": local}
+    return _AUTO
+
+
+def auto_state():
+    """The auto-data-parallel state set by enable_auto_data_parallel() (None when off)."""
+    return _AUTO or None
+
+
+def auto_shard(*tensors):
+    """Rank r's shard of every tensor whose batch (dim 0) divides by the world size; other tensors (and everything when the mode is off) pass
+    through.  -> (tuple of tensors, sharded?)"""
+    st = auto_state()
+    if st is None:
+        return tensors, False
+    w, r = st["world"], st["rank"]
+    if not all(t is None or (t.dim() >= 1 and t.shape[0] >= w and t.shape[0] % w == 0) for t in tensors):
+        return tensors, False
+    return tuple(None if t is None else shard_batch(t, r, w) for t in tensors), True
+

@@ -114,6 +114,8 @@ class KeypointNet(FlatParamsMixin, nn.Module):
         _lib.require_gpu(x)
         if not self._flat_ok():
             self._flatten()
+        if self.training and torch.is_grad_enabled() and not self.onnx_mode:
+            (x,) = self._auto_dp_shard(x)        # torchrun on the unchanged train_eval.py: rank r's shard (parallel.enable_auto_data_parallel)
         B, _, H, W = x.shape
         if (H, W) != tuple(self.image_size):
             raise ValueError(f"KeypointNet was built for image_size={self.image_size}, got {(H, W)}")

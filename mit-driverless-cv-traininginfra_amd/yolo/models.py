@@ -397,7 +397,7 @@ class FlatParamsMixin:
             "BatchNorm / build_targets + summed-gradient semantics as DataParallel), or hide the other GPUs from a single-process run "
             "(HIP_VISIBLE_DEVICES=0).  See INTEGRATION.md §1.")
 
-    _TRANSIENT = ("_plans", "_pipe_plan", "_last_train_plan", "_dp_reducer", "_pflat", "_gflat", "_flat_ptrs", "_goff", "_plist", "_flat_parent")
+    _TRANSIENT = ("_plans", "_pipe_plan", "_last_train_plan", "_dp_reducer", "_dp_auto", "_pflat", "_gflat", "_flat_ptrs", "_goff", "_plist", "_flat_parent")
 
     def _state_without_plans(self):
         d = {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
@@ -489,6 +489,17 @@ class FlatParamsMixin:
                 torch.cuda.current_stream().wait_event(ev)
                 plan._group_events[k] = None
 
+    def _auto_dp_shard(self, *tensors):
+        """Under torchrun with the drop-in modules (parallel.enable_auto_data_parallel): rank r's shard of a training batch -- nn.DataParallel's
+        scatter on dim 0, reference train.py:68 / :193-195 -- and, on first use, the overlapped gradient all-reduce attached to this model.
+        Off (the usual case): the tensors pass through."""
+        from ..parallel import auto_shard, GradAllReducer
+        out, sharded = auto_shard(*tensors)
+        if sharded and getattr(self, "_dp_reducer", None) is None:
+            GradAllReducer.attach(self)
+            self._dp_auto = True                             # backward() joins the comm stream itself: the script calls a stock optimizer.step()
+        return out
+
     def _run_backward(self, plan, gout):
         self._last_train_plan = plan
         pl = self._plist
@@ -507,6 +518,8 @@ class FlatParamsMixin:
             self._gflat.add_(keep)
         if red is not None:
             red.backward_done()
+            if getattr(self, "_dp_auto", False):
+                red.finish()                                 # (auto data parallel: nobody else will order the optimizer behind the exchange)
         for p in pl:
             v = self._grad_view(p)
             if p.grad is None:
@@ -580,6 +593,8 @@ class Darknet(FlatParamsMixin, nn.Module):
         _lib.require_gpu(x)
         if not self._flat_ok():
             self._flatten()
+        if targets is not None and self.training and torch.is_grad_enabled():
+            x, targets = self._auto_dp_shard(x, targets)     # torchrun on the unchanged train.py: rank r's shard (parallel.enable_auto_data_parallel)
         B, _, H, W = x.shape
         T = targets.shape[1] if targets is not None else 0
         key = (B, H, W, T, targets is not None, self.training, self.precision, x.device.index)
