@@ -311,13 +311,27 @@ class _NetPlan(Plan):
             roles = self._bwd_roles = self._classify_bwd()
         ev = ctypes.c_void_p()
         armed = False
+        pending = []                                           # deferred slab reduces (role 3): they ride behind the NEXT fork
+        overlapped_dp = self.on_ready is not None
+
+        def flush():
+            for pfn, pargs in pending:
+                prc = pfn(*pargs, ss)
+                if prc:
+                    raise _lib.MdcvError(f"{getattr(pfn, '__name__', pfn)} returned {prc}")
+            del pending[:]
         for (fn, args), role in zip(self.bwd, roles):
-            if role == 2:                                      # a weight gradient: side stream, behind "dY(L), X(L) ready"
+            if role == 3 and not overlapped_dp:                # slab reduce of a one-launch 1x1 backward: its producer is already in the main
+                pending.append((fn, args))                     # queue, so ANY later fork orders it; no fork (and no 5 us of main queue) of its own
+                continue
+            if role >= 2:                                      # a weight gradient: side stream, behind "dY(L), X(L) ready"
                 if armed:
                     L.check(L.stream_fork_wait(ss, ev), "stream_fork_wait")           # the kernel in front of it carried the event
                     armed = False
                 else:
                     L.check(fork(st, ss, self.fork_device_scope), "stream_fork")
+                if pending:
+                    flush()
                 rc = fn(*args, ss)
                 used = True
             else:
@@ -327,6 +341,10 @@ class _NetPlan(Plan):
                 rc = fn(*args, st)
             if rc:
                 raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
+        if pending:
+            L.check(fork(st, ss, self.fork_device_scope), "stream_fork")
+            flush()
+            used = True
         if used:
             L.check(fork(ss, st, self.fork_device_scope), "stream_fork")              # main waits for "all gradients done"
 
@@ -334,13 +352,20 @@ class _NetPlan(Plan):
     # kernel and its successor wherever a fork sat between them, 0.0 - 0.6 us elsewhere; 71 forks per YOLOv3 backward).  Where the call in
     # front of a weight gradient is ONE kernel launch, that kernel's own dispatch packet carries the event (mdcv_stream_fork_arm) instead.
     fork_on_dispatch = True
+    defer_slab_reduce = True           # the slab reduces of the one-launch 1x1 backward wait for the next weight gradient's fork (32 forks fewer per YOLOv3 step)
 
     def _classify_bwd(self):
-        """per backward-list entry: 2 = weight gradient (side stream), 1 = single-kernel library call right in front of one, 0 = other"""
+        """per backward-list entry: 2 = weight gradient (side stream), 3 = slab reduce that may wait for the next fork, 1 = single-kernel library call
+        right in front of a weight gradient, 0 = other"""
         L = self.L
         single = (L.bn_act_bwd_apply, L.pw_bwd)
         n = len(self.bwd)
         roles = [2 if getattr(fn, "__name__", "") == "conv2d_wgrad" else 0 for fn, _ in self.bwd]
+        if self.defer_slab_reduce:
+            for i, (fn, _) in enumerate(self.bwd):
+                info = getattr(fn, "info", None)
+                if roles[i] == 2 and info is not None and len(info) > 7 and info[7] == 0:        # k == 0: the reduce alone (engine._emit_pw_bwd1)
+                    roles[i] = 3
         if self.fork_on_dispatch:
             for i in range(n - 1):
                 if roles[i] == 0 and roles[i + 1] == 2 and any(self.bwd[i][0] is f for f in single):

@@ -37,10 +37,12 @@ def apply_build(codes):
     engine.Plan.pw_bwd1 = BUILD_DEFAULTS["pb"]
     from mdcv.yolo import models as _ym0
     _ym0._NetPlan.fork_on_dispatch = True
+    _ym0._NetPlan.defer_slab_reduce = True
     for c in codes:
         if c and c[0] == "K":          # K0 / K1: side-stream forks as event records on the main queue / carried by the producing kernel's dispatch packet
             from mdcv.yolo import models as _ym
-            _ym._NetPlan.fork_on_dispatch = bool(int(c[1:]))
+            _ym._NetPlan.fork_on_dispatch = bool(int(c[1:]) & 1)
+            _ym._NetPlan.defer_slab_reduce = not bool(int(c[1:]) & 2)               # K3: forks on dispatch, slab reduces NOT deferred
         if c and c[0] == "B":          # B0 / B1: 1x1 layers' backward as data gradient + weight gradient + reduce / in one launch (csrc/pw_bwd.hip)
             engine.Plan.pw_bwd1 = bool(int(c[1:]))
         if c and c[0] == "Y":          # Y0 / Y1: forward statistics as partial rows + finalize launch / through exact accumulators (csrc/exact_acc.h)
