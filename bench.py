@@ -279,13 +279,15 @@ def roofline_objects(krec, precision, traffic, in_step=None):
     return top, rows
 
 
-def load_traffic():
-    """Newest profiles/rNN_pmc_hbm_traffic.json (scripts/profile_round.sh) -- only if it was measured with THIS tree's kernels."""
+def load_traffic(workload="yolo"):
+    """Newest profiles/rNN_pmc_hbm_traffic.json (yolo) / rNN_rektnet_pmc_hbm_traffic.json (scripts/profile_round.sh) -- only if it was measured
+    with THIS tree's kernels."""
     import glob
     from mdcv._fingerprint import kernel_fingerprint
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic.json")))
+    name = "pmc_hbm_traffic.json" if workload == "yolo" else f"{workload}_pmc_hbm_traffic.json"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + name)))
     if not files:
-        return None, "no profiles/rNN_pmc_hbm_traffic.json"
+        return None, "no profiles/rNN_" + name
     t = json.load(open(files[-1]))
     fp = kernel_fingerprint()
     if t.get("fingerprint") != fp:
@@ -488,8 +490,8 @@ def build_line(a, world, primary, result, extra, cpu_baseline):
                                          % a.joint_batch}[primary],
                    "global_batch": {"yolo": a.yolo_batch, "rektnet": a.rekt_batch, "postprocess": a.post_batch, "joint": a.joint_batch}[primary] * world,
                    "parallelism": f"dp{world}", "hipgraph": bool(a.graph), "optimizer": "FusedAdam",
-                   **({"fidelity": "bf16 storage, fp32 accumulate: loss within 5e-3 of the fp32 oracle, per-layer gradient cosine vs fp32 >= the reference under "
-                                   "torch.autocast(bf16) - 0.02 (0.51 at conv 0, 0.9998+ at the heads); the fp32-equivalent rate is fp32_images_per_sec"}
+                   **({"fidelity": "bf16 storage / fp32 accumulate; per-layer grad cosine vs fp32 >= reference-under-autocast - 0.02 (0.51 at conv 0); "
+                                   "fp32-equivalent rate: fp32_images_per_sec"}
                       if (primary == "yolo" and a.precision == "bf16") else {})},
         "roofline": {k: roof[k] for k in ROOFLINE_KEYS if k in roof} if roof else None,
         "cpu_baseline": cpu_baseline,
@@ -501,6 +503,42 @@ def build_line(a, world, primary, result, extra, cpu_baseline):
     if env:
         line["env_overrides"] = env
     return line
+
+
+def measured_peaks():
+    """About one second of probes on this box ("confirm on the box"): the dense bf16 MFMA rate (mdcv_probe_mfma: register-operand
+    v_mfma_f32_16x16x32_bf16, 8 waves per CU) and the HBM rate of a 1 GiB device-to-device copy (read + write bytes).  Printed beside the
+    spec peaks the roofline fractions are priced against; never used to re-price them."""
+    import ctypes
+    from mdcv import _lib
+    L = _lib.lib()
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        sink = torch.zeros(4, device="cuda")
+        fl = ctypes.c_double()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 0.0
+        for iters in (2000, 20000, 20000, 20000):                 # (first: warm-up / clock ramp)
+            e0.record()
+            L.check(L.probe_mfma(ncu * 2, iters, sink.data_ptr(), ctypes.byref(fl), st), "probe_mfma")
+            e1.record()
+            e1.synchronize()
+            best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").fill_(1.0)
+        dst = torch.empty_like(src)
+        gbs = 0.0
+        for _ in range(4):
+            e0.record()
+            dst.copy_(src)
+            e1.record()
+            e1.synchronize()
+            gbs = max(gbs, 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del src, dst
+        return {"measured_peak_tflops": round(best, 1), "measured_hbm_gbs": round(gbs, 1), "spec_peak_tflops": PEAK_BF16_TFLOPS,
+                "spec_hbm_gbs": PEAK_HBM_GBS, "probe": "mdcv_probe_mfma: %d workgroups x 4 waves, 20000 x 8 MFMAs each; 1 GiB torch copy" % (ncu * 2)}
+    except Exception as e:                                          # noqa: BLE001  (a probe must never take the bench line down)
+        return {"error": repr(e)}
 
 
 def write_detail(line, extra, detail):
@@ -733,10 +771,13 @@ def main():
             rec, krec = kernel_breakdown(kp, plan, rekt_step)
             detail["rektnet_call_ms_per_serial_step"] = {k: round(v[1], 3) for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1])}
             detail["rektnet_kernel_ms_in_step"] = {k: [round(v[0], 2), round(v[1], 4)] for k, v in sorted(in_step.items(), key=lambda kv: -kv[1][1])}
-            top, rows = roofline_objects(krec, a.precision, None, in_step)
+            rtraffic, rwhy = load_traffic("rektnet") if (B == 256 and a.precision == "bf16") else (None, "non-default workload")
+            top, rows = roofline_objects(krec, a.precision, rtraffic, in_step)
             detail["rektnet_roofline_kernels"] = rows
+            if rtraffic:
+                extra["rektnet"]["hbm_bytes_per_step"] = rtraffic.get("total_bytes_per_step")
             if top:
-                top["traffic_source"] = "not collected for this workload"
+                top["traffic_source"] = rtraffic["_file"] if rtraffic else rwhy
                 extra["rektnet"]["dominant_kernel"] = {k: top[k] for k in ("kernel", "bound", "avg_us", "frac", "frac_alone")}
                 if a.workload == "rektnet":
                     result_roof = top
@@ -891,6 +932,8 @@ def main():
                     detail["postprocess_cpu_baseline"] = pb
                     extra["postprocess"]["cpu_images_per_sec"] = pb["value"]
         line = build_line(a, world, primary, result, extra, cb)
+        detail["peaks"] = measured_peaks()
+        line["peaks"] = {k: detail["peaks"].get(k) for k in ("measured_peak_tflops", "measured_hbm_gbs")}
         detail_path = write_detail(line, extra, detail)
         line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
         print(json.dumps(compact(line)))

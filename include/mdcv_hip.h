@@ -258,6 +258,9 @@ int mdcv_event_elapsed_ms(void* start, void* stop, float* ms);
 int mdcv_event_destroy(void* ev);
 /* everything enqueued on `from` so far happens before what is enqueued on `to` afterwards (one event record + one stream wait on a
  * ring event without timing; device_scope != 0: the record releases to device scope, all a consumer on the same GPU needs) */
+/* On-box peak probe: `blocks` workgroups x 4 waves x iters x 8 independent v_mfma_f32_16x16x32_bf16 on register operands; *flops = the FLOP
+ * count of the launch.  Time it with events on `stream`: the dense bf16 MFMA rate this box sustains (spec: ~2.5 PFLOP/s).  sink: >= 1 float. */
+int mdcv_probe_mfma(int blocks, int iters, float* sink, double* flops, void* stream);
 int mdcv_stream_fork(void* from, void* to, int device_scope);
 /* the same ordering without a marker packet in the producer's queue: the next kernel this library launches (exactly one, on `from`) carries
  * the event as its dispatch packet's stop event; mdcv_stream_fork_wait(to, ev) then makes `to` wait for it */

@@ -182,3 +182,38 @@ int mdcv_graph_launch(void* graph_exec, void* stream) { return (int)hipGraphLaun
 int mdcv_graph_destroy(void* graph_exec) { return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec); }
 
 }  // extern "C"
+
+// ---- on-box peak probe (SURVEY 8d "confirm on the box"): bench.py prices the kernels against the guide's spec peaks (2.5 PFLOP/s dense bf16, 8 TB/s)
+// and prints what THIS box sustains beside them.  MFMA: every wave runs `iters` rounds of eight independent v_mfma_f32_16x16x32_bf16 on register
+// operands (no memory in the loop); 2 * 16*16*32 FLOP each.  HBM: the caller times a large device-to-device copy.
+namespace {
+__global__ __launch_bounds__(256) void probe_mfma_kernel(float* __restrict__ sink, int iters) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+  const float seed = (float)(threadIdx.x & 15) * 0.001f;
+  b8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(seed + 0.01f * e); b[e] = (__bf16)(0.5f - seed); }
+  f32x4_t acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+  if (s == 12345.678f) sink[0] = s;                          // (keeps the loop alive; never true)
+}
+}  // namespace
+
+extern "C" {
+/* enqueue the MFMA probe: blocks x 4 waves x iters x 8 MFMAs of 16384 FLOP; returns the FLOP count through *flops (host side) */
+int mdcv_probe_mfma(int blocks, int iters, float* sink, double* flops, void* stream) {
+  if (blocks < 1 || iters < 1 || !sink) return MDCV_EARG;
+  MDCV_LAUNCH(probe_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, sink, iters);
+  MDCV_CHECK_LAUNCH();
+  if (flops) *flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2.0 * 16.0 * 16.0 * 32.0;
+  return MDCV_OK;
+}
+}  // extern "C"

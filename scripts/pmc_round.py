@@ -17,6 +17,8 @@ from bench import short_symbol                      # noqa: E402
 from mdcv._fingerprint import kernel_fingerprint    # noqa: E402
 
 tmp, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+wl = sys.argv[4] if len(sys.argv) > 4 else "yolo"
+pre = tag if wl == "yolo" else f"{tag}_{wl}"               # r05_pmc_hbm_traffic.json (yolo: the name bench.py has always looked for) / r05_rektnet_pmc_...
 STEPS = 4                                            # --steps 2 --warmup 1 + the final loss step
 
 
@@ -51,11 +53,11 @@ for k in set(fe) | set(wr):
                    "write_bytes_per_launch": 1024.0 * w[0] / max(w[1], 1)}
 tot = {k: (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches_per_step"] for k, v in kern.items()}
 json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes with --kernel-trace only, MDCV_WGRAD_STREAM=0, of `python bench.py --workload "
-                    "yolo --steps 2 --warmup 1 --no-breakdown` (4 training steps, batch 32, bf16); KB -> bytes; FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported",
-           "fingerprint": fp, "tag": tag, "steps": STEPS, "total_bytes_per_step": sum(tot.values()),
+                    + wl + " --steps 2 --warmup 1 --no-breakdown` (4 training steps, default batch, bf16); KB -> bytes; FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported",
+           "fingerprint": fp, "tag": tag, "workload": wl, "steps": STEPS, "total_bytes_per_step": sum(tot.values()),
            "bytes_per_step_by_kernel": dict(sorted(((k, round(v)) for k, v in tot.items()), key=lambda kv: -kv[1])),
            "kernels": dict(sorted(kern.items(), key=lambda kv: -tot[kv[0]]))},
-          open(os.path.join(out, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
+          open(os.path.join(out, f"{pre}_pmc_hbm_traffic.json"), "w"), indent=1)
 
 mf, du = collect("mfma"), durations("mfma")
 rows = {}
@@ -70,7 +72,7 @@ for k, c in mf.items():
                "mfma_busy_over_4x_sq_busy": (busy[0] / n) / (4.0 * sq[0] / max(sq[1], 1)) if sq[0] else None}
 json.dump({"_note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (one pass, --kernel-trace only, MDCV_WGRAD_STREAM=0) of the same short "
                     "bench command; per-launch averages per kernel symbol",
-           "fingerprint": fp, "tag": tag,
+           "fingerprint": fp, "tag": tag, "workload": wl,
            "kernels": dict(sorted(rows.items(), key=lambda kv: -(kv[1]["avg_ns_under_pmc"] * kv[1]["launches"])))},
-          open(os.path.join(out, f"{tag}_pmc_mfma_busy.json"), "w"), indent=1)
+          open(os.path.join(out, f"{pre}_pmc_mfma_busy.json"), "w"), indent=1)
 print(json.dumps({"fingerprint": fp, "total_hbm_GB_per_step": sum(tot.values()) / 1e9, "kernels": len(kern)}))
