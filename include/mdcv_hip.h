@@ -20,6 +20,12 @@ extern "C" {
 #define MDCV_EARG (-1)
 #define MDCV_F32 0
 #define MDCV_BF16 1
+/* The library holds NO mutable process state (round 5): a call's result depends on its arguments only.  The dispatch heuristics that were A/B-ed
+ * on the training step (csrc/tune.h: one documented knob each) can be overridden PER CALL through the dtype argument of the convolution and
+ * weight-gradient entry points: bits 0..7 = MDCV_F32 / MDCV_BF16, the bits above = a signed variant code of that entry point's family (0 =
+ * defaults; the code tables are in csrc/tune.h).  Plan-time queries (mdcv_conv2d_stats_rows_geom, mdcv_conv2d_wgrad_splits_geom, ...) take the same
+ * tuned dtype as the launch they size buffers for. */
+#define MDCV_TUNED(dtype, code) (((dtype) & 0xff) | ((code) * 256))
 #define MDCV_ACT_NONE 0
 #define MDCV_ACT_LEAKY 1
 #define MDCV_ACT_RELU 2
@@ -79,11 +85,9 @@ int mdcv_conv2d_stats_rows(int M);      /* generic kernels: one row per 128 outp
  * pad-1 shift kernel walks a padded pixel stream and writes more rows than M / 128; every row it returns is written). */
 int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil,
                                 int in_ldc);
-int mdcv_conv2d_set_variant(int v);   /* tuning hook: force a tile configuration for Nout > 64 (-1 = heuristic) */
 
 /* weight gradient: dW (OIHW fp32, real channel counts) = dY^T * im2col(X).  ws = splits*Cout*KH*KW*Cin floats of scratch. */
 int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot);
-int mdcv_conv2d_wgrad_set_variant(int v);   /* tuning hook: step size / ring depth of the bf16 weight-gradient kernel */
 /* number of fp32 slabs for the kernel mdcv_conv2d_wgrad picks for this geometry (3x3 stride-1 layers with 128-multiple channel
  * counts run a kernel whose kw taps share one activation tile and that wants its own split); ws = splits*Cout*KH*KW*Cin floats. */
 int mdcv_conv2d_wgrad_splits_geom(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride,
@@ -284,7 +288,6 @@ int mdcv_graph_destroy(void* graph_exec);
  *      (CVC-YOLOv3/models.py:48-72 + the shortcut of :322-327), the pair  mdcv_bn_act_fwd + mdcv_conv2d  by one launch with identical results.
  *      K = channels of the transformed operand (multiple of 32, K/8 divides 256, 64 <= K <= 1024), N = output channels (multiple of 8). */
 int mdcv_pw_rows(long long M, int K);          /* rows of stats_partial the entry points below write: one per pixel tile */
-int mdcv_pw_set_variant(int v);                /* tuning hook: 64 / 32 / 16 pixels per tile, 0 = heuristic */
 /* forward: z = act(y * scale + shift) (+ resid) -> z_out ; out = z . W^T (+ bias) ; stats_partial (may be NULL): [mdcv_pw_rows][2][N] */
 int mdcv_pw_conv_fwd(int dtype, const void* y, int ldy, const float* scale, const float* shift, const void* resid, int ldr, int act,
                      float slope, void* z_out, int ldz, const void* w_packed, const float* bias, void* out, int out_ldc,

@@ -14,6 +14,11 @@ HEADER = os.path.join(ROOT, "include", "mdcv_hip.h")
 LIB_PATH = os.path.join(_HERE, "libmdcv_hip.so")
 
 F32, BF16 = 0, 1
+
+
+def tuned(dtype, code):
+    """dtype argument carrying a per-call variant code (include/mdcv_hip.h MDCV_TUNED; csrc/tune.h lists the codes; 0 = defaults)"""
+    return (dtype & 0xff) | (int(code) * 256)
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 
 _CT = {
@@ -64,12 +69,6 @@ class _Lib:
             fn.restype = ret
             fn.argtypes = argt
             setattr(self, name[len("mdcv_"):], fn)
-        for v in os.environ.get("MDCV_CONV_VARIANT", "").split(","):      # tuning hook for in-network A/B runs (see conv2d_set_variant)
-            if v.strip():
-                self.cdll.mdcv_conv2d_set_variant(int(v))
-        for v in os.environ.get("MDCV_WGRAD_VARIANT", "").split(","):
-            if v.strip():
-                self.cdll.mdcv_conv2d_wgrad_set_variant(int(v))
 
     def check(self, rc, what=""):
         if rc != 0:

@@ -4,6 +4,8 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include "tune.h"
+
 typedef unsigned short bf16_t;   // raw bf16 bits; all arithmetic is done in fp32
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -19,17 +21,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // from which the symbol rocprofv3 prints is recovered.  Off: one predictable branch per launch.
 extern int mdcv_g_prof;
 void mdcv_prof_new(const void* fn, hipEvent_t* e0, hipEvent_t* e1);
-extern hipEvent_t mdcv_g_arm;      // mdcv_stream_fork_arm: the event the NEXT launch carries as its stop event (cleared by that launch)
+extern thread_local hipEvent_t mdcv_t_arm;      // mdcv_stream_fork_arm: the event the NEXT launch carries as its stop event (cleared by that launch)
 #define MDCV_LAUNCH(kern, grid, block, lds, st, ...)                                                      \
   do {                                                                                                    \
     if (mdcv_g_prof) {                                                                                    \
       hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                          \
       mdcv_prof_new(reinterpret_cast<const void*>(kern), &e0__, &e1__);                                   \
       hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0__, e1__, 0, __VA_ARGS__);                      \
-      if (mdcv_g_arm) { (void)hipEventRecord(mdcv_g_arm, st); mdcv_g_arm = nullptr; }   /* (profiling: a plain record behind it) */ \
-    } else if (mdcv_g_arm) {                                                                              \
-      hipEvent_t ea__ = mdcv_g_arm;                                                                       \
-      mdcv_g_arm = nullptr;                                                                               \
+      if (mdcv_t_arm) { (void)hipEventRecord(mdcv_t_arm, st); mdcv_t_arm = nullptr; }   /* (profiling: a plain record behind it) */ \
+    } else if (mdcv_t_arm) {                                                                              \
+      hipEvent_t ea__ = mdcv_t_arm;                                                                       \
+      mdcv_t_arm = nullptr;                                                                               \
       hipExtLaunchKernelGGL(kern, grid, block, lds, st, nullptr, ea__, 0, __VA_ARGS__);                   \
     } else {                                                                                              \
       hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                        \

@@ -41,34 +41,7 @@ struct ConvArgs {
 };
 
 #if MDCV_CONV_PART == 0
-int g_conv_no_ut = 0;    // tuning/A-B: 1 disables the uniform-tap address path
-int g_conv_tall_narrow = 256; // 256-row tiles for Nout <= 64 from this many Ki output positions (set_variant 2000 + M_min/1024; 2000 = off): half as
-                              // many workgroup prologues / epilogues on the 80^2 x 256 and 208^2..416^2 x 32 tensors.  Same-box A/B: RektNet +0.65 %, YOLOv3 +0.2 %
-int g_conv_deep_narrow = 1;  // 128x64 tiles of the 33..64-channel layers take the 3-stage ring from this many K steps (set_variant 30 + nk_min;
-                             // 30 = never).  Same-box A/B: RektNet 29.93k -> 30.17k img/s, YOLOv3 +0.3 %
-int g_conv_deep_small = 8;   // 128x128 and 128x64 tiles take the 3-stage DMA ring from this many K steps (set_variant 60 + nk_min; 60 = never).
-                             // Same-box A/B of the YOLOv3 step: never 2031, from 4 steps 2045, from 8 2050, from 16 2045, from 32 2034 img/s
-int g_conv_fuse_narrow = 1;  // (set_variant 92 = off) 1x1 data gradients with fused BatchNorm sums take 128x64 tiles on the 3-stage ring: their store loop (loads of
-                             // the shortcut gradient and y, sums, partial-row flush) is serial per workgroup, and three or four narrow workgroups per CU overlap it
-                             // better than one or two wide ones.  Alone (round-2 A/B): 52^2 60 -> 47 us, 104^2 103 -> 78, 26^2 35 -> 32, 13^2 21.5 -> 20
-int g_conv_variant = -1;   // -1: heuristic ; >= 0: forced tile configuration for wide layers (tuning / A-B benchmarking)
-int g_conv_tall_s2 = 1;      // (set_variant 18 = off; +0.3 % on the YOLOv3 step) the tall narrow tiles for the parity-class launches too
-int g_conv_deep_s2 = 1;      // (set_variant 20 = off; +0.6 % on the YOLOv3 step, same-box A/B) 3-stage ring for the parity-class launches of the stride-2 data gradients
-int g_conv_s2_allcls = 1;    // (set_variant 16 = off) one launch for the four parity classes of a stride-2 data gradient (conv_glds_kernel ALLCLS)
-int g_conv_s2_split = 512;   // ALLCLS grids below this many 128 x 128 tiles run two workgroups per tile (set_variant 4000 + n; 26->52 and 13->26 at batch 32)
-int g_conv_s2_split_on = 1;  // (set_variant 14 = off: those layers go back to four class launches; 15 = on)
 #else
-extern int g_conv_no_ut;
-extern int g_conv_tall_narrow;
-extern int g_conv_deep_narrow;
-extern int g_conv_deep_small;
-extern int g_conv_fuse_narrow;
-extern int g_conv_variant;
-extern int g_conv_tall_s2;
-extern int g_conv_deep_s2;
-extern int g_conv_s2_allcls;
-extern int g_conv_s2_split;
-extern int g_conv_s2_split_on;
 #endif
 // the per-part dispatch entry points (each defined by exactly one part)
 int mdcv_cd_bf16_fwd(const ConvArgs& a, hipStream_t st, int B);
@@ -889,7 +862,7 @@ template <typename T, int MODE, int BM, int BN, int WM, int WN, int STAGES = 2, 
 int launch_conv_glds(const ConvArgs& a, hipStream_t st, int B) {
   constexpr int BK = 4 * ET<T>::VEC;
   // uniform-tap fast path: K tiles never straddle a tap; the generic stride-2 dgrad (MODE 1, stride 2) keeps the per-lane cursor
-  const bool ut = (a.Cin % BK == 0) && !(MODE == 1 && a.stride != 1) && g_conv_no_ut == 0;
+  const bool ut = (a.Cin % BK == 0) && !(MODE == 1 && a.stride != 1) && TUNE().conv_no_ut == 0;
   if constexpr (ALLCLS) {                       // (bf16 layers of a Darknet: Cin is a multiple of 32; others keep the four launches)
     if (!ut) return MDCV_EARG;
     return launch_conv_glds_ut<T, MODE, BM, BN, WM, WN, STAGES, true, true>(a, st, B);
@@ -906,13 +879,13 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
   const bool small = (long long)B * a.Hin * a.Win * a.in_ldc * (long long)sizeof(T) < (1LL << 31) &&
                      (long long)a.Nout * a.Ktot * (long long)sizeof(T) < (1LL << 31);
   if (a.Nout > 64) {
-    int v = g_conv_variant;
+    int v = TUNE().conv_variant;
     if (v < 0) {   // measured on MI355X (scripts/conv_ab.py): tall tiles once the grid is >= 4 waves of CUs, half-width tiles
       const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);   // when 128x128 would leave CUs idle
       const int nk = a.Ktot / (4 * ET<T>::VEC);      // long K loops profit from the 3-stage DMA ring (scripts/conv_ab.py)
       v = t128 >= 1024 ? 11 : (nk >= 100 ? 9 : (t128 >= 300 ? 6 : 7));
-      if (g_conv_fuse_narrow && MODE == 1 && a.fuse.y && a.KH == 1 && a.KW == 1) v = 10;
-      if (g_conv_deep_small && nk >= g_conv_deep_small && (v == 6 || v == 7)) v += 3;   // 3-stage ring for the mid / sparse grids too
+      if (TUNE().conv_fuse_narrow && MODE == 1 && a.fuse.y && a.KH == 1 && a.KW == 1) v = 10;
+      if (TUNE().conv_deep_small && nk >= TUNE().conv_deep_small && (v == 6 || v == 7)) v += 3;   // 3-stage ring for the mid / sparse grids too
     }
     if (!BF && small) v = v == 8 ? 6 : (v == 11 ? 9 : v);   // the 8-wave 256-row tiles exist in bf16 only: fp32 takes the 128x128 LDS-DMA tiles
                                                                            // (the register-staged fallback has no inference epilogue and is slower)
@@ -934,15 +907,15 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
     }
     return launch_conv<T, MODE, 128, 128, 2, 2, 1>(a, st);
   }
-  const bool dma = small && g_conv_variant != 0;      // variant 0 forces the register-staged kernels everywhere (A/B)
+  const bool dma = small && TUNE().conv_variant != 0;      // variant 0 forces the register-staged kernels everywhere (A/B)
   if constexpr (BF) {
-    if (dma && g_conv_tall_narrow && a.M >= g_conv_tall_narrow * 1024) {   // tall tiles for the narrow layers of large images
+    if (dma && TUNE().conv_tall_narrow && a.M >= TUNE().conv_tall_narrow * 1024) {   // tall tiles for the narrow layers of large images
       if (a.Nout > 32) return launch_conv_glds<T, MODE, 256, 64, 4, 2, 3>(a, st, B);
       if (a.Nout > 16) return launch_conv_glds<T, MODE, 256, 32, 4, 1>(a, st, B);
       return launch_conv_glds<T, MODE, 256, 16, 4, 1>(a, st, B);
     }
   }
-  if (dma && g_conv_deep_narrow && a.Ktot / (4 * ET<T>::VEC) >= g_conv_deep_narrow) {
+  if (dma && TUNE().conv_deep_narrow && a.Ktot / (4 * ET<T>::VEC) >= TUNE().conv_deep_narrow) {
     if (a.Nout > 32) return launch_conv_glds<T, MODE, 128, 64, 2, 2, 3>(a, st, B);
   }
   if (a.Nout > 32) return dma ? launch_conv_glds<T, MODE, 128, 64, 2, 2>(a, st, B) : launch_conv<T, MODE, 128, 64, 2, 2, (BF ? 2 : 1)>(a, st);
@@ -955,7 +928,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st, int B) {
 // all four classes in one launch: same tile choice as the per-class dispatch below (a.M = positions of ONE class)
 static int dispatch_dgrad_s2_all(const ConvArgs& a, hipStream_t st, int B) {
   typedef bf16_t T;
-  if (g_conv_tall_s2 && g_conv_tall_narrow && a.Nout <= 64 && a.M >= g_conv_tall_narrow * 1024) {
+  if (TUNE().conv_tall_s2 && TUNE().conv_tall_narrow && a.Nout <= 64 && a.M >= TUNE().conv_tall_narrow * 1024) {
     if (a.Nout > 32) return launch_conv_glds<T, 2, 256, 64, 4, 2, 3, true>(a, st, B);
     if (a.Nout > 16) return launch_conv_glds<T, 2, 256, 32, 4, 1, 2, true>(a, st, B);
     return MDCV_EARG;
@@ -964,8 +937,8 @@ static int dispatch_dgrad_s2_all(const ConvArgs& a, hipStream_t st, int B) {
   // 26->52 (338 tiles of 128 x 128: one sparse round of long workgroups) 136 -> 183 and 13->26 140 -> 139: only grids of >= 512 tiles take it.
   const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
   if (a.Nout <= 64) return MDCV_EARG;
-  if (t128 < g_conv_s2_split) {                    // sparse grids: two workgroups per tile (4 + 5 tap-GEMMs), see conv_glds_kernel
-    if (!g_conv_s2_split_on) return MDCV_EARG;
+  if (t128 < TUNE().conv_s2_split) {                    // sparse grids: two workgroups per tile (4 + 5 tap-GEMMs), see conv_glds_kernel
+    if (!TUNE().conv_s2_split_on) return MDCV_EARG;
     ConvArgs c = a;
     c.cls_split = 1;
     return launch_conv_glds<T, 2, 128, 128, 2, 2, 3, true>(c, st, B);
@@ -977,13 +950,13 @@ static int dispatch_dgrad_s2_all(const ConvArgs& a, hipStream_t st, int B) {
 template <typename T>
 int dispatch_dgrad_s2(const ConvArgs& a, hipStream_t st, int B) {
   if constexpr (sizeof(T) == 2) {
-    if (g_conv_tall_s2 && g_conv_tall_narrow && a.Nout <= 64 && a.M >= g_conv_tall_narrow * 1024) {
+    if (TUNE().conv_tall_s2 && TUNE().conv_tall_narrow && a.Nout <= 64 && a.M >= TUNE().conv_tall_narrow * 1024) {
       if (a.Nout > 32) return launch_conv_glds<T, 2, 256, 64, 4, 2, 3>(a, st, B);
       if (a.Nout > 16) return launch_conv_glds<T, 2, 256, 32, 4, 1>(a, st, B);
       return launch_conv_glds<T, 2, 256, 16, 4, 1>(a, st, B);
     }
   }
-  if (g_conv_deep_s2 && a.Nout > 32) {
+  if (TUNE().conv_deep_s2 && a.Nout > 32) {
     const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.Nout, 128);
     if (a.Nout > 64) {
       if (sizeof(T) == 2 && t128 >= 1024) return launch_conv_glds<T, 2, (sizeof(T) == 2 ? 256 : 128), 128, (sizeof(T) == 2 ? 4 : 2), 2, 3>(a, st, B);
@@ -1690,8 +1663,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
   }
 }
 
-int g_wgrad_slots = 512;   // target block count of the generic weight-gradient kernel (tuning hook 20000 + n)
-int g_wgrad_variant = 0;    // 0: default dispatch ; 4: generic address path ; 5: wide tile everywhere ; 8 / 9 / 10 / 11: kernel-family choices (use_wgrad_*)
 
 template <int BP, int STAGES, bool SAME>
 static int launch_wgrad_dma_t(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
@@ -1724,16 +1695,16 @@ static int launch_wgrad_narrow_t(const WgradArgs& a, unsigned grid, hipStream_t 
 }
 static int launch_wgrad_dma(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
   const bool same = a.stride == 1 && a.Hin == a.Hout && a.Win == a.Wout;
-  if (a.Cout <= 32 && g_wgrad_variant != 5)                       // (variant 5: the wide tile for narrow layers too, A/B)
+  if (a.Cout <= 32 && TUNE().wgrad_variant != 5)                       // (variant 5: the wide tile for narrow layers too, A/B)
     return same ? launch_wgrad_narrow_t<true, 4>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 4>(a, grid, st, dyb, xb);
-  if (g_wgrad_variant == 4) return launch_wgrad_dma_t<64, 2, false>(a, grid, st, dyb, xb);        // generic address path (A/B)
+  if (TUNE().wgrad_variant == 4) return launch_wgrad_dma_t<64, 2, false>(a, grid, st, dyb, xb);        // generic address path (A/B)
   return same ? launch_wgrad_dma_t<64, 2, true>(a, grid, st, dyb, xb) : launch_wgrad_dma_t<64, 2, false>(a, grid, st, dyb, xb);
 }
 
 // all layers in one launch: blockIdx.y selects the layer descriptor, blockIdx.x grid-strides inside it
 // blocks per layer of the batched pack (grid.x; blocks past a layer's tile count exit at once).  With 64, the eight 4.7 M-parameter layers
 // (60 % of YOLOv3's parameters) ran on 64 blocks x 8 tiles each while every other block had long finished: 327 us for 0.5 GB.
-unsigned g_pack_blocks = 256;
+constexpr unsigned kPackBlocks = 256;
 struct PackDesc { const float* w; void* wf; void* wd; int Cout, Cin, KK, Cout_pad, Cin_pad; int pad_[3]; const float* bias; float* bias_pad; };   // 72 bytes
 // Tile = 16 output channels x up to 64 input channels x all taps, read from OIHW as contiguous runs (one run per output
 // channel), transposed through LDS and written as  wf[co][tap][ci .. ci+63]  (128-byte runs) and  wd[ci][tap][co .. co+15].
@@ -1916,13 +1887,13 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   // stride-2 data gradient: 4 launches, one per output-parity class, each visiting only its live taps (no masked MACs)
   const bool small = (long long)B * Hin * Win * in_ldc * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31) &&
                      (long long)Nout * KH * KW * Cin * (dtype == MDCV_BF16 ? 2 : 4) < (1LL << 31);
-  if (mode == 1 && stride == 2 && dil == 1 && small && (g_conv_variant != 0 || fuse)) {
+  if (mode == 1 && stride == 2 && dil == 1 && small && (TUNE().conv_variant != 0 || fuse)) {
     // 32- / 64-channel outputs (208 -> 416, 104 -> 208: HBM-bound): the shift kernel's stride-2 form, whole output rows per store (conv_shift.hip MODE 3)
-    if (!bias && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win && g_conv_variant < 0 &&
+    if (!bias && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win && TUNE().conv_variant < 0 &&
         mdcv_shift_s2_dgrad_eligible(dtype, B, Hin, Win, Cin, Nout, in_ldc))
       return mdcv_shift_conv(3, in, in_ldc, w_packed, out, out_ldc, nullptr, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Nout, fuse, st, nullptr, 1);
-    if (g_conv_s2_allcls && dtype == MDCV_BF16 && KH == 3 && KW == 3 && pad == 1 && !(Hout & 1) && !(Wout & 1) && (Cin % 32) == 0 && g_conv_deep_s2 &&
-        g_conv_tall_s2) {
+    if (TUNE().conv_s2_allcls && dtype == MDCV_BF16 && KH == 3 && KW == 3 && pad == 1 && !(Hout & 1) && !(Wout & 1) && (Cin % 32) == 0 && TUNE().conv_deep_s2 &&
+        TUNE().conv_tall_s2) {
       ConvArgs c = a;                              // every class: Hs x Ws = Hout/2 x Wout/2 positions; taps and Ktot are set per class in the kernel
       c.Hs = Hout / 2; c.Ws = Wout / 2;
       c.M = B * c.Hs * c.Ws;
@@ -1953,15 +1924,14 @@ static int conv2d_impl(int dtype, int mode, const void* in, int in_ldc, const vo
   }
   // 3x3 / stride 1 / pad 1 on wide layers: nine shifted GEMMs over one LDS-resident activation chunk (conv_shift.hip)
   const bool shift_ok = Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc);
-  if (shift_ok && (g_conv_variant < 0 || fuse))
+  if (shift_ok && (TUNE().conv_variant < 0 || fuse))
     return mdcv_shift_conv(mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hout, Wout, Cin, Nout, fuse, st, epi, dil, xacc);
   if (fuse) {                                     // the fused store loop lives in the LDS-DMA kernels: never fall back to the staged ones
     if (!small) return MDCV_EARG;
-    const int keep = g_conv_variant;
-    if (keep >= 0 && keep < 6) g_conv_variant = -1;
-    const int rc = dtype == MDCV_BF16 ? mdcv_cd_bf16_dgrad(a, st, B) : (dtype == MDCV_F32 ? mdcv_cd_f32_dgrad(a, st, B) : MDCV_EARG);
-    g_conv_variant = keep;
-    return rc;
+    MdcvTune t2 = TUNE();
+    if (t2.conv_variant >= 0 && t2.conv_variant < 6) t2.conv_variant = -1;
+    const TuneScope lds_dma_only(t2);
+    return dtype == MDCV_BF16 ? mdcv_cd_bf16_dgrad(a, st, B) : (dtype == MDCV_F32 ? mdcv_cd_f32_dgrad(a, st, B) : MDCV_EARG);
   }
   if (shift_ok && stats_partial) {   // forced generic kernel on a shift-eligible geometry (A/B runs): the caller sized the partial
     const int r0 = cdiv(a.M, 128), r1 = mdcv_shift_fwd_stats_rows(B, Hout, Wout, Nout, dil);   // rows for the shift kernel; zero the unused tail
@@ -1979,6 +1949,7 @@ int mdcv_conv2d(int dtype, int mode, const void* in, int in_ldc, const void* w_p
                 const float* bias, const void* addsrc, int add_ldc, float* stats_partial,
                 int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout,
                 int KH, int KW, int stride, int pad, int dil, void* stream) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_CONV);
   return conv2d_impl(dtype, mode, in, in_ldc, w_packed, out, out_ldc, bias, addsrc, add_ldc, stats_partial, B, Hin, Win, Cin, Hout, Wout, Nout,
                      KH, KW, stride, pad, dil, nullptr, stream);
 }
@@ -1992,6 +1963,7 @@ int mdcv_xstats_words(int reps, int C) { return reps * XACC_DIGITS * 2 * C; }
 int mdcv_conv2d_xstats(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const float* bias, void* xacc,
                        int reps, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride, int pad, int dil,
                        void* stream) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_CONV);
   const XAccArgs x{reinterpret_cast<long long*>(xacc), reps};
   return conv2d_impl(dtype, 0, in, in_ldc, w_packed, out, out_ldc, bias, nullptr, 0, nullptr, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW,
                      stride, pad, dil, nullptr, stream, nullptr, &x);
@@ -2006,6 +1978,7 @@ int mdcv_conv2d_xstats(int dtype, const void* in, int in_ldc, const void* w_pack
 int mdcv_conv2d_affine_act(int dtype, const void* in, int in_ldc, const void* w_packed, void* out, int out_ldc, const float* scale,
                            const float* shift, const void* addsrc, int add_ldc, int act, float slope, int B, int Hin, int Win, int Cin,
                            int Hout, int Wout, int Nout, int KH, int KW, int stride, int pad, int dil, void* stream) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_CONV);
   if (act < 0 || act > 2) return MDCV_EARG;
   const EpiArgs e{scale, act, slope};
   return conv2d_impl(dtype, 0, in, in_ldc, w_packed, out, out_ldc, shift, addsrc, add_ldc, nullptr, B, Hin, Win, Cin, Hout, Wout, Nout,
@@ -2014,12 +1987,13 @@ int mdcv_conv2d_affine_act(int dtype, const void* in, int in_ldc, const void* w_
 
 int mdcv_conv2d_dgrad_bnsums_rows(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
                                   int pad, int dil, int in_ldc) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_CONV);
   const int es = 2;
   if (dtype != MDCV_BF16) return 0;     // production dtype only: not every fp32 tile variant carries the fused store loop
   if ((long long)B * Hin * Win * in_ldc * es >= (1LL << 31) || (long long)Nout * KH * KW * Cin * es >= (1LL << 31)) return 0;
   if (Hin == Hout && Win == Wout && mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc))
     return mdcv_shift_stats_rows(B, Hout, Wout, dil, Nout);
-  if (stride == 2 && dil == 1 && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win && g_conv_variant < 0 &&
+  if (stride == 2 && dil == 1 && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win && TUNE().conv_variant < 0 &&
       mdcv_shift_s2_dgrad_eligible(dtype, B, Hin, Win, Cin, Nout, in_ldc))
     return mdcv_shift_s2_rows(B, Hin, Win);             // the shift kernel's stride-2 form: one row per tile of 8 x 31 dY positions
   if (stride == 2 && dil == 1) {
@@ -2038,6 +2012,7 @@ int mdcv_conv2d_dgrad_bnsums(int dtype, const void* in, int in_ldc, const void* 
                              int add_ldc, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
                              int pad, int dil, const void* y, int ldy, const float* scale, const float* shift, const float* mean, int act,
                              float slope, float* partial, void* stream) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_CONV);
   if (!y || !scale || !shift || !mean || !partial || (ldy & 7)) return MDCV_EARG;
   if (mdcv_conv2d_dgrad_bnsums_rows(dtype, B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW, stride, pad, dil, in_ldc) <= 0) return MDCV_EARG;
   BnFuseArgs f;
@@ -2051,8 +2026,9 @@ int mdcv_conv2d_dgrad_bnsums(int dtype, const void* in, int in_ldc, const void* 
 // one partial row of fused sums per 8 x 31 tile): the plan fuses the BatchNorm-backward sums into it at every size.
 int mdcv_conv2d_dgrad_s2_form_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
                                  int pad, int dil, int in_ldc) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_CONV);
   return dtype == MDCV_BF16 && stride == 2 && dil == 1 && KH == 3 && KW == 3 && pad == 1 && Hout == 2 * Hin && Wout == 2 * Win &&
-         g_conv_variant < 0 && (long long)B * Hin * Win * in_ldc * 2 < (1LL << 31) &&
+         TUNE().conv_variant < 0 && (long long)B * Hin * Win * in_ldc * 2 < (1LL << 31) &&
          mdcv_shift_s2_dgrad_eligible(dtype, B, Hin, Win, Cin, Nout, in_ldc);
 }
 
@@ -2061,52 +2037,18 @@ int mdcv_conv2d_stats_rows(int M) { return cdiv(M, 128); }
 // rows for a given forward geometry: the 3x3 stride-1 shift kernel walks a padded position stream and writes more rows
 int mdcv_conv2d_stats_rows_geom(int dtype, int B, int Hout, int Wout, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil,
                                 int in_ldc) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_CONV);
   if (mdcv_shift_eligible(dtype, B, Hout, Wout, Cin, Nout, KH, KW, stride, pad, dil, in_ldc)) return mdcv_shift_fwd_stats_rows(B, Hout, Wout, Nout, dil);
   return cdiv(B * Hout * Wout, 128);
-}
-
-// tuning hook: force the tile configuration of wide (Nout > 64) layers; -1 restores the heuristic
-int mdcv_conv2d_wgrad_set_variant(int v) {   /* tuning hook; 1000 + 100*d + blocks/64: stream-kernel prefetch depth / target blocks */
-  if (v >= 20000 && v < 30000) { g_wgrad_slots = v - 20000; return MDCV_OK; }   /* 20000 + target block count of the generic kernel */
-  if (v >= 30000 && v < 40000) { mdcv_wgrad_stream_tiled_blocks(v - 30000); return MDCV_OK; }   /* 30000 + target block count of the tiled LDS-ring kernel */
-  if (v >= 1000) { mdcv_wgrad_stream_tune((v - 1000) / 100, ((v - 1000) % 100) * 64); v = 0; }
-  else if (v == 0) mdcv_wgrad_stream_tune(0, 0);
-  g_wgrad_variant = v;
-  return MDCV_OK;
-}
-int mdcv_conv2d_set_variant(int v) {
-  // tuning / A-B hook of the conv family (tests walk the tile variants; scripts/ab_step.py times whole steps under a setting).  -1: heuristics.
-  //   0..11  forced tile configuration of wide layers (0-5 register-staged kernels, 6-11 LDS-DMA: 128x128 / 128x64 / 256x128 x 2 / 3 stages); 100 + v: generic address path
-  //   14/15  sparse stride-2 data gradients: four class launches / one launch with two workgroups per tile     4000+n  'sparse' = below n tiles
-  //   16/17  stride-2 data gradient as four parity-class launches / one launch        18/19, 20/21  its tall tiles, its 3-stage ring off / on
-  //   30+n   3-stage ring for 33..64-channel layers from n K steps (30 never)           60+n  the same for 128x128 / 128x64 tiles (60 never)
-  //   92/93  128x64 tiles for fused 1x1 data gradients off / on                         2000+n  256-row tiles for Nout <= 64 from n Ki positions (2000 off)
-  //   -3..-26  shift-kernel hooks (conv_shift.hip: mdcv_shift_set_ring)      -27 / -28  2-D pixel tiles for wide images off / on
-  //   -29 / -60  stride-2 data gradients with 32 / 64 output channels through the shift kernel off / on
-  //   -30 / -31 / -32  shift-kernel K loop of forward launches: lockstep / ping-pong everywhere / ping-pong where measured faster (default)
-  //   -200 / -201  384-row ping-pong tiles: by the plan / forced on every forward launch they fit
-  //   -63 / -64  3x3 data gradients with few positions and > 64 channels (13^2 layers) on 256 x 64 tiles off / on
-  if (v <= -3 && v >= -299) { mdcv_shift_set_ring(-v); v = -1; }
-  if (v == 93 || v == 92) { g_conv_fuse_narrow = v == 93; return MDCV_OK; }
-  if (v >= 60 && v < 92) { g_conv_deep_small = v - 60; return MDCV_OK; }
-  if (v >= 30 && v < 60) { g_conv_deep_narrow = v - 30; return MDCV_OK; }
-  if (v == 20 || v == 21) { g_conv_deep_s2 = v - 20; return MDCV_OK; }
-  if (v == 16 || v == 17) { g_conv_s2_allcls = v - 16; return MDCV_OK; }
-  if (v == 14 || v == 15) { g_conv_s2_split_on = v - 14; return MDCV_OK; }
-  if (v >= 4000 && v < 6000) { g_conv_s2_split = v - 4000; return MDCV_OK; }
-  if (v == 18 || v == 19) { g_conv_tall_s2 = v - 18; return MDCV_OK; }
-  if (v >= 2000 && v < 3000) { g_conv_tall_narrow = v - 2000; return MDCV_OK; }
-  if (v >= 100) { g_conv_no_ut = 1; v -= 100; } else g_conv_no_ut = 0;     // 100+v: variant v with the generic address path
-  g_conv_variant = v == 99 ? -1 : v;
-  return MDCV_OK;
 }
 
 // choose the pixel split of the weight-gradient kernel; returns the number of fp32 slabs.
 // ~2 blocks per CU in flight, but never less than 4 steps (512 bf16 pixels) per split so the fp32 epilogue stays amortised.
 int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_WGRAD);
   const int bp = dtype == MDCV_BF16 ? 128 : 64;
   const int tiles = cdiv(Cout, 128) * cdiv(Ktot, 128);
-  const int slots = g_wgrad_slots;   // resident blocks: 2 per CU (wide tile 66 KiB; narrow tile 4 x 20 KiB ring)
+  const int slots = TUNE().wgrad_slots;   // resident blocks: 2 per CU (wide tile 66 KiB; narrow tile 4 x 20 KiB ring)
   int s = slots / tiles;                  // never spill into a second, nearly empty round
   const int max_s = cdiv(M, bp * 4);
   if (s > max_s) s = max_s;
@@ -2122,27 +2064,28 @@ int mdcv_conv2d_wgrad_splits(int dtype, int M, int Cout, int Ktot) {
 // main stream's kernels that run beside the weight gradients).  Variant 8 forces it wherever eligible, 9 disables it.
 static bool use_wgrad_shift(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride, int pad,
                             int dil, long long dy_ldc, long long x_ldc) {
-  if (g_wgrad_variant == 9 || Hin != Hout || Win != Wout) return false;
+  if (TUNE().wgrad_variant == 9 || Hin != Hout || Win != Wout) return false;
   if (!mdcv_wgrad_shift_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc)) return false;
-  if (g_wgrad_variant == 8) return true;
+  if (TUNE().wgrad_variant == 8) return true;
   const long long Mq = (long long)B * (Hout + 1) * (Wout + 1);
   const int s = mdcv_wgrad_shift_splits(B, Hout, Wout, Cin, Cout);
   if (Mq / (64LL * s) >= 128) return true;
-  return g_wgrad_variant == 11 && mdcv_conv2d_wgrad_splits(dtype, B * Hout * Wout, Cout, KH * KW * Cin) == 1;   // A/B: also the split-less layers
+  return TUNE().wgrad_variant == 11 && mdcv_conv2d_wgrad_splits(dtype, B * Hout * Wout, Cout, KH * KW * Cin) == 1;   // A/B: also the split-less layers
 }
 
 // 16..128-channel 3x3 stride-1 layers (dilation 1 or 2): all nine taps read one activation window kept in an LDS ring
 // (wgrad_stream.hip).  Variants 9 and 10 disable it.
 static bool use_wgrad_stream(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride, int pad,
                              int dil, long long dy_ldc, long long x_ldc) {
-  if (g_wgrad_variant == 9 || g_wgrad_variant == 10 || Hin != Hout || Win != Wout) return false;
+  if (TUNE().wgrad_variant == 9 || TUNE().wgrad_variant == 10 || Hin != Hout || Win != Wout) return false;
   return mdcv_wgrad_stream_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc);
 }
 
 // geometry-aware variant: the kernel mdcv_conv2d_wgrad will pick for this layer decides the split (use this one to size `ws`)
 int mdcv_conv2d_wgrad_splits_geom(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride,
                                   int pad, int dil, int dy_ldc, int x_ldc) {
-  if (g_wgrad_variant != 9 && g_wgrad_variant != 10 && Hin == Hout && Win == Wout &&
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_WGRAD);
+  if (TUNE().wgrad_variant != 9 && TUNE().wgrad_variant != 10 && Hin == Hout && Win == Wout &&
       mdcv_wgrad_stem_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc))
     return mdcv_wgrad_stem_splits(B, Hout, Wout);
   if (use_wgrad_stream(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc))
@@ -2155,9 +2098,10 @@ int mdcv_conv2d_wgrad_splits_geom(int dtype, int B, int Hin, int Win, int Cin, i
 int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits,
                       float* dw_oihw, int accumulate, int B, int Hin, int Win, int Cin, int Cin_real,
                       int Hout, int Wout, int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_WGRAD);
   if (!dy || !x || !ws || !dw_oihw) return MDCV_EARG;
   if ((Cin & 7) || (Cout & 7) || (dy_ldc & 7) || (x_ldc & 7) || splits < 1) return MDCV_EARG;
-  if (g_wgrad_variant != 9 && g_wgrad_variant != 10 && Hin == Hout && Win == Wout &&
+  if (TUNE().wgrad_variant != 9 && TUNE().wgrad_variant != 10 && Hin == Hout && Win == Wout &&
       mdcv_wgrad_stem_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc) &&
       mdcv_wgrad_stem_splits_ok(splits, B, Hout, Wout)) {      // 7x7 stem with the input padded to 16 channels: LDS-ring kernel
     const int rc = mdcv_wgrad_stem(dy, dy_ldc, x, x_ldc, ws, splits, B, Hout, Wout, (hipStream_t)stream);
@@ -2187,7 +2131,7 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   a.pix_per_split = cdiv(cdiv(a.M, splits), bp) * bp;
   if (cdiv(a.M, a.pix_per_split) != splits) return MDCV_EARG;
   const long long dyb = (long long)a.M * dy_ldc * 2, xb = (long long)B * Hin * Win * x_ldc * 2;
-  const bool use_dma = dtype == MDCV_BF16 && dyb < (1LL << 31) && xb < (1LL << 31) && g_conv_variant != 0 &&
+  const bool use_dma = dtype == MDCV_BF16 && dyb < (1LL << 31) && xb < (1LL << 31) && TUNE().conv_variant != 0 &&
                        (long long)B * Hin * Win + 256 < (1LL << 24) && a.M + 256 < (1 << 24) && Wout >= 8 && x_ldc < (1 << 23) && dy_ldc < (1 << 23);
   a.tiles_k = cdiv(a.Ktot, 128);
   a.tiles_ck = a.tiles_k * cdiv(Cout, 128);
@@ -2251,8 +2195,8 @@ int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, int max
     if (e2 != hipSuccess) return (int)e2;
     lds_set = lds;
   }
-  if (dtype == MDCV_BF16) MDCV_LAUNCH(pack_weights_batched_kernel<bf16_t>, dim3(g_pack_blocks, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
-  else if (dtype == MDCV_F32) MDCV_LAUNCH(pack_weights_batched_kernel<float>, dim3(g_pack_blocks, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
+  if (dtype == MDCV_BF16) MDCV_LAUNCH(pack_weights_batched_kernel<bf16_t>, dim3(kPackBlocks, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
+  else if (dtype == MDCV_F32) MDCV_LAUNCH(pack_weights_batched_kernel<float>, dim3(kPackBlocks, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;

@@ -25,6 +25,5 @@ int mdcv_shift_fwd_stats_rows(int B, int H, int W, int Nout, int dil = 1);  // p
 int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* out, int out_ldc, const float* bias, const void* addsrc,
                     int add_ldc, float* stats, int B, int H, int W, int Cin, int Nout, const BnFuseArgs* fuse, hipStream_t st,
                     const EpiArgs* epi = nullptr, int dil = 1, const XAccArgs* xacc = nullptr);
-void mdcv_shift_set_ring(int ring);
 int mdcv_shift_s2_rows(int B, int H, int W);   // partial rows of mode 3's fused BatchNorm-backward sums (H, W = dY's)
 bool mdcv_shift_s2_dgrad_eligible(int dtype, int B, int H, int W, int Cin, int Nout, long long in_ldc);   // mode 3 of mdcv_shift_conv: H, W = dY's

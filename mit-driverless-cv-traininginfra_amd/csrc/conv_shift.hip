@@ -33,37 +33,7 @@
 #define MDCV_SHIFT_PART 0
 #endif
 #if MDCV_SHIFT_PART == 0
-int g_shift_ring = 4;   // weight-ring depth of sparse grids (<= 256 tiles); 3: off (tuning hook: mdcv_conv2d_set_variant(-3 / -4))
-int g_shift_wmax_narrow = 104; // rows up to 104 pixels for the 64- / 32-wide tiles (their smaller weight ring keeps two workgroups on a CU): the data gradients of
-                               // YOLOv3's 104x104 64->128 layers, +0.3 % on its step (set_variant(-24) off, (-23) on)
-int g_shift_wmax_n32 = 0;   // tuning (set_variant(-25) -> 208, (-26) -> off): 32-wide tiles on rows up to 208 pixels (128-row tiles)
-int g_shift_dil2 = 1;   // dilation-2 layers (stream padded with two shared zero columns / rows): 1 = where it pays (below), 2 = every eligible
-                        // layer (set_variant(-20)), 0 = never (set_variant(-21)), set_variant(-22) restores 1
-int g_shift_n64 = 2;    // 64- and 32-channel layers run one narrow tile column (set_variant(-18) off / (-17) 64 only / (-19) 64 and 32): RektNet's
-                        // 64->64 layers 210 -> 168 us forward, 211 -> 153 us data gradient, +0.5 % on its step; the 32->32 layers another +0.35 %
-int g_shift_wmax = 80;  // widest image row the shift kernel takes (set_variant(-15) -> 62, (-14) -> 80).  Up to 62 the chunk is 384 rows (3 DMAs per
-                        // wave); 63..80 take a fourth and still fit two workgroups on a CU: RektNet's 128->128 layers at 80x80 +3.1 % on its step,
-                        // the 76x76 layers of the 608^2 detector +1 % on the joint pipeline (same-box A/B)
-int g_shift_loop = 2;   // K-loop form of the FORWARD launches (set_variant(-30 - n)): 0 lockstep ; 1 ping-pong wave groups
-                        // (two groups of four waves one barrier apart: one wave of a SIMD multiplies while its partner reads fragments and issues
-                        // DMAs) ; 2 (default) ping-pong for grids of at most one workgroup per CU, where no second workgroup fills the
-                        // read phase (13^2 512->1024 forward 52.5 -> 48.9 us), and 384-row ping-pong tiles where they make ONE round of
-                        // 193..256 workgroups (26^2 256->512 forward 44.6 -> 42.4 us).  Denser grids: +1..2 % alone, data gradients -5..+3 %.
-int g_shift_2d = 1;   // images wider than the 1-D stream takes (below) run as 2-D pixel tiles of 8 x 30 outputs (set_variant(-27) off / (-28) on)
-int g_shift_big = 0;   // A/B: 384 forces the 384-row ping-pong tiles on every forward launch they fit
-int g_shift_n64_wide = 1;   // data gradients with few positions and > 64 channels on 256 x 64 tiles (see mdcv_shift_launch_dgrad)
-int g_shift_plan = 0;   // 0 / 5: default plan (192-row tiles where they save a round) ; 1: 256-row tiles only ; 2: 128-row only ; 6: never 192-row
 #else
-extern int g_shift_ring;
-extern int g_shift_wmax_narrow;
-extern int g_shift_wmax_n32;
-extern int g_shift_dil2;
-extern int g_shift_n64;
-extern int g_shift_wmax;
-extern int g_shift_plan, g_shift_n64_wide;
-extern int g_shift_loop;
-extern int g_shift_big;
-extern int g_shift_2d;
 #endif
 int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_bytes, unsigned w_bytes);   // defined by part 1
 
@@ -643,15 +613,15 @@ template <int MODE, int BM, int NPA, bool FUSE, int WN, bool EPI = false, int BR
 int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigned in_bytes, unsigned w_bytes) {
   constexpr int NW = WM * WN;
   constexpr int BN = BN_, BTILE = BN * 64, SROW = BN * 2 + 16;
-  if constexpr (LOOP == 0 && WN == 2 && !EPI && MODE == 0 && !FUSE) {   // ping-pong K loop: forward launches only (measured, see g_shift_loop)
-    if (g_shift_loop == 1 || BM > 256 || (g_shift_loop == 2 && tiles_m * a.tiles_n <= 256))
+  if constexpr (LOOP == 0 && WN == 2 && !EPI && MODE == 0 && !FUSE) {   // ping-pong K loop: forward launches only (measured, see TUNE().shift_loop)
+    if (TUNE().shift_loop == 1 || BM > 256 || (TUNE().shift_loop == 2 && tiles_m * a.tiles_n <= 256))
       return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, BRING, BN_, 1>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
   // A grid that puts one workgroup on a CU has only the ring's lookahead in flight on that CU's L2 -> LDS path (latency-bound fill):
   // such launches (batch 32: the 13x13 and 26x26 data gradients) take a 4-slot weight ring.  Same-box A/B of the YOLOv3 step:
   // +0.45 .. 0.6 % (6 slots +0.35 %; 4 slots on EVERY grid -2.8 %: the 36-step unrolled period and the third workgroup's worth of LDS).
   if constexpr (BRING == 3 && WN == 2 && !EPI) {
-    if ((g_shift_ring == 4 && tiles_m * a.tiles_n <= 256) || g_shift_ring == 5)
+    if ((TUNE().shift_ring == 4 && tiles_m * a.tiles_n <= 256) || TUNE().shift_ring == 5)
       return launch_shift_f<MODE, BM, NPA, FUSE, WN, EPI, 4, BN_, LOOP>(a, p_base, tiles_m, st, in_bytes, w_bytes);
   }
   a.p_base = p_base;
@@ -720,13 +690,13 @@ int shift_plan_bm(int Mq, int tiles_n, bool fused, int halo = 0, int bn = 128, b
   }
   if (bn == 128 && !fused && fwd && halo <= 110) {       // 384-row ping-pong tiles (one workgroup per CU): forward only
     const int t384 = ((Mq + 383) / 384) * tiles_n;
-    if (g_shift_big == 384 || (g_shift_loop == 2 && t384 > 192 && t384 <= 256)) return 384;
+    if (TUNE().shift_big == 384 || (TUNE().shift_loop == 2 && t384 > 192 && t384 <= 256)) return 384;
   }
-  if (g_shift_plan == 1) return 256;
-  if (g_shift_plan == 2) return 128;
+  if (TUNE().shift_plan == 1) return 256;
+  if (TUNE().shift_plan == 2) return 128;
   const int t256 = ((Mq + 255) / 256) * tiles_n;
   if (t256 <= 128) return 128;                       // (measured: 184- and 200-tile grids are still faster as 256-row tiles)
-  if (fused || g_shift_plan == 6) return 256;       // plan 6: the old default (no 192-row tiles)
+  if (fused || TUNE().shift_plan == 6) return 256;       // plan 6: the old default (no 192-row tiles)
   const int t192 = ((Mq + 191) / 192) * tiles_n;
   const int c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
   return c192 < c256 ? 192 : 256;
@@ -769,7 +739,7 @@ int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_byte
   // Few positions, many channels (13^2 x 32 images, 1024 -> 512: 25 x 4 tiles of 256 x 128): the plan below would fall back to 128-row tiles,
   // which stream the same 2.4 MB of weights per tile for half the MFMA work.  256 x 64 tiles give the same number of workgroups with half
   // the weight stream each (variant -64 / -63: on / off).
-  if (g_shift_n64_wide && !a.t2d && a.Nout % 64 == 0 && ((a.Mq + 255) / 256) * a.tiles_n <= 128) {
+  if (TUNE().shift_n64_wide && !a.t2d && a.Nout % 64 == 0 && ((a.Mq + 255) / 256) * a.tiles_n <= 128) {
     ShiftArgs b = a;
     b.tiles_n = a.Nout / 64;
     return launch_shift_mode<1, 64>(b, st, in_bytes, w_bytes);
@@ -785,20 +755,20 @@ int mdcv_shift_launch_dgrad(const ShiftArgs& a, hipStream_t st, unsigned in_byte
 // two positions per row whose window would wrap are junk (6 %), the chunk is 322 rows however wide the image is.  Same kernel, same
 // K loop: only the DMA source addresses and the position -> pixel table of the epilogue differ (ShiftArgs.t2d).
 static bool shift_fits_1d(int W, int Nout) {
-  return W <= g_shift_wmax || (g_shift_wmax_narrow && Nout <= 64 && W <= g_shift_wmax_narrow) || (g_shift_wmax_n32 && Nout <= 32 && W <= g_shift_wmax_n32);
+  return W <= TUNE().shift_wmax || (TUNE().shift_wmax_narrow && Nout <= 64 && W <= TUNE().shift_wmax_narrow) || (TUNE().shift_wmax_n32 && Nout <= 32 && W <= TUNE().shift_wmax_n32);
 }
-static bool shift_is_2d(int W, int Nout, int dil) { return dil == 1 && g_shift_2d && !shift_fits_1d(W, Nout); }
+static bool shift_is_2d(int W, int Nout, int dil) { return dil == 1 && TUNE().shift_2d && !shift_fits_1d(W, Nout); }
 constexpr int T2D_WQ = 32, T2D_TH = 8;                      // tile = 8 x 32 positions = 256 (30 output columns + 2 junk)
 static long long shift_2d_positions(int B, int H, int W) { return (long long)B * ((H + T2D_TH - 1) / T2D_TH) * ((W + T2D_WQ - 3) / (T2D_WQ - 2)) * 256; }
 
 bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int KH, int KW, int stride, int pad, int dil, long long in_ldc) {
-  if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != dil || (dil != 1 && !(dil == 2 && g_shift_dil2))) return false;
+  if (dtype != MDCV_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != dil || (dil != 1 && !(dil == 2 && TUNE().shift_dil2))) return false;
   // dilation 2 pays where the halo-heavy chunk is amortised over >= 2 channel chunks and two workgroups still fit a CU (narrow tiles):
   // RektNet data gradient 128->64 412 -> 332 us, 64->32 193 -> 183 us; forward 64->128 (128-wide tile, one workgroup per CU) 281 -> 360 us
-  if (dil == 2 && g_shift_dil2 == 1 && !(Nout <= 64 && Cin >= 64)) return false;
-  if ((Cin & 31) || ((Nout & 127) && !(Nout == 64 && g_shift_n64) && !(Nout == 32 && g_shift_n64 == 2))) return false;   // 128-wide tiles, or one 64-wide tile column
+  if (dil == 2 && TUNE().shift_dil2 == 1 && !(Nout <= 64 && Cin >= 64)) return false;
+  if ((Cin & 31) || ((Nout & 127) && !(Nout == 64 && TUNE().shift_n64) && !(Nout == 32 && TUNE().shift_n64 == 2))) return false;   // 128-wide tiles, or one 64-wide tile column
   if (H < 8 || W < 8) return false;
-  if (!shift_fits_1d(W, Nout) && !(g_shift_2d && dil == 1)) return false;   // wider rows: 2-D pixel tiles (dilation 1 only), or not at all
+  if (!shift_fits_1d(W, Nout) && !(TUNE().shift_2d && dil == 1)) return false;   // wider rows: 2-D pixel tiles (dilation 1 only), or not at all
   if ((long long)B * (H + dil) * (W + dil) + 1024 >= (1LL << 30) || shift_2d_positions(B, H, W) >= (1LL << 30)) return false;
   if ((long long)B * H * W * in_ldc * 2 >= (1LL << 31) || (long long)Nout * 9 * Cin * 2 >= (1LL << 31)) return false;
   return true;
@@ -806,9 +776,8 @@ bool mdcv_shift_eligible(int dtype, int B, int H, int W, int Cin, int Nout, int 
 
 // 3x3 / stride-2 / pad-1 data gradient with an even output (dx = 2H x 2W from dY = H x W) and 32 or 64 output channels: the two HBM-bound
 // layers of YOLOv3 (208 -> 416, 104 -> 208).  mdcv_shift_conv(mode 3).
-int g_shift_s2 = 1;        // set_variant(-29) off / (-60) on
 bool mdcv_shift_s2_dgrad_eligible(int dtype, int B, int H, int W, int Cin, int Nout, long long in_ldc) {
-  if (!g_shift_s2 || dtype != MDCV_BF16 || (Cin & 31) || Cin < 32 || !(Nout == 32 || Nout == 64) || H < 1 || W < 1) return false;
+  if (!TUNE().shift_s2 || dtype != MDCV_BF16 || (Cin & 31) || Cin < 32 || !(Nout == 32 || Nout == 64) || H < 1 || W < 1) return false;
   if ((long long)B * ((H + 7) / 8) * ((W + 30) / 31) * 256 >= (1LL << 30)) return false;
   if ((long long)B * H * W * in_ldc * 2 >= (1LL << 31) || (long long)Nout * 9 * Cin * 2 >= (1LL << 31)) return false;
   return true;
@@ -864,7 +833,6 @@ int mdcv_shift_conv(int mode, const void* in, int in_ldc, const void* w, void* o
   return launch_shift_mode<0, 128>(a, st, in_bytes, w_bytes);
 }
 
-void mdcv_shift_set_ring(int ring) { if (ring == 63 || ring == 64) { g_shift_n64_wide = ring - 63; return; } if (ring == 29 || ring == 60) { g_shift_s2 = ring == 60; return; } if (ring == 27 || ring == 28) { g_shift_2d = ring - 27; return; } if (ring >= 200 && ring < 300) { g_shift_big = ring == 201 ? 384 : 0; return; } if (ring >= 30 && ring <= 59) { g_shift_loop = ring - 30; return; } if (ring == 25 || ring == 26) { g_shift_wmax_n32 = ring == 25 ? 208 : 0; return; } if (ring == 23 || ring == 24) { g_shift_wmax_narrow = ring == 23 ? 104 : 0; return; } if (ring >= 20 && ring <= 22) { g_shift_dil2 = ring == 20 ? 2 : (ring == 21 ? 0 : 1); return; } if (ring >= 17 && ring <= 19) { g_shift_n64 = ring == 17 ? 1 : (ring == 18 ? 0 : 2); return; } if (ring >= 14 && ring <= 16) { g_shift_wmax = ring == 14 ? 80 : (ring == 15 ? 62 : 104); return; } if (ring >= 7) g_shift_plan = ring - 7; else if (ring >= 3 && ring <= 5) g_shift_ring = ring; }   // -7..-10 -> plan 0..3
 #ifdef MDCV_SHIFT_TS
 extern "C" int mdcv_debug_shift_ts(long long* host4x512) {
   return (int)hipMemcpyFromSymbol(host4x512, HIP_SYMBOL(g_shift_ts), sizeof(long long) * 4 * 512);

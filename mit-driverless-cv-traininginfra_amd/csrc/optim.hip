@@ -157,13 +157,13 @@ int mdcv_stream_fork_arm(void* from, int device_scope, void** ev_out) {
     if (dev != cur) (void)hipSetDevice(cur);
     if (e != hipSuccess) { ring[dev][sc][i] = nullptr; return (int)e; }
   }
-  mdcv_g_arm = ring[dev][sc][i];
+  mdcv_t_arm = ring[dev][sc][i];
   *ev_out = (void*)ring[dev][sc][i];
   return MDCV_OK;
 }
 int mdcv_stream_fork_wait(void* to, void* ev) {
   if (!ev) return MDCV_EARG;
-  if (mdcv_g_arm) { mdcv_g_arm = nullptr; return MDCV_EARG; }      // nothing was launched since the arm: the event was never bound
+  if (mdcv_t_arm) { mdcv_t_arm = nullptr; return MDCV_EARG; }      // nothing was launched since the arm: the event was never bound
   return (int)hipStreamWaitEvent((hipStream_t)to, (hipEvent_t)ev, 0);
 }
 

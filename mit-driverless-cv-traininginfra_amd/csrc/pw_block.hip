@@ -324,14 +324,12 @@ int launch_pw3(PwArgs a, hipStream_t st) {
   return MDCV_OK;
 }
 
-int g_pw_bmp = 0;    // tuning hooks (mdcv_pw_set_variant): forced pixels per tile, 0 = heuristic
-int g_pw_wres = 1;   // weights resident in LDS where they fit
 
 template <int BMP, int FNW, int NV, bool HASR>
 int launch_pw2(PwArgs a, hipStream_t st) {
   const int nchunks = (a.N + NCW * FNW * 16 - 1) / (NCW * FNW * 16);
   const int lds_res = 2 * BMP * a.K * 2 + NCW * (a.K / 32) * FNW * 1024 + NCW * BMP * (FNW * 32 + 16);
-  if (g_pw_wres && nchunks == 1 && lds_res <= 160 * 1024) return launch_pw3<BMP, FNW, NV, HASR, true>(a, st);
+  if (TUNE().pw_wres && nchunks == 1 && lds_res <= 160 * 1024) return launch_pw3<BMP, FNW, NV, HASR, true>(a, st);
   return launch_pw3<BMP, FNW, NV, HASR, false>(a, st);
 }
 
@@ -358,7 +356,7 @@ int dispatch_pw(PwArgs a, hipStream_t st) {
 
 // pixels per workgroup tile: the resident operand tile is kept at <= 32 KiB so that two workgroups share a CU
 int mdcv_pw_tile_rows(int K) {
-  if (g_pw_bmp) return g_pw_bmp;
+  if (TUNE().pw_bmp) return TUNE().pw_bmp;
   if (K <= 256) return 64;
   if (K <= 512) return 32;
   return 16;
@@ -375,8 +373,6 @@ bool mdcv_pw_eligible(int dtype, long long M, int K, int N, int ld0, int ld1, in
 }
 
 extern "C" {
-
-int mdcv_pw_set_variant(int v) { if (v == 1000 || v == 1001) { g_pw_wres = v - 1000; return MDCV_OK; } g_pw_bmp = (v == 64 || v == 32 || v == 16) ? v : 0; return MDCV_OK; }
 
 int mdcv_pw_rows(long long M, int K) { return (int)((M + mdcv_pw_tile_rows(K) - 1) / mdcv_pw_tile_rows(K)); }
 

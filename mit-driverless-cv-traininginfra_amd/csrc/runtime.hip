@@ -19,7 +19,9 @@
 #include <vector>
 
 int mdcv_g_prof = 0;
-hipEvent_t mdcv_g_arm = nullptr;
+static const MdcvTune kDefaultTune;                       // every knob at its measured default (tune.h)
+thread_local const MdcvTune* mdcv_t_tune = &kDefaultTune;
+thread_local hipEvent_t mdcv_t_arm = nullptr;   // (per thread: arm and launch happen on one thread)
 
 namespace {
 struct Rec { const void* fn; hipEvent_t e0, e1; };

@@ -19,8 +19,6 @@ int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil);
 bool mdcv_wgrad_stream_splits_ok(int splits, int B, int H, int W, int Cin, int Cout, int dil);
 int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, int Cin, int Cout,
                       int dil, hipStream_t st);
-void mdcv_wgrad_stream_tiled_blocks(int blocks);   // tuning hook: target block count of the channel-tiled instantiation (default 128)
-void mdcv_wgrad_stream_tune(int d, int blocks);   // tuning hook: prefetch depth (0 = default), target block count (0 = default)
 // 7x7 / stride 1 / pad 3 stem, 16 (padded) -> 16 channels
 bool mdcv_wgrad_stem_eligible(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
                               long long dy_ldc, long long x_ldc);

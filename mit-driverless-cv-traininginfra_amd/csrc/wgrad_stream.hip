@@ -539,19 +539,12 @@ __global__ __launch_bounds__(512) void wgrad7x7_stream_kernel(WgradStreamArgs a,
 
 struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; bool tiled = false; int nw = 8; };
 // Tuning hooks (mdcv_conv2d_wgrad_set_variant): ONE per decision that was measured on the training step.
-int g_stream_blocks = 0;   // force the target block count of every form; 0 = defaults below (1000 + blocks/64)
-int g_stream_tiled = 1;    // channel-tiled instantiation for the wide layers (Cin % 64 == 0, Cout % 128 == 0); 0 = off (1800)
 // Light form of the tiled instantiation: 64 co x 64 ci per block, FOUR waves (one per SIMD, 237 VGPRs), prefetch depth 1, 56 KiB of LDS -- about
 // half a CU, on 256 blocks.  The 8-wave form owns its CU outright (2 x 234 VGPRs per SIMD, 120 KiB) and runs on 128 blocks so that the main
 // stream keeps the other half of the chip; the light form leaves room for main-stream workgroups on EVERY CU instead, and their waves fill
 // the issue slots its single wave per SIMD leaves open.  Same-box A/B of the YOLOv3 step: 14.45 -> 14.32 ms (256 blocks; 192: 14.62, 224:
 // 14.35, 288: 14.39, 320: 14.54, 384: 14.77; depth 2: 14.60).  Layers with long position streams stay on the 8-wave form (RektNet's 80^2 x
 // 256-image layers, 1.68 M positions: -1.3 % with the light form in round 2, neutral since the round-3 address rework).
-int g_stream_light_maxpos = 600000;   // light form up to this many padded stream positions (30003: everywhere, 30005: never, 30002: default)
-int g_stream_light_blocks = 256;      // its block target (33000 + n)
-int g_stream_tiled_blocks = 128;      // block target of the 8-wave tiled form (30000 + n).  A block fills its CU, and the weight gradients run BESIDE
-                                      // the main stream: with one block on every CU the main stream's workgroups wait for whole weight-gradient blocks to
-                                      // retire (YOLOv3 step, same-box A/B: 256 blocks 2033, 192: 2080, 128: 2103, 64: 2033 img/s)
 
 // (Cin, Cout) -> instantiation; false if unsupported
 inline bool stream_cfg(int Cin, int Cout, StreamCfg& c, long long Mq = 0) {     // Mq: padded stream positions (0: unknown -> the 8-wave form)
@@ -560,10 +553,10 @@ inline bool stream_cfg(int Cin, int Cout, StreamCfg& c, long long Mq = 0) {     
   else if (Cin == 32 && Cout == 32)  c = {2, 2, 2, 4, 128, 2, 9};
   else if (Cin == 32 && Cout == 64)  c = {2, 4, 4, 4, 128, 2, 3};
   else if (Cin == 64 && Cout == 64)  c = {4, 4, 4, 2, 64, 2, 3};
-  else if (Cin == 64 && Cout == 128 && !g_stream_tiled) c = {4, 8, 4, 1, 64, 2, 1};
-  else if (g_stream_tiled && Cin % 64 == 0 && Cout % 128 == 0 && Cin <= 4096 && Cout <= 4096) {
+  else if (Cin == 64 && Cout == 128 && !TUNE().stream_tiled) c = {4, 8, 4, 1, 64, 2, 1};
+  else if (TUNE().stream_tiled && Cin % 64 == 0 && Cout % 128 == 0 && Cin <= 4096 && Cout <= 4096) {
     c = {4, 8, 4, 1, 64, 2, 1}; c.tiled = true;
-    if (Mq > 0 && Mq <= g_stream_light_maxpos) { c.nco = 4; c.nw = 4; c.d = 1; }   // light form
+    if (Mq > 0 && Mq <= TUNE().stream_light_maxpos) { c.nco = 4; c.nw = 4; c.d = 1; }   // light form
   }
   else return false;
   return true;
@@ -624,8 +617,8 @@ int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil) {
   StreamCfg c;
   const int Mq = B * (H + dil) * (W + dil);
   if (!stream_cfg(Cin, Cout, c, Mq)) return 1;
-  int s = g_stream_blocks > 0 ? g_stream_blocks : (c.a <= 2 ? 512 : 256);
-  if (c.tiled) s = ((g_stream_blocks > 0 ? g_stream_blocks : (c.nco == 4 ? g_stream_light_blocks : g_stream_tiled_blocks)) + (Cout / (16 * c.nco)) * (Cin / 64) - 1) / ((Cout / (16 * c.nco)) * (Cin / 64));   // blocks = splits x channel tiles
+  int s = TUNE().stream_blocks > 0 ? TUNE().stream_blocks : (c.a <= 2 ? 512 : 256);
+  if (c.tiled) s = ((TUNE().stream_blocks > 0 ? TUNE().stream_blocks : (c.nco == 4 ? TUNE().stream_light_blocks : TUNE().stream_tiled_blocks)) + (Cout / (16 * c.nco)) * (Cin / 64) - 1) / ((Cout / (16 * c.nco)) * (Cin / 64));   // blocks = splits x channel tiles
   const int max_s = (Mq + c.bp * 4 - 1) / (c.bp * 4);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -679,16 +672,6 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
 #undef STREAM_CASE
   return MDCV_EARG;
 }
-
-void mdcv_wgrad_stream_tiled_blocks(int blocks) {      // 30000 + n: block target of the 8-wave form ; 30002: default form choice ; 30003: light form everywhere ;
-                                                       // 30005: never ; 33000 + n: the light form's block target
-  if (blocks == 2) { g_stream_light_maxpos = 600000; return; }
-  if (blocks == 3) { g_stream_light_maxpos = 1 << 30; return; }
-  if (blocks == 5) { g_stream_light_maxpos = 0; return; }
-  if (blocks >= 3000 && blocks < 5000) { g_stream_light_blocks = blocks - 3000; return; }
-  g_stream_tiled_blocks = blocks > 0 ? blocks : 128;
-}
-void mdcv_wgrad_stream_tune(int d, int blocks) { g_stream_tiled = !(d & 8); g_stream_blocks = blocks; }
 
 // ---- 7x7 stem (see wgrad7x7_stream_kernel)
 static int stem_hpad(int W) { return (3 * (W + 3 + 1) + 31) / 32 * 32; }

@@ -15,7 +15,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, ACT_NONE, ACT_LEAKY, ACT_RELU  # noqa: F401
+from ._lib import F32, BF16, ACT_NONE, ACT_LEAKY, ACT_RELU, tuned  # noqa: F401
 
 
 _POISON = os.environ.get("MDCV_POISON", "0") == "1"     # debug: NaN-fill every uninitialised plan buffer (finds reads of unwritten memory)
@@ -179,12 +179,19 @@ class BnSpec:
 
 
 class Plan:
+    tune_conv = int(os.environ.get("MDCV_CONV_VARIANT", "0") or 0)      # variant code of the conv family for this plan's calls (0: defaults)
+    tune_wgrad = int(os.environ.get("MDCV_WGRAD_VARIANT", "0") or 0)    # ... of the weight-gradient family
+
     def __init__(self, device, precision, training, grad_sink=None):
         _lib.require_gpu()
         self.L = _lib.lib()
         self.device = device
         self.dtype = parse_precision(precision)
         self.tdtype = torch.bfloat16 if self.dtype == BF16 else torch.float32
+        # per-call tuning (csrc/tune.h): the plan hands its variant codes to every convolution / weight-gradient call through the dtype argument --
+        # the library keeps no tuning state, so two plans of one process may differ (A/B runs: scripts/ab_step.py "c<code>" / "w<code>")
+        self.cdt = tuned(self.dtype, self.tune_conv)
+        self.wdt = tuned(self.dtype, self.tune_wgrad)
         self.training = training
         self.fwd, self.bwd = [], []
         self.keep = []                 # keeps every buffer alive
@@ -335,13 +342,13 @@ class Plan:
 
     def stats_rows(self, cs, x, y):
         """rows of the BatchNorm partial-statistics buffer the forward conv of this geometry writes"""
-        return int(self.L.conv2d_stats_rows_geom(self.dtype, x.B, y.H, y.W, cs.cin_pad, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad,
+        return int(self.L.conv2d_stats_rows_geom(self.cdt, x.B, y.H, y.W, cs.cin_pad, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad,
                                                  cs.dil, x.ldc))
 
     def emit_conv_fwd(self, cs, x, y, stats_partial=None):
         """x, y: Act.  y.C == cs.cout_pad."""
         assert x.C == cs.cin_pad and y.C == cs.cout_pad, (x.C, cs.cin_pad, y.C, cs.cout_pad)
-        self.call(self.fwd, self.L.conv2d, self.dtype, 0, x.ptr, x.ldc, cs.wf.data_ptr(), y.ptr, y.ldc,
+        self.call(self.fwd, self.L.conv2d, self.cdt, 0, x.ptr, x.ldc, cs.wf.data_ptr(), y.ptr, y.ldc,
                   cs.bias_pad.data_ptr() if cs.bias_pad is not None else None, None, 0,
                   stats_partial.data_ptr() if stats_partial is not None else None,
                   x.B, x.H, x.W, cs.cin_pad, y.H, y.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
@@ -399,13 +406,13 @@ class Plan:
     def _emit_wgrad_single(self, cs, xw, dy, cin_w):
         L, dt = self.L, self.dtype
         gw = self.param_grad(cs.weight)
-        splits = int(L.conv2d_wgrad_splits_geom(dt, xw.B, xw.H, xw.W, cin_w, dy.H, dy.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad,
+        splits = int(L.conv2d_wgrad_splits_geom(self.wdt, xw.B, xw.H, xw.W, cin_w, dy.H, dy.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad,
                                                 cs.dil, dy.ldc, xw.ldc))
         self.ws_floats = max(self.ws_floats, splits * cs.cout_pad * cs.kh * cs.kw * cin_w)
         plan = self
 
         def wgrad(stream, cs=cs, x=xw, dy=dy, gw=gw, splits=splits, cin_w=cin_w):
-            return L.conv2d_wgrad(dt, dy.ptr, dy.ldc, x.ptr, x.ldc, plan.wgrad_ws(stream).data_ptr(), splits, gw.data_ptr(), 0,
+            return L.conv2d_wgrad(plan.wdt, dy.ptr, dy.ldc, x.ptr, x.ldc, plan.wgrad_ws(stream).data_ptr(), splits, gw.data_ptr(), 0,
                                   x.B, x.H, x.W, cin_w, cs.cin, dy.H, dy.W, cs.cout_pad, cs.cout, cs.kh, cs.kw,
                                   cs.stride, cs.pad, cs.dil, stream)
         wgrad.__name__ = "conv2d_wgrad"
@@ -422,7 +429,7 @@ class Plan:
                 geom=(x.B, dy.H, dy.W, cs.cout_pad, x.H, x.W, cs.cin_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil),
                 head=(dy.ptr, dy.ldc, cs.wd.data_ptr(), out.ptr, out.ldc, add.ptr if add is not None else None,
                       add.ldc if add is not None else 0))
-            self.call(self.bwd, L.conv2d, dt, 1, dy.ptr, dy.ldc, cs.wd.data_ptr(), out.ptr, out.ldc, None,
+            self.call(self.bwd, L.conv2d, self.cdt, 1, dy.ptr, dy.ldc, cs.wd.data_ptr(), out.ptr, out.ldc, None,
                       add.ptr if add is not None else None, add.ldc if add is not None else 0, None,
                       x.B, dy.H, dy.W, cs.cout_pad, x.H, x.W, cs.cin_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
 
@@ -462,7 +469,7 @@ class Plan:
         self.call(self.fwd, self.L.bn_eval_coeffs_bias, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                   bn.running_var.data_ptr(), float(bn.eps), cs.bias_pad.data_ptr() if cs.bias_pad is not None else None,
                   bs.scale.data_ptr(), bs.shift.data_ptr(), bs.C)
-        self.call(self.fwd, self.L.conv2d_affine_act, self.dtype, x.ptr, x.ldc, cs.wf.data_ptr(), out.ptr, out.ldc, bs.scale.data_ptr(),
+        self.call(self.fwd, self.L.conv2d_affine_act, self.cdt, x.ptr, x.ldc, cs.wf.data_ptr(), out.ptr, out.ldc, bs.scale.data_ptr(),
                   bs.shift.data_ptr(), resid.ptr if resid is not None else None, resid.ldc if resid is not None else 0, act, float(slope),
                   x.B, x.H, x.W, cs.cin_pad, out.H, out.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
 
@@ -696,19 +703,19 @@ class Plan:
             assert self.bwd[e["idx"]][0] is L.pw_bwd
             self.bwd[e["idx"]] = (L.pw_bwd, tuple(a2))
         else:
-            s2_shift = bool(L.conv2d_dgrad_s2_form_ok(dt, *g, e["head"][1]))    # the shift kernel's stride-2 form (csrc/conv_shift.hip MODE 3): its
+            s2_shift = bool(L.conv2d_dgrad_s2_form_ok(self.cdt, *g, e["head"][1]))    # the shift kernel's stride-2 form (csrc/conv_shift.hip MODE 3): its
             # store loop writes whole output rows from LDS and takes the y loads of the sums in its stride -- 208 -> 416: stand-alone reduce
             # 180 us in the step against +70 us in the data gradient, at the HBM-bound tail of the backward; one row per 8 x 31 tile.
             # (It pays at every size: the pixel classes of _fuse_pays describe the per-class im2col launches.)
             if not s2_shift and not self._fuse_pays(g):
                 return False
-            rows = int(L.conv2d_dgrad_bnsums_rows(dt, *g, e["head"][1]))
+            rows = int(L.conv2d_dgrad_bnsums_rows(self.cdt, *g, e["head"][1]))
             if rows <= 0 or rows > (self.fuse_max_rows_s2 if s2_shift else self.fuse_max_rows):
                 return False
             assert self.bwd[e["idx"]][0] is L.conv2d
             partial = self.f32(rows * 2 * y.C, zero=False)
             h = e["head"]
-            self.bwd[e["idx"]] = (L.conv2d_dgrad_bnsums, (dt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], *e["geom"], y.ptr, y.ldc,
+            self.bwd[e["idx"]] = (L.conv2d_dgrad_bnsums, (self.cdt, h[0], h[1], h[2], h[3], h[4], h[5], h[6], *e["geom"], y.ptr, y.ldc,
                                                           bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), act, float(slope),
                                                           partial.data_ptr()))
         e["used"] = True

@@ -1,7 +1,7 @@
 """Same-box A/B of the whole YOLOv3 training step (BASELINE config 3) under tuning hooks, interleaved in one process, one model per setting
 (plan-build-time switches need their own plan).
 usage: ab_step.py "c-30;c-31;c-31,w30005;P0" [rounds] [steps] [yolo|rektnet]
-  c<n> = mdcv_conv2d_set_variant(n), w<n> = mdcv_conv2d_wgrad_set_variant(n), p<n> = mdcv_pw_set_variant(n)   (applied before every timing block)
+  c<n> / w<n> = engine.Plan.tune_conv / tune_wgrad: ONE variant code per family (csrc/tune.h), carried by every conv / weight-gradient call of that model's plans
   P0 / P1 = engine.Plan.pw_fuse off / on, F<mask> = engine.Plan.fuse_skip, R<n> = engine.Plan.fuse_max_rows, Y0 / Y1 = engine.Plan.stats_xacc, B0 / B1 = engine.Plan.pw_bwd1, X<substr> = what-if timing without the launches whose name contains it, S0 = model.strict_targets off                                      (applied when the model is built)
 Every setting is applied on top of the first one (the baseline), which is re-applied in front of each."""
 import os, sys, tempfile, time, statistics
@@ -25,16 +25,14 @@ BUILD_DEFAULTS = dict(pw_fuse=engine.Plan.pw_fuse, fuse_skip=engine.Plan.fuse_sk
 
 
 def apply(codes):
-    for c in codes:
-        if not c or c[0] in "PFSRXYBK":
-            continue
-        {"c": L.cdll.mdcv_conv2d_set_variant, "w": L.cdll.mdcv_conv2d_wgrad_set_variant, "p": L.cdll.mdcv_pw_set_variant}[c[0]](int(c[1:]))
+    """(run-time hooks are gone with the library's tuning state: c<code> / w<code> are plan-build-time switches now, see apply_build)"""
 
 
 def apply_build(codes):
     engine.Plan.pw_fuse, engine.Plan.fuse_skip, engine.Plan.fuse_max_rows = BUILD_DEFAULTS["pw_fuse"], BUILD_DEFAULTS["fuse_skip"], BUILD_DEFAULTS["fuse_max_rows"]
     engine.Plan.stats_xacc = BUILD_DEFAULTS["sx"]
     engine.Plan.pw_bwd1 = BUILD_DEFAULTS["pb"]
+    engine.Plan.tune_conv = engine.Plan.tune_wgrad = 0
     from mdcv.yolo import models as _ym0
     _ym0._NetPlan.fork_on_dispatch = True
     _ym0._NetPlan.defer_slab_reduce = True
@@ -43,6 +41,10 @@ def apply_build(codes):
             from mdcv.yolo import models as _ym
             _ym._NetPlan.fork_on_dispatch = bool(int(c[1:]) & 1)
             _ym._NetPlan.defer_slab_reduce = not bool(int(c[1:]) & 2)               # K3: forks on dispatch, slab reduces NOT deferred
+        if c and c[0] == "c":
+            engine.Plan.tune_conv = int(c[1:])
+        if c and c[0] == "w":
+            engine.Plan.tune_wgrad = int(c[1:])
         if c and c[0] == "B":          # B0 / B1: 1x1 layers' backward as data gradient + weight gradient + reduce / in one launch (csrc/pw_bwd.hip)
             engine.Plan.pw_bwd1 = bool(int(c[1:]))
         if c and c[0] == "Y":          # Y0 / Y1: forward statistics as partial rows + finalize launch / through exact accumulators (csrc/exact_acc.h)

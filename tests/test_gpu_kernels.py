@@ -4,6 +4,9 @@ fp32 mode (exact-f32 MFMA) pins indexing/layout tightly; bf16 mode is checked ag
 bf16-rounded inputs with a tolerance that covers output rounding only.
 """
 import ctypes
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -20,6 +23,10 @@ TD = {F32: torch.float32, BF16: torch.bfloat16}
 
 def st():
     return torch.cuda.current_stream().cuda_stream
+
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+from variant_lib import VariantLib  # noqa: E402
 
 
 def to_nhwc(x, dtype, cpad=None):
@@ -151,7 +158,7 @@ def test_stride2_dgrad_all_classes_in_one_launch(case):
     """Large stride-2 data gradients (>= 512 tiles, even sizes, bf16) run the four output-parity classes inside ONE launch (each workgroup
     walks the classes of its tile of dY positions: conv_glds_kernel ALLCLS); set_variant(16) restores the four launches.  Both == torch,
     and the two forms agree bit for bit (same products, same K order per class); with the fused BatchNorm sums too."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     B, Ci, H, W, Co, fused = case
     g = torch.Generator().manual_seed(B + Ci + H)
@@ -201,7 +208,7 @@ VARIANT_CASES = [(2, 72, 15, 17, 255, 3, 1, 1, 1, True), (2, 136, 14, 14, 144, 3
 @pytest.mark.parametrize("dt", [F32, BF16], ids=["fp32", "bf16"])
 def test_conv_tile_variants(variant, dt):
     """Every tile configuration of the wide-layer dispatch (register-staged and LDS-DMA kernels) on fwd + dgrad."""
-    L = _lib.lib()
+    L = VariantLib()
     L.conv2d_set_variant(variant)
     try:
         for case in VARIANT_CASES:
@@ -565,7 +572,7 @@ def test_shift_tile_plans(variant):
     """Every tuning plan of the 3x3 shift kernel (256 / 128 / mixed rows, 192-row tiles; K loop in lockstep (-30) or with ping-pong wave
     groups on every forward launch (-31); 384-row ping-pong tiles forced (-201)) gives the forward result and the same BatchNorm
     statistics as the default plan."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     g = torch.Generator().manual_seed(5)
     outs = {}
@@ -751,7 +758,7 @@ WGRAD_SHIFT_CASES = [(2, 128, 13, 13, 128), (3, 128, 26, 20, 256), (1, 256, 52, 
 @pytest.mark.parametrize("case", WGRAD_SHIFT_CASES, ids=[str(c) for c in WGRAD_SHIFT_CASES])
 def test_wgrad_shift_kernel(case):
     """3x3 stride-1 weight gradient with the kw taps sharing one activation tile == torch reference == generic kernel."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     B, Ci, H, W, Co = case
     g = torch.Generator().manual_seed(Ci + Co + H)
@@ -794,7 +801,7 @@ WGRAD_STREAM_CASES = [(2, 16, 16, 12, 9, 1), (3, 16, 16, 80, 80, 2), (2, 16, 32,
 def test_wgrad_stream_kernel(case):
     """3x3 stride-1 weight gradient (dilation 1 / 2) with the nine taps reading one LDS activation ring == torch reference
     == generic kernel."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     B, Ci, Co, H, W, dil = case
     g = torch.Generator().manual_seed(Ci + Co + H + dil)
@@ -830,7 +837,7 @@ def test_wgrad_tiled_light_and_heavy_forms(case):
     """The channel-tiled LDS-ring weight gradient has two forms: 128 co x 64 ci per block on 8 waves (it owns its CU) and the light one,
     64 co x 64 ci on 4 waves (half a CU, the default for position streams of up to 600 K), csrc/wgrad_stream.hip.  Both == torch, both
     deterministic, and they agree to fp32 summation order (different splits)."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     B, Ci, Co, H, W, dil = case
     g = torch.Generator().manual_seed(Ci + Co + H + W)
@@ -867,7 +874,7 @@ def test_wgrad_tiled_light_and_heavy_forms(case):
 def test_wgrad_stream_kernel_channel_slices(case):
     """The LDS-ring weight gradient on operands that are channel slices of wider NHWC buffers (route / concat buffers: ldc > C,
     base pointer inside a pixel row) == the generic kernel on the same slices == torch."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     B, Ci, Co, H, W, dil = case
     g = torch.Generator().manual_seed(11 * Ci + Co + W)
@@ -922,7 +929,7 @@ def test_wgrad_stream_accumulate_and_determinism():
 def test_wgrad_stem_7x7_kernel(case):
     """RektNet's 7x7 / pad 3 stem (3 real input channels in a 16-channel buffer, 16 output channels): LDS-ring kernel == torch ==
     the generic kernel on the same buffers; accumulate flag; guard region behind the slabs."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     B, H, W = case
     Ci, Co = 3, 16
@@ -1007,7 +1014,7 @@ def test_conv2d_affine_act_inference_epilogue(case, dt):
 def test_shift_conv_64_wide_tile_column(case):
     """64- (and, variant -19, 32-) channel layers through the shift kernel's narrow tile column == the im2col kernel (-18): forward
     with BatchNorm statistics, data gradient with addsrc."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     B, Ci, H, W, Co = case
     gg = torch.Generator().manual_seed(B + Ci + W)
@@ -1053,7 +1060,7 @@ def test_shift_stride2_dgrad(case, with_add):
     """3x3 / stride-2 / pad-1 data gradients with 32 or 64 output channels run the shift kernel's stride-2 form (one accumulator set per
     output parity class, whole output rows per store; variant -60, the default) == the per-class im2col path (-29) == torch
     conv_transpose2d; ragged tiles and addsrc included.  case = (B, Cdy, Hdy, Wdy, Cdx)."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     B, Co, H, W, Ci = case                      # the layer: Ci -> Co, stride 2, input 2H x 2W
     gg = torch.Generator().manual_seed(B + Co + W + 9)
@@ -1276,7 +1283,7 @@ def test_shift_conv_2d_tiles(case, fused):
     """Images wider than the 1-D position stream takes run the shift kernel over 2-D pixel tiles (8 x 30 outputs + halo ring; variant -28,
     the default) == the im2col kernel (-27) == torch: forward with BatchNorm statistics, data gradient with addsrc and (fused) the
     BatchNorm-backward sums of the producer layer; ragged right / bottom tiles included."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     B, Ci, H, W, Co = case
     gg = torch.Generator().manual_seed(B + Ci + W + 5)
@@ -1339,7 +1346,7 @@ def test_shift_conv_2d_tiles(case, fused):
 def test_shift_conv_dilation2(case):
     """Dilation-2 / pad-2 layers through the shift kernel (variant -20: stream with two shared zero columns / rows) == the im2col kernel
     (-21) == torch: forward with BatchNorm statistics, data gradient with addsrc."""
-    L = _lib.lib()
+    L = VariantLib()
     dt = BF16
     B, Ci, H, W, Co = case
     gg = torch.Generator().manual_seed(B + Ci + W + 2)

@@ -1,11 +1,17 @@
 """Memory-safety checks on the GPU: every output / scratch buffer of the conv kernels is allocated with a sentinel-filled guard
 region behind it; a kernel that writes one element past what the C-ABI size queries promise fails here.  (Found in round 1: the
 shift conv's last 256-row tile wrote a second BatchNorm partial row past the buffer whenever ceil(positions/128) was odd.)"""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 from mdcv import _lib
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+from variant_lib import VariantLib  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 BF16 = _lib.BF16
@@ -37,7 +43,7 @@ GEOMS = [(32, 13, 13, 512, 1024, 3, 1, 1), (3, 52, 52, 128, 256, 3, 1, 1), (5, 2
 
 @pytest.mark.parametrize("geom", GEOMS, ids=str)
 def test_conv_kernels_stay_inside_their_buffers(geom):
-    L = _lib.lib()
+    L = VariantLib()
     B, H, W, Ci, Co, k, s, dil = geom
     pad = dil * (k - 1) // 2
     Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // s + 1, (W + 2 * pad - dil * (k - 1) - 1) // s + 1
