@@ -11,7 +11,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(ROOT, "include", "mdcv_hip.h")
-LIB_PATH = os.path.join(_HERE, "libmdcv_hip.so")
+LIB_PATH = os.environ.get("MDCV_LIB") or os.path.join(_HERE, "libmdcv_hip.so")      # MDCV_LIB: another BUILD of the same library (timing ablations, scripts/wgrad_ab.py)
 
 F32, BF16 = 0, 1
 

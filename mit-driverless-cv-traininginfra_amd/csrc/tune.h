@@ -56,6 +56,7 @@ struct MdcvTune {
   int stream_blocks = 0;   // force the target block count of every form; 0 = defaults below (1000 + blocks/64)
   int stream_tiled = 1;   // channel-tiled instantiation for the wide layers (Cin % 64 == 0, Cout % 128 == 0); 0 = off (1800)
   int stream_light_maxpos = 600000;   // light form up to this many padded stream positions (30003: everywhere, 30005: never, 30002: default)
+  int stream_light_depth = 1;      // its DMA prefetch depth (steps in flight behind the one being multiplied; 34000 + d)
   int stream_light_blocks = 256;   // its block target (33000 + n)
   int stream_tiled_blocks = 128;   // block target of the 8-wave tiled form (30000 + n).  A block fills its CU, and the weight gradients run BESIDE
       // the main stream: with one block on every CU the main stream's workgroups wait for whole weight-gradient blocks to
@@ -118,10 +119,11 @@ inline void mdcv_tune_apply_wgrad(MdcvTune& t, int v) {
   if (v >= 20000 && v < 30000) { t.wgrad_slots = v - 20000; return; }
   if (v >= 30000 && v < 40000) {
     const int b = v - 30000;
+    if (b >= 4001 && b <= 4002) { t.stream_light_depth = b - 4000; return; }
     if (b == 2) t.stream_light_maxpos = 600000;
     else if (b == 3) t.stream_light_maxpos = 1 << 30;
     else if (b == 5) t.stream_light_maxpos = 0;
-    else if (b >= 3000 && b < 5000) t.stream_light_blocks = b - 3000;
+    else if (b >= 3000 && b < 4000) t.stream_light_blocks = b - 3000;
     else t.stream_tiled_blocks = b > 0 ? b : 128;
     return;
   }

@@ -556,7 +556,7 @@ inline bool stream_cfg(int Cin, int Cout, StreamCfg& c, long long Mq = 0) {     
   else if (Cin == 64 && Cout == 128 && !TUNE().stream_tiled) c = {4, 8, 4, 1, 64, 2, 1};
   else if (TUNE().stream_tiled && Cin % 64 == 0 && Cout % 128 == 0 && Cin <= 4096 && Cout <= 4096) {
     c = {4, 8, 4, 1, 64, 2, 1}; c.tiled = true;
-    if (Mq > 0 && Mq <= TUNE().stream_light_maxpos) { c.nco = 4; c.nw = 4; c.d = 1; }   // light form
+    if (Mq > 0 && Mq <= TUNE().stream_light_maxpos) { c.nco = 4; c.nw = 4; c.d = TUNE().stream_light_depth; }   // light form
   }
   else return false;
   return true;
@@ -653,7 +653,7 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   a.xcd_chunk = (splits * a.tiles + 7) / 8;
   const int lds = stream_lds(c, W, dil);
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
-  if (c.tiled && c.nw == 4) return launch_stream<4, 4, 4, 1, 64, 1, 1, true, 4>(a, lds, dyb, xb, st);
+  if (c.tiled && c.nw == 4) return c.d == 1 ? launch_stream<4, 4, 4, 1, 64, 1, 1, true, 4>(a, lds, dyb, xb, st) : launch_stream<4, 4, 4, 1, 64, 2, 1, true, 4>(a, lds, dyb, xb, st);
   if (c.tiled) {
     if (c.d == 1) return launch_stream<4, 8, 4, 1, 64, 1, 1, true>(a, lds, dyb, xb, st);
     return launch_stream<4, 8, 4, 1, 64, 2, 1, true>(a, lds, dyb, xb, st);
