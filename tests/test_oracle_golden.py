@@ -392,7 +392,7 @@ def test_synth_oracle_heatmap_matches_dense_resize_and_blur():
 
 def test_autocast_bf16_cosine_curve_is_reference_output_and_the_oracle_agrees():
     """tests/golden/yolo_autocast_bf16_cos.json (the bar of the full-size bf16 GPU test) was produced by the REFERENCE's Darknet under
-    torch.autocast; the same procedure on the oracle, stored beside it, agrees to 1e-3 in every conv layer."""
+    torch.autocast; the same procedure on the oracle, stored beside it, agrees to 1.5e-3 in every conv layer."""
     import json
     d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "yolo_autocast_bf16_cos.json")))
     assert d["generator"] == "tests/golden/make_golden.py autocast" and d["batch"] == 32 and d["size"] == 416
