@@ -196,9 +196,11 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(float* __restrict__ sin
   f32x4_t acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // (inline asm on fixed registers: with the builtin, hipcc rotated the eight accumulators through ~50 v_accvgpr moves per round and the
+  //  probe read half the rate)
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k], 0, 0, 0);
+    for (int k = 0; k < 8; ++k) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b));
   }
   float s = 0.f;
 #pragma unroll
