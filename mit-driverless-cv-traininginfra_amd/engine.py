@@ -363,8 +363,15 @@ class Plan:
             return
         xw = x_wgrad if x_wgrad is not None else x
         cin_w = xw.C if x_wgrad is not None else cs.cin_pad
-        self._emit_wgrad_single(cs, xw, dy, cin_w)
-        self._emit_dgrad(cs, xnode, dy)
+        if self.wgrad_after_dgrad and cs.kh == 3 and cs.stride == 1:
+            self._emit_dgrad(cs, xnode, dy)
+            self._emit_wgrad_single(cs, xw, dy, cin_w)
+        else:
+            self._emit_wgrad_single(cs, xw, dy, cin_w)
+            self._emit_dgrad(cs, xnode, dy)
+
+    wgrad_after_dgrad = False          # A/B switch: a 3x3 layer's weight gradient forked BEHIND its data gradient (beside the next layers' BatchNorm passes)
+                                       # instead of beside it: 13.17 -> 13.62 ms (round 5, scripts/ab_step.py "B1;W1"; round 4: 13.75 -> 14.10)
 
     # ---- 1x1 layers: data gradient + weight-gradient slabs in ONE launch (csrc/pw_bwd.hip).  The three launches it replaces each read dy
     # from HBM and were bound by neither MFMA nor bandwidth (3.2 ms serial for 10 % of the step's FLOPs).  Same-box timing of the
