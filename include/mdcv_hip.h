@@ -303,6 +303,16 @@ int mdcv_pw_bwd_slabs(int dtype, long long M, int Cin, int Cout, int ldy, int ld
 int mdcv_pw_bwd(int dtype, const void* dy, int ldy, const void* x, int ldx, const void* wd_packed, void* dx, int lddx, const void* addsrc,
                 int ldadd, float* ws, int slabs, const void* fy, int ldfy, const float* fscale, const float* fshift, const float* fmean, int fact,
                 float fslope, float* fpartial, long long M, int Cin, int Cout, void* stream);
+/* Weight gradient of a conv -> BatchNorm -> activation layer whose INPUT needs no gradient (a network's first conv, CVC-YOLOv3/models.py:57-71 at
+ * index 0), straight from dz (gradient of the activation output) and y (raw conv output): dy = cA*g + cB*y + cC, g = dz * act'(scale*y + shift) is formed
+ * in the kernel's operand load, rounded to bf16 as mdcv_bn_act_bwd_apply rounds it -- bit-identical to apply + mdcv_conv2d_wgrad, without the apply
+ * pass over the layer's output tensor.  _ok() = 1 where the geometry takes this form (bf16, Cout_pad <= 32); splits as mdcv_conv2d_wgrad_splits_geom. */
+int mdcv_conv2d_wgrad_bnapply_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride,
+                                 int pad, int dil, int dz_ldc, int y_ldc, int x_ldc);
+int mdcv_conv2d_wgrad_bnapply(int dtype, const void* dz, int dz_ldc, const void* y, int y_ldc, const float* scale, const float* shift,
+                              const float* cA, const float* cB, const float* cC, int act, float slope, const void* x, int x_ldc, float* ws,
+                              int splits, float* dw_oihw, int accumulate, int B, int Hin, int Win, int Cin, int Cin_real, int Hout, int Wout,
+                              int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream);
 /* sum of fp32 weight-gradient slabs ws[splits][Cout_pad][KK * Cin_pad] into the OIHW gradient [Cout][Cin][KK] (fixed split order) */
 int mdcv_wgrad_reduce(const float* ws, int splits, float* dw_oihw, int accumulate, int Cout_pad, int Cout, int Cin_pad, int Cin, int KK,
                       void* stream);

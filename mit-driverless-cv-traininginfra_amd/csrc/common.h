@@ -83,6 +83,15 @@ template <> struct ET<bf16_t> {
   }
 };
 
+// BatchNorm(+activation)-backward apply of ONE element: dy = cA * g + cB * y + cC with g = dz * act'(scale * y + shift).  Explicit fused
+// multiply-adds in a fixed order: the apply pass (elementwise.hip) and the kernels that form dy in their operand load (conv_igemm.hip BNA)
+// must round identically -- left to -ffp-contract, two kernels contract the same expression differently and differ in the last fp32 bit.
+__device__ __forceinline__ float mdcv_bn_bwd_dy(float dz, float y, float scale, float shift, float cA, float cB, float cC, int act, float slope) {
+  const float pre = __builtin_fmaf(y, scale, shift);
+  const float g = dz * (act == 0 ? 1.f : (pre > 0.f ? 1.f : slope));
+  return __builtin_fmaf(cA, g, __builtin_fmaf(cB, y, cC));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -988,6 +988,9 @@ struct WgradArgs {
   int Hin, Win, Cin, Hout, Wout, Cout;
   int KH, KW, stride, pad, dil;
   int M, Ktot, tiles_k, tiles_ck, pix_per_split, blocks_total, xcd_chunk;
+  // BNA form of the narrow kernel (a layer whose input needs no gradient): `dy` holds dz, the operand dy = cA g + cB y + cC is formed in LDS
+  const void* y; int y_ldc, act, creal; float slope;
+  const float* s1; const float* b1; const float* cA; const float* cB; const float* cC;
 };
 
 // 128(co) x 128(k) output tile per block, 4 waves of 64x64.  One step = 128 pixels (bf16; 64 in fp32) = 256 bytes per LDS row:
@@ -1495,10 +1498,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 // The dY tile is [64 px][32 co] = 64-byte rows, 16 pixel rows per 1 KiB chunk (one chunk per wave), no swizzle needed (the 4 rows
 // of a transpose read sit 64 B apart -> distinct banks).  Each wave owns a 32 x 32 slice: 4 MFMAs per 32-pixel k-step instead of
 // 16 MFMAs on a tile that would be 75-87 % zero padding.  These layers are HBM-bound; the point is to stop wasting issue slots.
-template <bool SAME, int STAGES>
+// BNA (round 5): the layer's input needs no gradient (YOLOv3's first conv), so dy = cA g + cB y + cC, g = dz act'(scale y + shift), has this
+// kernel as its ONLY reader: it is formed here, in LDS, from the dz and y tiles (two DMAs instead of one; every thread transforms one 16-byte
+// vector of the 64 x 32 tile per step, rounding to bf16 exactly as mdcv_bn_act_bwd_apply does -- the results are bit-identical to apply +
+// this kernel), and the BatchNorm-apply pass over the largest tensor of the network (416^2 x 32 at batch 32: read 708 MB, write 354 MB, then
+// read again here) never runs.  It sat at the exposed tail of the backward: apply 193 us on the main queue, then this kernel 131 us alone.
+template <bool SAME, int STAGES, bool BNA = false>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a, unsigned dy_bytes, unsigned x_bytes) {
-  constexpr int BP = 64, NJ = 4, GD = 5;
-  constexpr int TA = BP * 64, TB = BP * 256;   // bytes per operand tile
+  constexpr int BP = 64, NJ = 4, GD = BNA ? 6 : 5;
+  constexpr int TA = BP * 64 * (BNA ? 2 : 1), TB = BP * 256;   // bytes per operand tile (BNA: dz tile + y tile)
   constexpr int OROW = 132;
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -1510,6 +1518,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
   const int tile_k = logical - split * a.tiles_ck;          // tiles_co == 1
   const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, dy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BNA ? a.y : a.dy), 0,
+                                                                      BNA ? (unsigned)a.M * (unsigned)a.y_ldc * 2u : 0u, 0x00020000);
 
   // A (dY) DMA role: chunk = wave; lane fills pixel row ra = lane>>2, 16-byte slot lane&3; rows with bit 2 set hold their two
   // 32-byte halves swapped, so the 8 consecutive rows one LDS service group reads (64-byte rows: 4 rows per bank period) hit all banks
@@ -1544,6 +1554,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
       const int m = m0 + 16 * wave + ra;
       const unsigned offa = (m < p_end && a_ok) ? __umul24((unsigned)m, ldy2) + (unsigned)coA * 2u : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t*)(sA + wave * 1024), 16, offa, 0, 0, 0);
+      if constexpr (BNA) {
+        const unsigned offy = (m < p_end && a_ok) ? __umul24((unsigned)m, (unsigned)a.y_ldc * 2u) + (unsigned)coA * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void_t*)(sA + BP * 64 + wave * 1024), 16, offy, 0, 0, 0);
+      }
     }
     int m = m0 + 4 * wave + r;
     int img = 0, ho = 0, wo = 0;
@@ -1601,6 +1615,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
     return __builtin_bit_cast(bf16x8_t, v);
   };
 
+  // BNA transform role: thread tid owns the 16-byte vector at byte tid * 16 of the 64 x 64-byte tile: row tid >> 2 (the row's pixel is m0 + row),
+  // physical slot tid & 3 = channels coT .. coT + 7 (the DMA's half swap for rows with bit 2 set)
+  const int rowT = tid >> 2, coT = ((tid & 3) ^ (2 * ((rowT >> 2) & 1))) * 8;
+  float ts1[BNA ? 8 : 1], tb1[BNA ? 8 : 1], tA[BNA ? 8 : 1], tB[BNA ? 8 : 1], tC[BNA ? 8 : 1];
+  if constexpr (BNA) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = coT + e < a.creal;
+      ts1[e] = ok ? a.s1[coT + e] : 0.f; tb1[e] = ok ? a.b1[coT + e] : 0.f;
+      tA[e] = ok ? a.cA[coT + e] : 0.f; tB[e] = ok ? a.cB[coT + e] : 0.f; tC[e] = ok ? a.cC[coT + e] : 0.f;
+    }
+  }
+  auto transform = [&](int slot, int m0) {                   // dz tile -> dy tile, in place (rows past the split: zeros, not cC)
+    unsigned char* sA = smem + slot * (TA + TB);
+    const unsigned ad = lds_addr(sA) + (unsigned)(tid * 16);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t rd, ry4;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(rd) : "v"(ad) : "memory");            // (asm: a plain LDS access behind an LDS-DMA gets a compiler-inserted vmcnt(0))
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(ry4) : "v"(ad) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rd), "+v"(ry4)::"memory");
+    float d[8], v[8], o[8];
+    ET<bf16_t>::unpack(make_uint4(rd[0], rd[1], rd[2], rd[3]), d);
+    ET<bf16_t>::unpack(make_uint4(ry4[0], ry4[1], ry4[2], ry4[3]), v);
+    const bool live = m0 + rowT < p_end;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = live ? mdcv_bn_bwd_dy(d[e], v[e], ts1[e], tb1[e], tA[e], tB[e], tC[e], a.act, a.slope) : 0.f;
+    const uint4 qo = ET<bf16_t>::pack(o);
+    const u32x4_t wo = {qo.x, qo.y, qo.z, qo.w};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(wo) : "memory");
+  };
+
   f32x4_t acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1641,6 +1686,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_narrow_kernel(WgradArgs a,
       ++issued;
       islot = islot + 1 == STAGES ? 0 : islot + 1;
     }
+    if constexpr (BNA) {
+      transform(slot, p_begin + st * BP);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                          // the dy tile is complete before any wave's transpose reads
+    }
     compute(slot);
     slot = slot + 1 == STAGES ? 0 : slot + 1;
   }
@@ -1679,11 +1729,11 @@ static int launch_wgrad_dma_t(const WgradArgs& a, unsigned grid, hipStream_t st,
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
-template <bool SAME, int STAGES>
+template <bool SAME, int STAGES, bool BNA = false>
 static int launch_wgrad_narrow_t(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
-  constexpr int LDS = STAGES * (64 * 64 + 64 * 256);   // 20 KiB per stage (the 32 x 132 fp32 epilogue staging fits inside)
+  constexpr int LDS = STAGES * (64 * 64 * (BNA ? 2 : 1) + 64 * 256);   // 20 (24) KiB per stage (the 32 x 132 fp32 epilogue staging fits inside)
   static bool attr = false;
-  auto kern = conv_wgrad_dma_narrow_kernel<SAME, STAGES>;
+  auto kern = conv_wgrad_dma_narrow_kernel<SAME, STAGES, BNA>;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
@@ -2155,6 +2205,49 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   else if (dtype == MDCV_F32) MDCV_LAUNCH(conv_wgrad_kernel<float>, dim3(grid), dim3(256), lds, st, a);
   else return MDCV_EARG;
   MDCV_CHECK_LAUNCH();
+  return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, KH * KW, accumulate, st);
+}
+
+// ---- weight gradient of a conv -> BatchNorm -> activation layer whose INPUT needs no gradient (the first layer), straight from (dz, y): the
+// BatchNorm-backward apply pass is folded into the operand load of the narrow kernel (conv_wgrad_dma_narrow_kernel BNA).  _ok() = 1 when the
+// geometry takes that kernel (bf16, Cout_pad <= 32, not one of the LDS-ring forms); splits = mdcv_conv2d_wgrad_splits_geom of the same geometry.
+int mdcv_conv2d_wgrad_bnapply_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride,
+                                 int pad, int dil, int dz_ldc, int y_ldc, int x_ldc) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_WGRAD);
+  if (dtype != MDCV_BF16 || Cout > 32 || (Cin & 7) || (Cout & 7) || (dz_ldc & 7) || (y_ldc & 7) || (x_ldc & 7) || TUNE().wgrad_variant != 0) return 0;
+  if (Hin == Hout && Win == Wout && mdcv_wgrad_stem_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dz_ldc, x_ldc)) return 0;
+  if (use_wgrad_stream(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dz_ldc, x_ldc)) return 0;
+  if (use_wgrad_shift(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dz_ldc, x_ldc)) return 0;
+  const long long M = (long long)B * Hout * Wout;
+  const int ldmax = dz_ldc > y_ldc ? dz_ldc : y_ldc;
+  return M * ldmax * 2 < (1LL << 31) && (long long)B * Hin * Win * x_ldc * 2 < (1LL << 31) && TUNE().conv_variant != 0 &&
+         (long long)B * Hin * Win + 256 < (1LL << 24) && M + 256 < (1 << 24) && Wout >= 8 && x_ldc < (1 << 23) && ldmax < (1 << 23);
+}
+int mdcv_conv2d_wgrad_bnapply(int dtype, const void* dz, int dz_ldc, const void* y, int y_ldc, const float* scale, const float* shift,
+                              const float* cA, const float* cB, const float* cC, int act, float slope, const void* x, int x_ldc, float* ws,
+                              int splits, float* dw_oihw, int accumulate, int B, int Hin, int Win, int Cin, int Cin_real, int Hout, int Wout,
+                              int Cout, int Cout_real, int KH, int KW, int stride, int pad, int dil, void* stream) {
+  MDCV_TUNE_ENTRY(dtype, MDCV_TUNE_WGRAD);
+  if (!dz || !y || !scale || !shift || !cA || !cB || !cC || !x || !ws || !dw_oihw || splits < 1) return MDCV_EARG;
+  if (!mdcv_conv2d_wgrad_bnapply_ok(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dz_ldc, y_ldc, x_ldc)) return MDCV_EARG;
+  WgradArgs a;
+  a.dy = dz; a.x = x; a.ws = ws; a.dy_ldc = dz_ldc; a.x_ldc = x_ldc;
+  a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = dil;
+  a.M = B * Hout * Wout; a.Ktot = KH * KW * Cin;
+  a.pix_per_split = cdiv(cdiv(a.M, splits), 128) * 128;
+  if (cdiv(a.M, a.pix_per_split) != splits) return MDCV_EARG;
+  a.tiles_k = cdiv(a.Ktot, 128);
+  a.tiles_ck = a.tiles_k;
+  a.blocks_total = a.tiles_ck * splits;
+  a.xcd_chunk = cdiv(a.blocks_total, 8);
+  a.y = y; a.y_ldc = y_ldc; a.act = act; a.slope = act == 2 ? 0.f : slope; a.creal = Cout_real;
+  a.s1 = scale; a.b1 = shift; a.cA = cA; a.cB = cB; a.cC = cC;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)(a.xcd_chunk * 8), dyb = (unsigned)((long long)a.M * dz_ldc * 2), xb = (unsigned)((long long)B * Hin * Win * x_ldc * 2);
+  const bool same = stride == 1 && Hin == Hout && Win == Wout;
+  const int rc = same ? launch_wgrad_narrow_t<true, 4, true>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 4, true>(a, grid, st, dyb, xb);
+  if (rc) return rc;
   return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, KH * KW, accumulate, st);
 }
 

@@ -664,11 +664,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnBwdArgs a) {
       if constexpr (DUAL) ET<T>::unpack(qw[u], w);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        float pre = v[e] * s1[e] + b1[e];
-        if constexpr (DUAL) pre += w[e] * s2[e] + b2[e];
-        const float g = d[e] * act_grad(pre, a.act, a.slope);
-        o1[e] = A1[e] * g + B1[e] * v[e] + C1[e];
-        if constexpr (DUAL) o2[e] = A2[e] * g + B2[e] * w[e] + C2[e];
+        if constexpr (!DUAL) {
+          o1[e] = mdcv_bn_bwd_dy(d[e], v[e], s1[e], b1[e], A1[e], B1[e], C1[e], a.act, a.slope);     // (shared with the operand-load forms: bit-identical)
+        } else {
+          float pre = v[e] * s1[e] + b1[e];
+          pre += w[e] * s2[e] + b2[e];
+          const float g = d[e] * act_grad(pre, a.act, a.slope);
+          o1[e] = A1[e] * g + B1[e] * v[e] + C1[e];
+          o2[e] = A2[e] * g + B2[e] * w[e] + C2[e];
+        }
       }
       *reinterpret_cast<uint4*>(dy1 + p * a.ldy1 + cv * VEC) = ET<T>::pack(o1);
       if constexpr (DUAL) *reinterpret_cast<uint4*>(dy2 + p * a.ldy2 + cv * VEC) = ET<T>::pack(o2);

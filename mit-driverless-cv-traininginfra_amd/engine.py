@@ -604,10 +604,11 @@ class Plan:
                   stats_partial.data_ptr() if stats_partial is not None else None, x.M, cs.cin_pad, cs.cout_pad)
         self.pw_fwd_count = getattr(self, "pw_fwd_count", 0) + 1
 
-    def emit_bn_act_bwd(self, dout, y1, bs1, act, slope, y2=None, bs2=None):
-        """Returns the gradient(s) of the raw conv output(s): dy1 [, dy2]."""
+    def emit_bn_act_bwd(self, dout, y1, bs1, act, slope, y2=None, bs2=None, apply=True):
+        """Returns the gradient(s) of the raw conv output(s): dy1 [, dy2].  apply=False: only the statistics part (sums + coefficients); the
+        consumer forms dy itself (emit_first_conv_bwd) and nothing is returned."""
         L, dt = self.L, self.dtype
-        dy1 = self._alloc_like(y1)
+        dy1 = self._alloc_like(y1) if apply else None
         dy2 = self._alloc_like(y2) if y2 is not None else None
         n = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
         pws = self.f32(L.bn_act_bwd_reduce_ws_floats(dt, y1.M, y1.C, 3 if y2 is not None else 2), zero=False)
@@ -624,6 +625,9 @@ class Plan:
                       bs1.bn.weight.data_ptr(), g1.data_ptr(), b1.data_ptr(), n(bs1.cA), n(bs1.cB), n(bs1.cC),
                       bs2.bn.weight.data_ptr() if bs2 else None, n(g2), n(b2), n(bs2.cA) if bs2 else None, n(bs2.cB) if bs2 else None,
                       n(bs2.cC) if bs2 else None)
+        if not apply:
+            assert y2 is None
+            return None
         self.call(self.bwd, L.bn_act_bwd_apply, dt, dout.ptr, dout.ldc, y1.ptr, y1.ldc, n(bs1.scale), n(bs1.shift), n(bs1.cA),
                   n(bs1.cB), n(bs1.cC), dy1.ptr, dy1.ldc,
                   y2.ptr if y2 is not None else None, y2.ldc if y2 is not None else 0,
@@ -631,6 +635,39 @@ class Plan:
                   n(bs2.cB) if bs2 else None, n(bs2.cC) if bs2 else None,
                   dy2.ptr if dy2 is not None else None, dy2.ldc if dy2 is not None else 0, y1.M, y1.C, act, float(slope))
         return (dy1, dy2) if y2 is not None else dy1
+
+    # ---- first layer (its input needs no gradient): dy = BatchNorm-backward(dz, y) has the weight gradient as its ONLY reader, so it is formed in
+    # that kernel's operand load (mdcv_conv2d_wgrad_bnapply, conv_igemm.hip BNA) and the apply pass over the network's largest tensor never runs.
+    # YOLOv3 416^2 batch 32: apply 193 us on the main queue + weight gradient 131 us alone behind it, at the exposed tail of the backward.
+    wgrad_bnapply = True               # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
+
+    def emit_first_conv_bwd(self, dout, y, bs, act, slope, cs, xnode):
+        """Backward of conv -> BatchNorm -> activation for a layer whose input needs no gradient: statistics as usual, then ONE weight-gradient
+        launch that reads (dz, y) itself.  Bit-identical to apply + weight gradient.  Returns False (nothing emitted) when the layer does not
+        take this form."""
+        L = self.L
+        x = xnode.act
+        if not self.wgrad_bnapply or xnode.needs_grad or self.dtype != BF16 or cs.bias is not None:
+            return False
+        geom = (x.B, x.H, x.W, cs.cin_pad, y.H, y.W, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil)
+        if not int(L.conv2d_wgrad_bnapply_ok(self.wdt, *geom, dout.ldc, y.ldc, x.ldc)):
+            return False
+        self.emit_bn_act_bwd(dout, y, bs, act, slope, apply=False)
+        gw = self.param_grad(cs.weight)
+        splits = int(L.conv2d_wgrad_splits_geom(self.wdt, *geom, dout.ldc, x.ldc))
+        self.ws_floats = max(self.ws_floats, splits * cs.cout_pad * cs.kh * cs.kw * cs.cin_pad)
+        plan = self
+        n = lambda t: t.data_ptr()  # noqa: E731
+
+        def wgrad(stream):
+            return L.conv2d_wgrad_bnapply(plan.wdt, dout.ptr, dout.ldc, y.ptr, y.ldc, n(bs.scale), n(bs.shift), n(bs.cA), n(bs.cB), n(bs.cC), act,
+                                          float(slope), x.ptr, x.ldc, plan.wgrad_ws(stream).data_ptr(), splits, gw.data_ptr(), 0, x.B, x.H, x.W,
+                                          cs.cin_pad, cs.cin, y.H, y.W, cs.cout_pad, cs.cout, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil, stream)
+        wgrad.__name__ = "conv2d_wgrad"
+        wgrad.info = (x.B, x.H, x.W, cs.cin_pad, y.H, y.W, cs.cout_pad, cs.kh, cs.stride, splits)
+        self.bwd.append((wgrad, ()))
+        self.first_conv_fused = True
+        return True
 
     # On by default (Plan.fuse_bn = False restores the two-pass form).  YOLOv3 416^2 B=32: it removes 0.95 ms of stand-alone reduce kernels
     # per step and adds ~1.1 ms to the 66 data gradients' store loops (the y loads are HBM misses whose latency is exposed once per

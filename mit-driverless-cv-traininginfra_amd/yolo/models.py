@@ -933,8 +933,9 @@ class Darknet(FlatParamsMixin, nn.Module):
                         continue
                     if rnode is not None:
                         plan.grad_identity(rnode, z.grad)
-                    dy = plan.emit_bn_act_bwd(z.grad, y, bs, act_code, slope)
-                    plan.emit_conv_bwd(cs, xn, y, dy)
+                    if not plan.emit_first_conv_bwd(z.grad, y, bs, act_code, slope, cs, xn):
+                        dy = plan.emit_bn_act_bwd(z.grad, y, bs, act_code, slope)
+                        plan.emit_conv_bwd(cs, xn, y, dy)
                 elif kind == "shortcut":
                     _, a, b, z = r
                     if z.gstate == "none":

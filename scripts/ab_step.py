@@ -34,6 +34,7 @@ def apply_build(codes):
     engine.Plan.pw_bwd1 = BUILD_DEFAULTS["pb"]
     engine.Plan.tune_conv = engine.Plan.tune_wgrad = 0
     engine.Plan.wgrad_after_dgrad = False
+    engine.Plan.wgrad_bnapply = True
     from mdcv.yolo import models as _ym0
     _ym0._NetPlan.fork_on_dispatch = True
     _ym0._NetPlan.defer_slab_reduce = True
@@ -46,6 +47,8 @@ def apply_build(codes):
             engine.Plan.tune_conv = int(c[1:])
         if c and c[0] == "w":
             engine.Plan.tune_wgrad = int(c[1:])
+        if c and c[0] == "G":          # G0 / G1: the first layer's BatchNorm-apply pass as a launch / inside its weight gradient's operand load
+            engine.Plan.wgrad_bnapply = bool(int(c[1:]))
         if c and c[0] == "W":          # W0 / W1: a 3x3 layer's weight gradient forked in front of / behind its data gradient
             engine.Plan.wgrad_after_dgrad = bool(int(c[1:]))
         if c and c[0] == "B":          # B0 / B1: 1x1 layers' backward as data gradient + weight gradient + reduce / in one launch (csrc/pw_bwd.hip)

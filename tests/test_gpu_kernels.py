@@ -662,6 +662,56 @@ def test_pw_block_forward(case):
         np.testing.assert_allclose(tot.cpu().numpy(), s1.double().sum(0).cpu().numpy(), rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("case", [(2, 3, 40, 56, 32, 3, 1, 1, 1), (3, 3, 33, 47, 16, 3, 1, 1, 1), (2, 5, 30, 30, 32, 3, 2, 1, 1), (1, 8, 64, 40, 24, 1, 1, 0, 0)], ids=str)
+def test_wgrad_with_bn_apply_in_the_operand_load(case):
+    """mdcv_conv2d_wgrad_bnapply (a first layer's weight gradient straight from dz and y: the BatchNorm-backward apply formed in LDS, rounded to bf16
+    like the apply pass) == mdcv_bn_act_bwd_apply + mdcv_conv2d_wgrad BIT FOR BIT, and == F.conv2d autograd on the float64 dy within bf16 rounding;
+    ragged channel counts (16 / 24 real of 16 / 24 / 32 padded), ragged last pixel tiles and splits, stride 2, a 1x1 kernel, ReLU / leaky / none."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, H, W, Co, k, stride, pad, act = case
+    g = torch.Generator().manual_seed(B + Ci + W + Co)
+    cip, cop = pad8(Ci), pad8(Co)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    M = B * Ho * Wo
+    x = torch.randn(B, Ci, H, W, generator=g)
+    xb = to_nhwc(x, dt)
+    dz = to_nhwc(torch.randn(B, Co, Ho, Wo, generator=g), dt)
+    y = to_nhwc(torch.randn(B, Co, Ho, Wo, generator=g) * 1.5, dt)
+    scale = (torch.rand(Co, generator=g) + 0.5).cuda(); shift = (torch.randn(Co, generator=g) * 0.3).cuda()
+    cA = (torch.rand(Co, generator=g) + 0.5).cuda(); cB = (torch.randn(Co, generator=g) * 0.05).cuda(); cC = (torch.randn(Co, generator=g) * 0.05).cuda()
+    geom = (B, H, W, cip, Ho, Wo, cop, k, k, stride, pad, 1)
+    assert L.conv2d_wgrad_bnapply_ok(dt, *geom, cop, cop, cip) == 1
+    splits = L.conv2d_wgrad_splits_geom(dt, *geom, cop, cip)
+    # the two-launch form
+    dy = torch.zeros(B, Ho, Wo, cop, dtype=torch.bfloat16, device="cuda")
+    L.check(L.bn_act_bwd_apply(dt, dz.data_ptr(), cop, y.data_ptr(), cop, scale.data_ptr(), shift.data_ptr(), cA.data_ptr(), cB.data_ptr(), cC.data_ptr(),
+                               dy.data_ptr(), cop, None, 0, None, None, None, None, None, None, 0, M, Co, act, 0.1, st()))
+    ws0 = torch.empty(splits * cop * k * k * cip, device="cuda")
+    dw0 = torch.full((Co, Ci, k, k), 7.0, device="cuda")
+    L.check(L.conv2d_wgrad(dt, dy.data_ptr(), cop, xb.data_ptr(), cip, ws0.data_ptr(), splits, dw0.data_ptr(), 0, B, H, W, cip, Ci, Ho, Wo, cop, Co,
+                           k, k, stride, pad, 1, st()), "wgrad")
+    # one launch
+    ws1 = torch.full((splits * cop * k * k * cip,), float("nan"), device="cuda")
+    dw1 = torch.full((Co, Ci, k, k), 7.0, device="cuda")
+    L.check(L.conv2d_wgrad_bnapply(dt, dz.data_ptr(), cop, y.data_ptr(), cop, scale.data_ptr(), shift.data_ptr(), cA.data_ptr(), cB.data_ptr(),
+                                   cC.data_ptr(), act, 0.1, xb.data_ptr(), cip, ws1.data_ptr(), splits, dw1.data_ptr(), 0, B, H, W, cip, Ci, Ho, Wo,
+                                   cop, Co, k, k, stride, pad, 1, st()), "wgrad_bnapply")
+    torch.cuda.synchronize()
+    assert torch.equal(dw0, dw1), float((dw0 - dw1).abs().max() / dw0.abs().max())
+    # float64 reference from the bf16-rounded operands
+    dzf, yf = dz[..., :Co].double().cpu(), y[..., :Co].double().cpu()
+    pre = y[..., :Co].float().cpu() * scale.cpu() + shift.cpu()
+    slope = {0: 1.0, 1: 0.1, 2: 0.0}[act]
+    gg = dzf * torch.where(pre > 0, torch.ones_like(dzf), torch.full_like(dzf, float(np.float32(slope)))) if act else dzf
+    dyf = (cA.double().cpu() * gg + cB.double().cpu() * yf + cC.double().cpu()).permute(0, 3, 1, 2).contiguous()
+    wz = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xb[..., :Ci].double().cpu().permute(0, 3, 1, 2), wz, None, stride, pad).backward(dyf)
+    ref = wz.grad.numpy()
+    np.testing.assert_allclose(dw1.cpu().numpy(), ref, rtol=0, atol=3e-3 * max(1.0, float(np.abs(ref).max())))
+    assert L.conv2d_wgrad_bnapply_ok(dt, B, H, W, 64, Ho, Wo, 64, k, k, stride, pad, 1, 64, 64, 64) == 0        # wide layers keep their apply pass
+
+
 PWB_CASES = [  # (M, Cout = channels of dy, real Cout, Cin = channels of x / dx, extra channel stride, addsrc)
     (32 * 21 + 17, 256, 256, 512, 0, True), (5408, 512, 512, 1024, 0, True), (3000, 128, 128, 256, 8, False), (2703, 256, 255, 256, 0, False),
     (700, 64, 64, 128, 16, True), (86528, 128, 128, 256, 0, True), (1100, 256, 256, 768, 8, True), (96, 128, 128, 64, 0, False)]
