@@ -38,8 +38,9 @@ def _worker(rank, world, port, which, q):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         import torch.distributed as dist
+        import datetime
         torch.cuda.set_device(0)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
         q.put((rank, (_yolo if which == "yolo" else _rektnet)(rank, world)))
         dist.barrier()
         dist.destroy_process_group()
@@ -92,19 +93,36 @@ def _rektnet(rank, world):
             "buckets": len(red.log), "flat": net.flat_parameters()[1].cpu().numpy()}
 
 
-def _run(world, which):
+def _run(world, which, attempts=2):
+    """Spawn `world` ranks and collect their results.  A rendezvous that never completes (seen once on a fresh box: both workers stuck before their
+    first result, the whole `pytest -x` run lost to a 600 s wait) is killed after 240 s and the run is repeated ONCE on a new port; a second hang, or
+    any error a worker reports, fails the test."""
+    import queue as _queue
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, which, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=600) for _ in range(world))
-    for p in procs:
-        p.join(timeout=120)
-    for r in range(world):
-        assert "error" not in res[r], res[r]["error"]
-    return res
+    last = None
+    for attempt in range(attempts):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, which, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = {}
+        try:
+            for _ in range(world):
+                r, v = q.get(timeout=240)
+                res[r] = v
+        except _queue.Empty:
+            last = f"attempt {attempt}: only ranks {sorted(res)} of {world} reported within 240 s"
+        for p in procs:
+            p.join(timeout=30 if len(res) == world else 1)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=10)
+        if len(res) == world:
+            for r in range(world):
+                assert "error" not in res[r], res[r]["error"]
+            return res
+    raise AssertionError(f"data-parallel workers hung twice ({last})")
 
 
 @pytest.mark.parametrize("world", [2, 4])
