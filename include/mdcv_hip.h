@@ -306,7 +306,8 @@ int mdcv_pw_bwd(int dtype, const void* dy, int ldy, const void* x, int ldx, cons
 /* Weight gradient of a conv -> BatchNorm -> activation layer whose INPUT needs no gradient (a network's first conv, CVC-YOLOv3/models.py:57-71 at
  * index 0), straight from dz (gradient of the activation output) and y (raw conv output): dy = cA*g + cB*y + cC, g = dz * act'(scale*y + shift) is formed
  * in the kernel's operand load, rounded to bf16 as mdcv_bn_act_bwd_apply rounds it -- bit-identical to apply + mdcv_conv2d_wgrad, without the apply
- * pass over the layer's output tensor.  _ok() = 1 where the geometry takes this form (bf16, Cout_pad <= 32); splits as mdcv_conv2d_wgrad_splits_geom. */
+ * pass over the layer's output tensor.  _ok() = 1 where the geometry takes this form (bf16, Cout_pad <= 32); splits: any count
+ * mdcv_conv2d_wgrad_splits_geom returns for the geometry -- the plans ask it with MDCV_TUNED(dtype, 20768), a target of three blocks per CU. */
 int mdcv_conv2d_wgrad_bnapply_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride,
                                  int pad, int dil, int dz_ldc, int y_ldc, int x_ldc);
 int mdcv_conv2d_wgrad_bnapply(int dtype, const void* dz, int dz_ldc, const void* y, int y_ldc, const float* scale, const float* shift,

@@ -2246,7 +2246,11 @@ int mdcv_conv2d_wgrad_bnapply(int dtype, const void* dz, int dz_ldc, const void*
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)(a.xcd_chunk * 8), dyb = (unsigned)((long long)a.M * dz_ldc * 2), xb = (unsigned)((long long)B * Hin * Win * x_ldc * 2);
   const bool same = stride == 1 && Hin == Hout && Win == Wout;
-  const int rc = same ? launch_wgrad_narrow_t<true, 4, true>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 4, true>(a, grid, st, dyb, xb);
+  const int stages = TUNE().wgrad_bna_stages;
+  int rc;
+  if (stages <= 2) rc = same ? launch_wgrad_narrow_t<true, 2, true>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 2, true>(a, grid, st, dyb, xb);
+  else if (stages == 3) rc = same ? launch_wgrad_narrow_t<true, 3, true>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 3, true>(a, grid, st, dyb, xb);
+  else rc = same ? launch_wgrad_narrow_t<true, 4, true>(a, grid, st, dyb, xb) : launch_wgrad_narrow_t<false, 4, true>(a, grid, st, dyb, xb);
   if (rc) return rc;
   return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, KH * KW, accumulate, st);
 }

@@ -26,6 +26,10 @@ struct MdcvTune {
   int conv_s2_split = 512;   // ALLCLS grids below this many 128 x 128 tiles run two workgroups per tile (set_variant 4000 + n; 26->52 and 13->26 at batch 32)
   int conv_s2_split_on = 1;   // (set_variant 14 = off: those layers go back to four class launches; 15 = on)
   int wgrad_slots = 512;   // target block count of the generic weight-gradient kernel (tuning hook 20000 + n)
+  int wgrad_bna_stages = 2;   // ring stages of the narrow kernel with the BatchNorm apply in its operand load (34012..34014 -> 2..4), 24 KiB each.  The kernel is
+      // HBM-latency-bound with little work per step: it wants blocks, not depth.  416^2 x 32 at batch 32, alone (scripts/bna_ab.py), stages 2 / 3 / 4:
+      // 258 / 262 / 391 us at the generic target of 512 blocks (four stages = 96 KiB leave room for ONE block per CU: two rounds),
+      // 191 / 267 / 388 us at 768 blocks (three two-stage blocks per CU in one round; the plan asks for that split count, engine.emit_first_conv_bwd)
   int wgrad_variant = 0;   // 0: default dispatch ; 4: generic address path ; 5: wide tile everywhere ; 8 / 9 / 10 / 11: kernel-family choices (use_wgrad_*)
   // ---- conv_shift.hip
   int shift_ring = 4;   // weight-ring depth of sparse grids (<= 256 tiles); 3: off (tuning hook: mdcv_conv2d_set_variant(-3 / -4))
@@ -120,6 +124,7 @@ inline void mdcv_tune_apply_wgrad(MdcvTune& t, int v) {
   if (v >= 30000 && v < 40000) {
     const int b = v - 30000;
     if (b >= 4001 && b <= 4002) { t.stream_light_depth = b - 4000; return; }
+    if (b >= 4012 && b <= 4014) { t.wgrad_bna_stages = b - 4010; return; }
     if (b == 2) t.stream_light_maxpos = 600000;
     else if (b == 3) t.stream_light_maxpos = 1 << 30;
     else if (b == 5) t.stream_light_maxpos = 0;

@@ -654,7 +654,10 @@ class Plan:
             return False
         self.emit_bn_act_bwd(dout, y, bs, act, slope, apply=False)
         gw = self.param_grad(cs.weight)
-        splits = int(L.conv2d_wgrad_splits_geom(self.wdt, *geom, dout.ldc, x.ldc))
+        # block target 768 = three 48 KiB (two-stage) blocks on every CU in ONE round: alone at 416^2 batch 32 (scripts/bna_ab.py) 191 us against
+        # 262 us with the generic target of 512 and three stages, 391 us with four stages (96 KiB: one block per CU, two rounds)
+        sdt = _lib.tuned(self.dtype, 20000 + 768) if self.tune_wgrad == 0 else self.wdt
+        splits = int(L.conv2d_wgrad_splits_geom(sdt, *geom, dout.ldc, x.ldc))
         self.ws_floats = max(self.ws_floats, splits * cs.cout_pad * cs.kh * cs.kw * cs.cin_pad)
         plan = self
         n = lambda t: t.data_ptr()  # noqa: E731
