@@ -51,9 +51,13 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int
 // overlap.  The asm read is invisible to that pass; the kernel orders DMA and reads itself (counted vmcnt + barrier) and waits for
 // the reads with wait_frags() below, whose "+v" operands make every MFMA depend on the wait.
 template <int OFF> __device__ __forceinline__ s16x4_t lds_tr16(unsigned addr) {      // addr: LDS byte address; OFF: immediate offset
+#ifdef MDCV_WST_NOREADS                                      // timing ablation (scripts/wgrad_ab.py, MDCV_LIB): fragments without LDS reads
+  return s16x4_t{1, 1, 1, 1};
+#else
   s16x4_t v;
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
   return v;
+#endif
 }
 // wait until at most N of this wave's LDS reads are outstanding (they return in order); the MFMAs that use `f...` depend on it
 template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory"); }
@@ -363,10 +367,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
     // DMA issued behind the barrier refills the dY stage -- and, when the ring has less than one step of slack, activation rows -- those
     // reads come from.  ds_reads are served in issue order against other waves' ds_writes, not against an LDS-DMA write: the reads must have
     // RETURNED before any wave passes the barrier (same hazard as in conv_shift.hip; scripts/check_ring_barriers.py checks the built code).
+#ifndef MDCV_WST_NOBARRIER                                   // (timing ablation: the step loop without its waits and barrier)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (its own statement: on every path to the barrier, whichever vmcnt wait is taken)
     if (issued - 1 - t >= D - 1 && D > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#endif
     const bool more = issued < nt;
     step(t, rho0, more, issued, rho_new);
     if (more) {
