@@ -5,6 +5,8 @@
 #include <stdint.h>
 
 #include "tune.h"
+#include <atomic>
+#include <mutex>
 
 typedef unsigned short bf16_t;   // raw bf16 bits; all arithmetic is done in fp32
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -82,6 +84,26 @@ template <> struct ET<bf16_t> {
     return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
   }
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a function ON a device.  One cache per call site (a `static DynLds` next to the launch):
+// per device the largest size already granted; the slow path (first launch of a kernel on a device, or a larger size) is serialised, so two threads
+// cannot leave the attribute below what either of them asked for.  (Until round 5 the call sites kept one `static bool` per process: a second GPU in
+// the same process never got the attribute and its launches above 64 KiB of LDS failed -- ADVICE r4.)
+struct DynLds { std::atomic<int> granted[64]; };
+inline hipError_t mdcv_dyn_lds(DynLds& c, const void* fn, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::atomic<int>& g = c.granted[dev & 63];
+  if (g.load(std::memory_order_acquire) >= bytes) return hipSuccess;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (g.load(std::memory_order_relaxed) >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) g.store(bytes, std::memory_order_release);
+  return e;
+}
+
 
 // BatchNorm(+activation)-backward apply of ONE element: dy = cA * g + cB * y + cC with g = dz * act'(scale * y + shift).  Explicit fused
 // multiply-adds in a fixed order: the apply pass (elementwise.hip) and the kernels that form dy in their operand load (conv_igemm.hip BNA)

@@ -307,13 +307,9 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
   constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;
   static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-  static bool attr_set = false;
+  static DynLds dyn_lds;
   auto kern = conv_igemm_kernel<T, MODE, BM, BN, WM, WN, KT>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(kern), LDS); e != hipSuccess) return (int)e;
   a.tiles_n = cdiv(a.Nout, BN);
   a.tiles_total = cdiv(a.M, BM) * a.tiles_n;
   a.xcd_chunk = cdiv(a.tiles_total, 8);
@@ -824,13 +820,9 @@ int launch_conv_glds_f(const ConvArgs& a0, hipStream_t st, int B) {
   constexpr int PIPE = STAGES * (BM + BN) * 64 + ((STAGES > 2 && ((BM / 16) % NWV != 0 || (BN / 16) % NWV != 0)) ? 1024 : 0);   // + the DMA sink
   constexpr int STAGE = BM * (BN * (int)sizeof(T) + 16);
   constexpr int LDS = (PIPE > STAGE ? PIPE : STAGE) + WM * 2 * BN * 4;   // + statistics / fp32 fused-sum scratch (NW*BN floats <= WM*2*BN)
-  static bool attr_set = false;
+  static DynLds dyn_lds;
   auto kern = conv_glds_kernel<T, MODE, BM, BN, WM, WN, STAGES, UT, FUSE, EPI, ALLCLS>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(kern), LDS); e != hipSuccess) return (int)e;
   a.tiles_n = cdiv(a.Nout, BN);
   a.tiles_total = cdiv(a.M, BM) * a.tiles_n * ((ALLCLS && a.cls_split) ? 2 : 1);
   a.xcd_chunk = cdiv(a.tiles_total, 8);
@@ -1718,13 +1710,9 @@ template <int BP, int STAGES, bool SAME>
 static int launch_wgrad_dma_t(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
   constexpr int RING = STAGES * 2 * BP * 256, EPI = 128 * 132 * 4;
   constexpr int LDS = RING > EPI ? RING : EPI;
-  static bool attr = false;
+  static DynLds dyn_lds;
   auto kern = conv_wgrad_dma_kernel<BP, STAGES, SAME>;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(kern), LDS); e != hipSuccess) return (int)e;
   MDCV_LAUNCH(kern, dim3(grid), dim3(256), LDS, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -1732,13 +1720,9 @@ static int launch_wgrad_dma_t(const WgradArgs& a, unsigned grid, hipStream_t st,
 template <bool SAME, int STAGES, bool BNA = false>
 static int launch_wgrad_narrow_t(const WgradArgs& a, unsigned grid, hipStream_t st, unsigned dyb, unsigned xb) {
   constexpr int LDS = STAGES * (64 * 64 * (BNA ? 2 : 1) + 64 * 256);   // 20 (24) KiB per stage (the 32 x 132 fp32 epilogue staging fits inside)
-  static bool attr = false;
+  static DynLds dyn_lds;
   auto kern = conv_wgrad_dma_narrow_kernel<SAME, STAGES, BNA>;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(kern), LDS); e != hipSuccess) return (int)e;
   MDCV_LAUNCH(kern, dim3(grid), dim3(256), LDS, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -2189,14 +2173,9 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   a.xcd_chunk = cdiv(a.blocks_total, 8);
   hipStream_t st = (hipStream_t)stream;
   const int lds = 256 * (64 * 4 + 16);   // 69632 B: one transposed step; the fp32 epilogue staging (67584 B) reuses it
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e1 != hipSuccess) return (int)e1;
-    if (e2 != hipSuccess) return (int)e2;
-    attr_set = true;
-  }
+  static DynLds dyn_lds16, dyn_lds32;
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds16, reinterpret_cast<const void*>(conv_wgrad_kernel<bf16_t>), lds); e != hipSuccess) return (int)e;
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds32, reinterpret_cast<const void*>(conv_wgrad_kernel<float>), lds); e != hipSuccess) return (int)e;
   const unsigned grid = (unsigned)(a.xcd_chunk * 8);
   if (use_dma) {
     const int rc = launch_wgrad_dma(a, grid, st, (unsigned)dyb, (unsigned)xb);
@@ -2284,14 +2263,9 @@ int mdcv_pack_weights_batched(int dtype, const void* table, int nlayers, int max
   hipStream_t st = (hipStream_t)stream;
   const int lds = 16 * (64 * max_taps + 1) * 4;          // 16 x (64 ci x taps + 1) floats
   if (lds > 160 * 1024) return MDCV_EARG;
-  static int lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(pack_weights_batched_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(pack_weights_batched_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e1 != hipSuccess) return (int)e1;
-    if (e2 != hipSuccess) return (int)e2;
-    lds_set = lds;
-  }
+  static DynLds dyn_lds16, dyn_lds32;
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds16, reinterpret_cast<const void*>(pack_weights_batched_kernel<bf16_t>), lds); e != hipSuccess) return (int)e;
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds32, reinterpret_cast<const void*>(pack_weights_batched_kernel<float>), lds); e != hipSuccess) return (int)e;
   if (dtype == MDCV_BF16) MDCV_LAUNCH(pack_weights_batched_kernel<bf16_t>, dim3(kPackBlocks, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
   else if (dtype == MDCV_F32) MDCV_LAUNCH(pack_weights_batched_kernel<float>, dim3(kPackBlocks, (unsigned)nlayers), dim3(256), lds, st, (const PackDesc*)table);
   else return MDCV_EARG;

@@ -632,13 +632,9 @@ int launch_shift_f(ShiftArgs a, int p_base, int tiles_m, hipStream_t st, unsigne
   const int epi = MODE == 3 ? 512 * SROW + NW * 2 * BN * 4      // stride-2 data gradient: two column classes of the tile interleaved as output rows (+ fold scratch)
                             : BM * SROW + BM * 4 + WM * 2 * BN * 4;      // staging + position table + statistics (the fused sums fold inside dead staging rows)
   const int lds = pipe > epi ? pipe : epi;
-  static int attr_lds = 0;
+  static DynLds dyn_lds;
   auto kern = mdcv_conv3x3_shift_kernel<MODE, BM, NPA, BRING, FUSE, WN, EPI, BN_, LOOP>;
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_lds = lds;
-  }
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return (int)e;
   MDCV_LAUNCH(kern, dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, in_bytes, w_bytes);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;

@@ -266,12 +266,8 @@ int mdcv_wgrad_shift(const void* dy, int dy_ldc, const void* x, int x_ldc, float
   a.xcd_chunk = (a.blocks_total + 7) / 8;
   const int ring = NSTAGE * STAGE + 1024, stage_out = 128 * OROW * 4;      // ring + sink, or the fp32 epilogue staging
   const int lds = ring > stage_out ? ring : stage_out;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_shift_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static DynLds dyn_lds;
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(wgrad3x3_shift_kernel), lds); e != hipSuccess) return (int)e;
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
   MDCV_LAUNCH(wgrad3x3_shift_kernel, dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();

@@ -590,13 +590,9 @@ inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c, lon
 
 template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8>
 int launch_stream(const WgradStreamArgs& a, int lds, unsigned dyb, unsigned xb, hipStream_t st) {
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_lds = lds;
-  }
+  static DynLds dyn_lds;
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW>), lds); e != hipSuccess)
+    return (int)e;
   MDCV_LAUNCH((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
@@ -723,12 +719,8 @@ int mdcv_wgrad_stem(const void* dy, int dy_ldc, const void* x, int x_ldc, float*
   a.tiles = a.tiles_ci = 1;
   a.xcd_chunk = (splits + 7) / 8;
   const int lds = stem_lds(W);
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad7x7_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr_lds = lds;
-  }
+  static DynLds dyn_lds;
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(wgrad7x7_stream_kernel), lds); e != hipSuccess) return (int)e;
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
   MDCV_LAUNCH(wgrad7x7_stream_kernel, dim3((unsigned)(a.xcd_chunk * 8)), dim3(512), lds, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();

@@ -21,8 +21,15 @@ class _FlatOptimizer(torch.optim.Optimizer):
 
     def _flat(self, nstate):
         pflat, gflat = self.model.flat_parameters()
-        if self._state_bufs is None or self._state_bufs[0].numel() != pflat.numel() or self._state_bufs[0].device != pflat.device:
+        if self._state_bufs is None:
             self._state_bufs = [torch.zeros_like(pflat) for _ in range(nstate)]
+        elif self._state_bufs[0].numel() != pflat.numel() or len(self._state_bufs) != nstate:
+            # moments of another flat layout (a checkpoint written before parameters were padded to 16-byte boundaries, another model): zeroing them
+            # while keeping `step` would resume with wrong bias correction and no sign of it
+            raise ValueError(f"optimizer state holds {len(self._state_bufs)} buffer(s) of {self._state_bufs[0].numel()} elements, the model's flat "
+                             f"parameter buffer has {pflat.numel()} ({nstate} expected): the state belongs to another parameter layout")
+        elif self._state_bufs[0].device != pflat.device:
+            self._state_bufs = [b.to(pflat.device) for b in self._state_bufs]
         # gradients normally ARE views of gflat (written in place by the backward plan); fold in anything that is not
         for p in self.model._plist:
             v = self.model._grad_view(p)
@@ -37,9 +44,14 @@ class _FlatOptimizer(torch.optim.Optimizer):
             {k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        self._step = sd["step"]
         if sd["state"]:
+            n = self.model.flat_parameters()[0].numel()
+            bad = [int(b.numel()) for b in sd["state"] if b.numel() != n]
+            if bad:
+                raise ValueError(f"optimizer checkpoint holds flat state of {bad[0]} elements, this model's flat parameter buffer has {n}: it was "
+                                 "written for another parameter layout (e.g. before parameters were padded to 16-byte boundaries)")
             self._state_bufs = [b.clone() for b in sd["state"]]
+        self._step = sd["step"]
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
 

@@ -220,6 +220,40 @@ def test_mini_darknet_optimizer_step(opt_name):
                 assert np.quantile(d, 0.99) < (2e-4 if opt_name == "adam" else 1e-5), (k, fused, float(d.max()))
 
 
+def test_fused_adam_checkpoint_resumes_bit_identically_and_rejects_another_layout():
+    """train.py saves / resumes the optimizer with state_dict() (CVC-YOLOv3/train.py:180-187): two steps == one step + checkpoint + one step in
+    a fresh optimizer, to the bit; flat moments of another parameter layout raise instead of being replaced by zeros under the kept step count."""
+    from mdcv.optim import FusedAdam
+    z = load("mini_darknet.npz")
+    x, tg = T(z["x"]).cuda(), T(z["targets"]).cuda()
+
+    def one(net, opt):
+        opt.zero_grad()
+        net(x, tg)[0].sum().backward()
+        opt.step()
+    a = make_mini("fp32"); a.train()
+    oa = FusedAdam(a, lr=1e-3)
+    one(a, oa); one(a, oa)
+    b = make_mini("fp32"); b.train()
+    ob = FusedAdam(b, lr=1e-3)
+    one(b, ob)
+    ck = ob.state_dict()
+    ob2 = FusedAdam(b, lr=5.0)
+    ob2.load_state_dict(ck)
+    assert ob2.param_groups[0]["lr"] == 1e-3
+    one(b, ob2)
+    torch.cuda.synchronize()
+    assert torch.equal(a.flat_parameters()[0], b.flat_parameters()[0])
+    bad = {"step": ck["step"], "state": [t[:-4].clone() for t in ck["state"]], "param_groups": ck["param_groups"]}
+    with pytest.raises(ValueError, match="another parameter layout"):
+        FusedAdam(b, lr=1e-3).load_state_dict(bad)
+    oc = FusedAdam(b, lr=1e-3)
+    oc._state_bufs = [t[:-4].clone() for t in ck["state"]]
+    oc._step = 1
+    with pytest.raises(ValueError, match="another parameter layout"):
+        one(b, oc)
+
+
 def test_mini_darknet_vs_oracle_other_batch():
     """Seeded inputs the golden set does not contain: HIP fp32 path vs the CPU oracle on the same weights."""
     from oracle import yolo_oracle as yo
