@@ -189,6 +189,10 @@ int mdcv_yolo_head_grad(int dtype, const void* logits, int ldc, void* dlogits, i
                         float wh_loss, float obj_loss, float noobj_loss, void* workspace, const float* gscale, void* stream);
 int mdcv_yolo_head_decode(int dtype, const void* logits, int ldc, const float* anchors_scaled, float stride, int B, int A, int C, int Gh,
                           int Gw, float* out, int rows_total, int row_off, void* stream);
+/* utils.bbox_iou (utils/utils.py:163-193, "+1 pixel" convention) for n = max(n1, n2) box pairs; a side with ONE row is broadcast.  Rows are `stride`
+ * floats apart, the first four are the box (corners = 1: x1 y1 x2 y2; 0: cx cy w h).  fp32; every operation rounds where the reference's torch op
+ * rounds, NaN propagates as torch.max / torch.min / clamp propagate it: bit-identical to the reference. */
+int mdcv_bbox_iou(const float* box1, long long n1, int stride1, const float* box2, long long n2, int stride2, int corners, float* out, void* stream);
 long long mdcv_build_targets_workspace_bytes(int B, int T, int A, int Gh, int Gw);
 int mdcv_build_targets(const float* targets, const float* anchors, int B, int T, int A, int C, int Gh, int Gw, float thresh,
                        unsigned char* mask, unsigned char* conf_mask, float* tx, float* ty, float* tw, float* th, float* tconf,

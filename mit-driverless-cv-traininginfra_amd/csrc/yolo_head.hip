@@ -294,10 +294,50 @@ __global__ void bt_tcls_kernel(const float* __restrict__ tg, HeadGeom g, const i
   }
 }
 
+// utils.bbox_iou (CVC-YOLOv3/utils/utils.py:163-193) as the reference writes it, one thread per pair: boxes as rows of `stride` floats (the
+// first four are read), either side broadcast when it has one row.  Every fp32 operation rounds where the reference's torch op rounds (this
+// file is compiled with -ffp-contract=off): bit-identical to the reference on the same inputs.
+__global__ __launch_bounds__(256) void bbox_iou_kernel(const float* __restrict__ b1, long long n1, int s1, const float* __restrict__ b2, long long n2,
+                                                       int s2, int corners, float* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* p = b1 + (n1 == 1 ? 0 : i) * s1;
+  const float* q = b2 + (n2 == 1 ? 0 : i) * s2;
+  float ax1, ay1, ax2, ay2, bx1, by1, bx2, by2;
+  if (corners) {
+    ax1 = p[0]; ay1 = p[1]; ax2 = p[2]; ay2 = p[3];
+    bx1 = q[0]; by1 = q[1]; bx2 = q[2]; by2 = q[3];
+  } else {                                                                       // :168-173 centre / size -> corners
+    ax1 = p[0] - p[2] / 2; ax2 = p[0] + p[2] / 2; ay1 = p[1] - p[3] / 2; ay2 = p[1] + p[3] / 2;
+    bx1 = q[0] - q[2] / 2; bx2 = q[0] + q[2] / 2; by1 = q[1] - q[3] / 2; by2 = q[1] + q[3] / 2;
+  }
+  // torch.max / torch.min propagate NaN; fmaxf / fminf would drop it
+  const float ix1 = (ax1 != ax1 || bx1 != bx1) ? __builtin_nanf("") : (ax1 > bx1 ? ax1 : bx1);
+  const float iy1 = (ay1 != ay1 || by1 != by1) ? __builtin_nanf("") : (ay1 > by1 ? ay1 : by1);
+  const float ix2 = (ax2 != ax2 || bx2 != bx2) ? __builtin_nanf("") : (ax2 < bx2 ? ax2 : bx2);
+  const float iy2 = (ay2 != ay2 || by2 != by2) ? __builtin_nanf("") : (ay2 < by2 ? ay2 : by2);
+  float w = ix2 - ix1 + 1.f, h = iy2 - iy1 + 1.f;                                // :184-186 clamp(min=0) keeps NaN
+  w = w < 0.f ? 0.f : w; h = h < 0.f ? 0.f : h;
+  const float inter = w * h;
+  const float a1 = (ax2 - ax1 + 1.f) * (ay2 - ay1 + 1.f);                        // :188-189
+  const float a2 = (bx2 - bx1 + 1.f) * (by2 - by1 + 1.f);
+  out[i] = inter / (a1 + a2 - inter + 1e-12f);                                   // :191
+}
 
 }  // namespace
 
 extern "C" {
+// IoU with the reference's "+1 pixel" convention (utils/utils.py:163-193): n = max(n1, n2) pairs, a side with ONE row is broadcast; rows are
+// `stride` floats apart and their first four floats are the box (corners = 1: x1 y1 x2 y2, 0: cx cy w h).  fp32, bit-identical to the reference.
+int mdcv_bbox_iou(const float* box1, long long n1, int stride1, const float* box2, long long n2, int stride2, int corners, float* out, void* stream) {
+  if (!box1 || !box2 || !out || n1 < 1 || n2 < 1 || stride1 < 4 || stride2 < 4 || (n1 != n2 && n1 != 1 && n2 != 1)) return MDCV_EARG;
+  const long long n = n1 > n2 ? n1 : n2;
+  if (n > (1LL << 31) * 256 - 256) return MDCV_EARG;
+  MDCV_LAUNCH(bbox_iou_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, box1, n1, stride1, box2, n2, stride2, corners, out, n);
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
 
 // workspace (ints): owner[B*A*Gh*Gw] | ignore[Gh*Gw] | err[1] (+pad) ; then acc[8] doubles (8-byte aligned by construction)
 long long mdcv_yolo_head_workspace_bytes(int B, int A, int Gh, int Gw) {

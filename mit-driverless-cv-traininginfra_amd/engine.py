@@ -554,7 +554,7 @@ class Plan:
         return done
 
     # ---- 1x1 conv blocks with the neighbouring BatchNorm pass folded into the operand load (csrc/pw_block.hip).  Policy from same-box
-    # timing of the fused launch against the pair it replaces (scripts/pw_block_ab.py alone, scripts/pw_diag.py inside a serial step;
+    # timing of the fused launch against the pair it replaces (scripts/pw_block_ab.py alone, per-kernel times of a serial step from bench.py --dump-launches;
     # YOLOv3 416^2 batch 32): the forward form wins where the layer's weights stay resident in LDS -- 52^2: 32.7 vs 43.3 us, 104^2: 61.5
     # vs 72.7 us -- and is level at 26^2 (25 vs 27 us alone, 29 vs 25 in the step); the backward form is level at 52^2 (48.7 vs 54.9 us
     # alone, 57 vs 54.5 in the step) and loses elsewhere (13^2, K = 1024: 16-pixel tiles re-stream 1 MiB of weights per tile).  These

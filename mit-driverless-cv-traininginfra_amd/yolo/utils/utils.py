@@ -1,6 +1,6 @@
 """GPU drop-ins for the helpers of the reference's CVC-YOLOv3/utils/utils.py that sit on the train / validate path:
 
-  bbox_iou          (utils.py:163-193)  — tiny elementwise helper, plain torch on whatever device the boxes live on
+  bbox_iou          (utils.py:163-193)  — HIP kernel (csrc/yolo_head.hip: mdcv_bbox_iou) for fp32 boxes on the GPU, bit-identical
   build_targets     (utils.py:195-275)  — HIP kernel (csrc/yolo_head.hip), bit-exact masks / indices
   xywh2xyxy         (utils.py:121-127)  — elementwise helper, plain torch on the boxes' device
   average_precision (utils.py:58-88) / compute_ap (utils.py:90-119) — HIP kernel (csrc/postprocess.hip)
@@ -13,7 +13,32 @@ from ... import _lib
 
 
 def bbox_iou(box1, box2, x1y1x2y2=True):
-    """IoU with the reference's "+1 pixel" convention on [...,4] boxes (corner format unless x1y1x2y2=False)."""
+    """IoU with the reference's "+1 pixel" convention on [..., 4+] boxes (corner format unless x1y1x2y2=False), leading dimensions broadcast
+    as the reference's tensor expression broadcasts them (utils/utils.py:163-193).  fp32 boxes on the GPU go through mdcv_bbox_iou
+    (csrc/yolo_head.hip: one thread per pair, every operation rounded as the reference's op chain rounds it -> bit-identical); boxes on the host,
+    other dtypes or boxes that carry autograd history take the same expression in torch ops."""
+    if (box1.is_cuda and box2.is_cuda and box1.dtype == torch.float32 and box2.dtype == torch.float32
+            and not (torch.is_grad_enabled() and (box1.requires_grad or box2.requires_grad))
+            and box1.shape[-1] >= 4 and box2.shape[-1] >= 4 and box1.dim() >= 1 and box2.dim() >= 1):
+        lead = torch.broadcast_shapes(box1.shape[:-1], box2.shape[:-1])
+        n = 1
+        for d in lead:
+            n *= int(d)
+        if n == 0:
+            return torch.empty(lead, dtype=torch.float32, device=box1.device)
+
+        def rows(b):                   # -> ([rows, >= 4] contiguous, row count 1 or n)
+            if b.shape[:-1].numel() == 1:
+                return b.detach().reshape(1, b.shape[-1]).contiguous(), 1
+            return b.detach().expand(*lead, b.shape[-1]).reshape(n, b.shape[-1]).contiguous(), n
+        r1, n1 = rows(box1)
+        r2, n2 = rows(box2)
+        out = torch.empty(n, dtype=torch.float32, device=box1.device)
+        L = _lib.lib()
+        with torch.cuda.device(box1.device):
+            L.check(L.bbox_iou(r1.data_ptr(), n1, r1.shape[1], r2.data_ptr(), n2, r2.shape[1], 1 if x1y1x2y2 else 0, out.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream), "bbox_iou")
+        return out.reshape(lead)
     if x1y1x2y2:
         ax1, ay1, ax2, ay2 = box1[..., 0], box1[..., 1], box1[..., 2], box1[..., 3]
         bx1, by1, bx2, by2 = box2[..., 0], box2[..., 1], box2[..., 2], box2[..., 3]

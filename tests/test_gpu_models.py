@@ -56,10 +56,33 @@ def test_build_targets_out_of_grid_raises():
 
 
 def test_bbox_iou():
+    """utils.bbox_iou on the GPU is the HIP kernel mdcv_bbox_iou (csrc/yolo_head.hip), BIT-identical to the reference's vectors (both box formats,
+    the reference's own broadcast forms: [1, 4] against [A, 4] as build_targets calls it, [N, T, 4] pairs as validate.py:116 calls it, rows wider
+    than four floats), NaN / inf boxes included; the torch-op expression (host tensors) gives the same."""
     from mdcv.yolo.utils.utils import bbox_iou
+    from mdcv import _lib
     z = load("bbox_iou.npz")
-    close(bbox_iou(T(z["c1"]).cuda(), T(z["c2"]).cuda(), True).cpu(), z["iou_corner"], rtol=1e-6)
-    close(bbox_iou(T(z["b1"]).cuda(), T(z["b2"]).cuda(), False).cpu(), z["iou_center"], rtol=1e-6)
+    assert hasattr(_lib.lib(), "bbox_iou")
+    for a, b, corners, want in ((z["c1"], z["c2"], True, z["iou_corner"]), (z["b1"], z["b2"], False, z["iou_center"])):
+        got = bbox_iou(T(a).cuda(), T(b).cuda(), corners)
+        assert got.is_cuda and got.dtype == torch.float32 and tuple(got.shape) == tuple(want.shape)
+        assert np.array_equal(got.cpu().numpy(), want.astype(np.float32)), float(np.abs(got.cpu().numpy() - want).max())
+        assert np.array_equal(bbox_iou(T(a), T(b), corners).numpy(), want.astype(np.float32))          # host path: the same expression in torch ops
+    g = torch.Generator().manual_seed(3)
+    box = torch.rand(1, 4, generator=g) * 40
+    box[:, 2:] += box[:, :2]
+    many = torch.rand(9, 7, generator=g) * 40                       # rows of 7 floats (detections): the first four are the box
+    many[:, 2:4] += many[:, :2]
+    many[3, 0] = float("nan"); many[5, 2] = float("inf")
+    from oracle import yolo_oracle as yo
+    ref = yo.corner_iou_plus1(box, many[:, :4])
+    got = bbox_iou(box.cuda(), many.cuda(), True).cpu()
+    assert np.array_equal(got.numpy(), ref.numpy(), equal_nan=True)
+    pr = torch.rand(5, 1, 4, generator=g).expand(-1, 6, -1) * 30    # validate.py:116: predictions expanded against every target
+    tb = torch.rand(6, 4, generator=g).unsqueeze(0).expand(5, -1, -1) * 30
+    ref = yo.center_iou_plus1(pr, tb)
+    got = bbox_iou(pr.cuda(), tb.cuda(), False)
+    assert tuple(got.shape) == (5, 6) and np.array_equal(got.cpu().numpy(), ref.numpy())
 
 
 # ------------------------------------------------------------------------------------------------ YOLOLayer
