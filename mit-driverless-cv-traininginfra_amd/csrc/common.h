@@ -105,6 +105,19 @@ inline hipError_t mdcv_dyn_lds(DynLds& c, const void* fn, int bytes) {
 }
 
 
+// Operands a pass reads for the LAST time before they are long dead (raw conv outputs y on the way forward; dz and y in the BatchNorm-backward apply;
+// the residual of a fused shortcut; weight-gradient slabs in their reduce) are loaded NON-TEMPORALLY: such a pass streams tensors of 11-350 MB through
+// the L2 / MALL that the co-running weight gradient and the next data gradient re-read their operand rows from.  Same box, whole YOLOv3 step, two
+// processes each (scripts/ab_step.py, MDCV_LIB builds): 13.16 / 13.20 -> 13.03 / 13.05 ms with the loads of the two apply passes, 13.04 / 13.07 with the
+// residual's too; RektNet 7.59 / 7.86 -> 7.45 / 7.67 ms.  The OUTPUTS stay ordinary stores -- their readers are the very next kernels (non-temporal stores
+// gave the gain back: 13.16 / 13.15); the LDS-DMA loads of the 1x1 backward's x / addsrc tiles with the nt policy and the producer loads of the fused
+// 1x1 forward block (pw_block.hip) measured level (12.80 vs 12.81; 12.85 / 12.84 / 12.83 vs 12.85 / 12.88 / 12.82) and keep the default policy.
+typedef unsigned mdcv_u32x4_nt_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 mdcv_ld_stream(const void* p) {
+  const mdcv_u32x4_nt_t v = __builtin_nontemporal_load(reinterpret_cast<const mdcv_u32x4_nt_t*>(p));
+  return uint4{v.x, v.y, v.z, v.w};
+}
+
 // BatchNorm(+activation)-backward apply of ONE element: dy = cA * g + cB * y + cC with g = dz * act'(scale * y + shift).  Explicit fused
 // multiply-adds in a fixed order: the apply pass (elementwise.hip) and the kernels that form dy in their operand load (conv_igemm.hip BNA)
 // must round identically -- left to -ffp-contract, two kernels contract the same expression differently and differ in the last fp32 bit.

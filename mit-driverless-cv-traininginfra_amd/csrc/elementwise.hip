@@ -12,6 +12,9 @@
 
 namespace {
 
+using ::mdcv_ld_stream;
+__device__ __forceinline__ uint4 ld_stream(const void* p) { return mdcv_ld_stream(p); }     // (common.h: non-temporal 16-byte load of a last-use operand)
+
 struct Strip {
   int CV, PPI, PB;   // vectors per pixel, pixels per block-iteration, pixels per block
 };
@@ -206,9 +209,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs a) {
     for (int u = 0; u < 4; ++u) {
       const long long p = pb + (long long)u * a.PPI;
       if (p < p1) {
-        q1[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
-        if (y2) q2[u] = *reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC);
-        if (rs) qr[u] = *reinterpret_cast<const uint4*>(rs + p * a.ldr + cv * VEC);
+        q1[u] = ld_stream(y1 + p * a.ld1 + cv * VEC);
+        if (y2) q2[u] = ld_stream(y2 + p * a.ld2 + cv * VEC);
+        if (rs) qr[u] = ld_stream(rs + p * a.ldr + cv * VEC);
       }
     }
 #pragma unroll
@@ -303,8 +306,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (int u = 0; u < 4; ++u) {
     const long long p = pb + (long long)u * a.PPI;
     if (p < p1) {
-      q1[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
-      if (rsd) qr[u] = *reinterpret_cast<const uint4*>(rsd + p * a.ldr + cv * VEC);
+      q1[u] = ld_stream(y1 + p * a.ld1 + cv * VEC);
+      if (rsd) qr[u] = ld_stream(rsd + p * a.ldr + cv * VEC);
     }
   }
   // A non-finite partial sum poisoned the top digit of ITS replica (atomic max with INT64_MAX, exact_acc.h).  The poison is looked for per
@@ -380,8 +383,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int u = 0; u < 4; ++u) {
         const long long p = pb + (long long)u * a.PPI;
         if (p < p1) {
-          q1[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
-          if (rsd) qr[u] = *reinterpret_cast<const uint4*>(rsd + p * a.ldr + cv * VEC);
+          q1[u] = ld_stream(y1 + p * a.ld1 + cv * VEC);
+          if (rsd) qr[u] = ld_stream(rsd + p * a.ldr + cv * VEC);
         }
       }
     }
@@ -649,9 +652,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(BnBwdArgs a) {
     for (int u = 0; u < 4; ++u) {
       const long long p = pb + (long long)u * a.PPI;
       if (p < p1) {
-        qd[u] = *reinterpret_cast<const uint4*>(dout + p * a.ldd + cv * VEC);
-        qv[u] = *reinterpret_cast<const uint4*>(y1 + p * a.ld1 + cv * VEC);
-        if constexpr (DUAL) qw[u] = *reinterpret_cast<const uint4*>(y2 + p * a.ld2 + cv * VEC);
+        qd[u] = ld_stream(dout + p * a.ldd + cv * VEC);
+        qv[u] = ld_stream(y1 + p * a.ld1 + cv * VEC);
+        if constexpr (DUAL) qw[u] = ld_stream(y2 + p * a.ld2 + cv * VEC);
       }
     }
 #pragma unroll
