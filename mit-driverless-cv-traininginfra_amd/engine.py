@@ -259,6 +259,7 @@ class Plan:
                 plan.on_ready(lw)
             return 0
         ready.__name__ = "grad_ready"
+        ready.low_water = lw
         self.bwd.append((ready, ()))
 
     def wgrad_ws(self, stream=0):

@@ -120,6 +120,10 @@ class GradAllReducer:
             self._reduce(seg)
         self._pending_hi = lo
 
+    def would_fire(self, low_water):
+        """True if on_ready(low_water) would start at least one bucket (the plans enqueue their deferred side-stream work first)."""
+        return bool(self._overlap) and self._pending_hi - self.bucket_elems >= low_water
+
     def on_ready(self, low_water):
         if not self._overlap:
             return

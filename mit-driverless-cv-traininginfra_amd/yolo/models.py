@@ -320,10 +320,17 @@ class _NetPlan(Plan):
                 if prc:
                     raise _lib.MdcvError(f"{getattr(pfn, '__name__', pfn)} returned {prc}")
             del pending[:]
+        dp_red = getattr(self.on_ready, "__self__", None) if overlapped_dp else None
         for (fn, args), role in zip(self.bwd, roles):
-            if role == 3 and not overlapped_dp:                # slab reduce of a one-launch 1x1 backward: its producer is already in the main
+            if role == 3 and (not overlapped_dp or dp_red is not None):   # slab reduce of a one-launch 1x1 backward: its producer is already in the main
                 pending.append((fn, args))                     # queue, so ANY later fork orders it; no fork (and no 5 us of main queue) of its own
                 continue
+            if pending and dp_red is not None and getattr(fn, "__name__", "") == "grad_ready" and dp_red.would_fire(fn.low_water):
+                # data parallel: this marker starts the all-reduce of a bucket, which waits for the side stream -- the deferred slab reduces of the
+                # bucket's layers must be IN that stream first (about eight buckets per YOLOv3 step: eight forks instead of one per 1x1 layer)
+                L.check(fork(st, ss, self.fork_device_scope), "stream_fork")
+                flush()
+                used = True
             if role >= 2:                                      # a weight gradient: side stream, behind "dY(L), X(L) ready"
                 if armed:
                     L.check(L.stream_fork_wait(ss, ev), "stream_fork_wait")           # the kernel in front of it carried the event
@@ -532,7 +539,9 @@ class FlatParamsMixin:
         if pl[0].grad is not None:                       # gradients were not reset to None: accumulate semantics
             keep = self._gflat.clone()
         red = getattr(self, "_dp_reducer", None)
-        overlap = red is not None and keep is None and not plan.use_graph
+        # (an attached reducer with ONE rank has nothing to exchange: no markers, and the backward keeps its single-GPU schedule -- the markers switch
+        #  off the deferred slab reduces of run_bwd_list, 32 forks = 0.17 ms of main queue per YOLOv3 step, which bench.py at --gpus 1 paid until round 5)
+        overlap = red is not None and red._active() and keep is None and not plan.use_graph
         plan.on_ready = red.on_ready if overlap else None
         if red is not None:
             red.extra_streams = [plan.side()] if (plan.overlap_wgrad and not plan.use_graph and self._gflat.is_cuda) else []

@@ -41,7 +41,10 @@ def _worker(rank, world, port, which, q):
         import datetime
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
-        q.put((rank, (_yolo if which == "yolo" else _rektnet)(rank, world)))
+        if which.startswith("full"):
+            q.put((rank, _yolo_full(rank, world, which.endswith("1"))))
+        else:
+            q.put((rank, (_yolo if which == "yolo" else _rektnet)(rank, world)))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:                                  # surface failures instead of letting the parent wait for its timeout
@@ -93,6 +96,41 @@ def _rektnet(rank, world):
             "buckets": len(red.log), "flat": net.flat_parameters()[1].cpu().numpy()}
 
 
+def _yolo_full(rank, world, defer):
+    """the full yolo_baseline (bf16, 416^2, two images per rank): the one-launch 1x1 backward's slab reduces are DEFERRED on the side stream
+    (mdcv/yolo/models.py run_bwd_list) and, under data parallel, flushed in front of every marker that starts a bucket"""
+    import tempfile
+    sys.path.insert(0, ROOT)
+    import bench
+    from mdcv.yolo import models as ym
+    from mdcv.parallel import GradAllReducer
+    ym._NetPlan.defer_slab_reduce = bool(defer)
+    tmp = tempfile.mkdtemp(prefix=f"mdcv_dp{rank}_")
+    cfg = bench.write_yolo_cfg(tmp)
+    os.chdir(tmp)
+    torch.manual_seed(0)
+    net = ym.Darknet(cfg, 2.0, 1.6, 25.0, 0.1, True, precision="bf16").cuda().train()
+    red = GradAllReducer.attach(net, bucket_mb=32.0) if world > 1 else None
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(2 * 2, 3, 416, 416, generator=g)
+    tg = bench.synth_targets(2 * 2, 16, g)
+    if world > 1:
+        x, tg = x[2 * rank:2 * rank + 2], tg[2 * rank:2 * rank + 2]
+    outs = []
+    shards = [(x, tg)] if world > 1 else [(x[:2], tg[:2]), (x[2:], tg[2:])]
+    for xs, ts in shards:                                     # (world == 1: the two shards one after the other, for the sum the exchange must give)
+        net.zero_grad()
+        out = net(xs.cuda(), ts.cuda())
+        out[0].sum().backward()
+        if red is not None:
+            red.finish()
+        torch.cuda.synchronize()
+        outs.append(net.flat_parameters()[1].double().cpu().numpy().copy())
+    plan = [p for p in net._plans.values() if p.has_bwd][0]
+    roles = plan._classify_bwd()
+    return {"flat": outs, "deferred": int(sum(1 for r in roles if r == 3)), "buckets": len(red.log) if red is not None else 0}
+
+
 def _run(world, which, attempts=2):
     """Spawn `world` ranks and collect their results.  A rendezvous that never completes (seen once on a fresh box: both workers stuck before their
     first result, the whole `pytest -x` run lost to a 600 s wait) is killed after 240 s and the run is repeated ONCE on a new port; a second hang, or
@@ -138,6 +176,37 @@ def test_hip_mini_darknet_data_parallel_vs_reference(world):
         np.testing.assert_allclose(res[r]["gnorm"], z[f"gnorm_{world}"], rtol=2e-3, atol=1e-6)
         assert res[r]["buckets"] > 3                         # the exchange really ran bucket by bucket
         assert np.array_equal(res[r]["flat"], res[0]["flat"]), f"rank {r} holds a different reduced gradient than rank 0"
+
+
+def test_full_yolo_data_parallel_with_deferred_slab_reduces():
+    """Two ranks of the FULL yolo_baseline (bf16; the mini cfg above has no layer that takes the one-launch 1x1 backward): with the slab reduces of the
+    1x1 layers deferred behind the next weight gradient's fork -- and flushed in front of every marker that starts a bucket's all-reduce -- the
+    reduced gradient is bit-identical to the schedule with one fork per slab reduce, every rank holds the same buffer, and it is the SUM of the two
+    shards' gradients computed one after the other in a single process (fp64 sum of the fp32 buffers; the exchange adds in fp32)."""
+    a = _run(2, "full1")
+    b = _run(2, "full0")
+    assert a[0]["deferred"] >= 30 and b[0]["deferred"] == 0 and a[0]["buckets"] >= 4, (a[0]["deferred"], b[0]["deferred"], a[0]["buckets"])
+    assert np.array_equal(a[0]["flat"][0], a[1]["flat"][0]) and np.array_equal(a[0]["flat"][0], b[0]["flat"][0])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_full, args=(q,))
+    p.start()
+    single = q.get(timeout=600)
+    p.join(timeout=60)
+    assert "error" not in single, single.get("error")
+    want = single["flat"][0] + single["flat"][1]
+    got = a[0]["flat"][0]
+    scale = float(np.abs(want).max())
+    assert float(np.abs(got - want).max()) <= 1e-6 * scale, float(np.abs(got - want).max()) / scale
+
+
+def _single_full(q):
+    try:
+        torch.cuda.set_device(0)
+        q.put(_yolo_full(0, 1, True))
+    except Exception as e:
+        import traceback
+        q.put({"error": repr(e) + traceback.format_exc()})
 
 
 @pytest.mark.parametrize("world", [2, 4])
