@@ -56,6 +56,16 @@ int mdcv_conv2d_dgrad_bnsums(int dtype, const void* in, int in_ldc, const void* 
                              int add_ldc, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,
                              int pad, int dil, const void* y, int ldy, const float* scale, const float* shift, const float* mean, int act,
                              float slope, float* partial, void* stream);
+/* The network's FIRST conv -> BatchNorm(batch statistics) -> activation (CVC-YOLOv3/models.py:57-71 at index 0; 3 -> 32 channels, 3x3 / stride 1 / pad 1) as two
+ * streaming launches that never re-read the layer's 354 MB output: the conv is 25 GFLOP on an 88 MB input, so it is computed twice.  _stats: x -> partial rows
+ * [mdcv_first_conv_rows(B, H)][2][32] (sum, sum of squares of the fp32 accumulators; finish with mdcv_bn_stats_finalize).  _bn_act: x -> y (raw conv output, bf16, kept
+ * for the backward) AND z = act(scale * y + shift) from the y it stores, in one store loop.  _ok: 1 where the geometry takes this form (bf16, 8 padded input
+ * channels at stride 8, 32 output channels); elsewhere: mdcv_conv2d + mdcv_bn_act_fwd. */
+int mdcv_first_conv_ok(int dtype, int B, int H, int W, int Cin_pad, int Cout_pad, int KH, int KW, int stride, int pad, int dil, int ldx);
+int mdcv_first_conv_rows(int B, int H);
+int mdcv_first_conv_stats(int dtype, const void* x, int ldx, const void* w_packed, float* partial, int B, int H, int W, void* stream);
+int mdcv_first_conv_bn_act(int dtype, const void* x, int ldx, const void* w_packed, const float* scale, const float* shift, int act, float slope,
+                           void* y, int ldy, void* z, int ldz, int B, int H, int W, void* stream);
 /* 1 when the data gradient of this geometry runs as the stride-2 form of the 3x3 shift kernel (bf16, 3x3 / stride 2 / pad 1, Hout = 2 Hin, 32 or 64
  * output channels): its store loop writes whole output rows from LDS and carries the fused sums at every size (one partial row per 8 x 31 tile). */
 int mdcv_conv2d_dgrad_s2_form_ok(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Nout, int KH, int KW, int stride,

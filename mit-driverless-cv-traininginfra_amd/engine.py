@@ -641,6 +641,7 @@ class Plan:
     # that kernel's operand load (mdcv_conv2d_wgrad_bnapply, conv_igemm.hip BNA) and the apply pass over the network's largest tensor never runs.
     # YOLOv3 416^2 batch 32: apply 193 us on the main queue + weight gradient 131 us alone behind it, at the exposed tail of the backward.
     wgrad_bnapply = True               # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
+    first_conv_2pass = True            # the first conv's forward as two streaming passes over its INPUT (csrc/first_conv.hip; yolo/models.py)
 
     def emit_first_conv_bwd(self, dout, y, bs, act, slope, cs, xnode):
         """Backward of conv -> BatchNorm -> activation for a layer whose input needs no gradient: statistics as usual, then ONE weight-gradient

@@ -783,6 +783,26 @@ class Darknet(FlatParamsMixin, nn.Module):
                     y = plan.new_act(B, ho, wo, conv.out_channels)
                     fuse = (i + 1 < n and defs[i + 1]["type"] == "shortcut" and users[i] == [i + 1]
                             and res(i + 1, int(defs[i + 1]["from"])) != i)
+                    first2 = (bn_train and pw_lb is None and not fuse and plan.first_conv_2pass and cs.bias is None and plan.dtype == _lib.BF16 and
+                              bool(L.first_conv_ok(plan.cdt, B, cur.act.H, cur.act.W, cs.cin_pad, cs.cout_pad, cs.kh, cs.kw, cs.stride, cs.pad, cs.dil,
+                                                   cur.act.ldc)))
+                    if first2:
+                        # the HBM-bound first conv (25 GFLOP, 88 MB in, 354 MB out at 416^2 x 32): statistics from one streaming pass over x, then
+                        # y AND z = act(BatchNorm(y)) from a second one -- the layer's output is never re-read (csrc/first_conv.hip)
+                        rows = int(L.first_conv_rows(B, ho))
+                        partial = plan.f32(rows * 2 * y.C, zero=False)
+                        plan.call(plan.fwd, L.first_conv_stats, plan.cdt, cur.act.ptr, cur.act.ldc, cs.wf.data_ptr(), partial.data_ptr(), B, cur.act.H, cur.act.W)
+                        plan.emit_bn_stats(bs, y, partial, rows)
+                        nbt.append(bn.num_batches_tracked)
+                        z = TNode(out_act(i), name="conv%d" % i)
+                        plan.call(plan.fwd, L.first_conv_bn_act, plan.cdt, cur.act.ptr, cur.act.ldc, cs.wf.data_ptr(), bs.scale.data_ptr(), bs.shift.data_ptr(),
+                                  act_code, slope, y.ptr, y.ldc, z.act.ptr, z.act.ldc, B, cur.act.H, cur.act.W)
+                        plan.last_bnact = None
+                        plan.first_conv_fwd2 = True
+                        recs.append(("convbn", cs, bs, cur, y, z, None))
+                        outs[i] = z
+                        cur = z
+                        continue
                     if bn_train and pw_lb is not None:
                         rows = int(L.pw_rows(cur.act.M, cs.cin_pad))
                         partial = plan.f32(rows * 2 * y.C, zero=False)

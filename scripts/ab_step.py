@@ -35,6 +35,7 @@ def apply_build(codes):
     engine.Plan.tune_conv = engine.Plan.tune_wgrad = 0
     engine.Plan.wgrad_after_dgrad = False
     engine.Plan.wgrad_bnapply = True
+    engine.Plan.first_conv_2pass = True
     from mdcv.yolo import models as _ym0
     _ym0._NetPlan.fork_on_dispatch = True
     _ym0._NetPlan.defer_slab_reduce = True
@@ -47,6 +48,8 @@ def apply_build(codes):
             engine.Plan.tune_conv = int(c[1:])
         if c and c[0] == "w":
             engine.Plan.tune_wgrad = int(c[1:])
+        if c and c[0] == "I":          # I0 / I1: the first conv's forward as conv + apply pass / as two streaming passes over its input (csrc/first_conv.hip)
+            engine.Plan.first_conv_2pass = bool(int(c[1:]))
         if c and c[0] == "G":          # G0 / G1: the first layer's BatchNorm-apply pass as a launch / inside its weight gradient's operand load
             engine.Plan.wgrad_bnapply = bool(int(c[1:]))
         if c and c[0] == "W":          # W0 / W1: a 3x3 layer's weight gradient forked in front of / behind its data gradient

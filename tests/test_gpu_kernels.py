@@ -498,6 +498,79 @@ def test_maxpool2x2(dt, stride, H, W):
     np.testing.assert_allclose(to_nchw(din, dt, C).numpy(), xr.grad.numpy(), rtol=1e-6 if dt == F32 else 1e-2, atol=1e-6 if dt == F32 else 2e-2)
 
 
+FIRST_CONV_CASES = [(2, 3, 416, 416, 1), (3, 3, 37, 53, 1), (1, 3, 5, 16, 0), (2, 1, 30, 95, 2), (1, 3, 64, 640, 1)]   # B, Cin, H, W, activation
+
+
+@pytest.mark.parametrize("case", FIRST_CONV_CASES, ids=[str(c) for c in FIRST_CONV_CASES])
+def test_first_conv_two_streaming_passes(case):
+    """mdcv_first_conv_stats + mdcv_bn_stats_finalize + mdcv_first_conv_bn_act (the first conv -> BatchNorm -> activation without re-reading the layer's output)
+    against F.conv2d on the bf16-rounded operands (y within one bf16 step of the float64 result, z likewise through the same scale / shift), against the
+    generic path mdcv_conv2d(+statistics) + finalize + mdcv_bn_act_fwd (same statistics to fp32 summation order, same y / z up to bf16 roundings of
+    accumulators that differ in the last fp32 bits), ragged widths / heights (not multiples of 16 / 4), every activation."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, H, W, act = case
+    Co = 32
+    g = torch.Generator().manual_seed(B * 7 + H + W)
+    x = torch.rand(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    xb = to_nhwc(x, dt)                                              # [B, H, W, 8]
+    wf, _ = pack(dt, w, need_d=False)
+    assert L.first_conv_ok(dt, B, H, W, 8, Co, 3, 3, 1, 1, 1, 8) == 1
+    assert L.first_conv_ok(dt, B, H, W, 16, Co, 3, 3, 1, 1, 1, 16) == 0 and L.first_conv_ok(F32, B, H, W, 8, Co, 3, 3, 1, 1, 1, 8) == 0
+    M = B * H * W
+    gamma = (torch.rand(Co, generator=g) + 0.5).cuda(); beta = (torch.randn(Co, generator=g) * 0.3).cuda()
+    slope = 0.1
+
+    def finalize(partial, rows):
+        acc = torch.zeros(2 * Co, dtype=torch.float64, device="cuda")
+        rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        out = [torch.zeros(Co, device="cuda") for _ in range(4)]     # scale, shift, mean, invstd
+        L.check(L.bn_stats_finalize(partial.data_ptr(), rows, acc.data_ptr(), float(M), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                    0.1, 1e-5, *[o.data_ptr() for o in out], Co, st()))
+        return out
+    # the two-pass form
+    rows = L.first_conv_rows(B, H)
+    part = torch.full((rows, 2, Co), float("nan"), device="cuda")
+    L.check(L.first_conv_stats(dt, xb.data_ptr(), 8, wf.data_ptr(), part.data_ptr(), B, H, W, st()), "first_conv_stats")
+    sc1, sh1, mean1, is1 = finalize(part, rows)
+    ldz = 40                                                         # z inside a wider buffer (a concat slice)
+    y1 = torch.zeros(B, H, W, Co, dtype=TD[dt], device="cuda")
+    z1 = torch.zeros(B, H, W, ldz, dtype=TD[dt], device="cuda")
+    L.check(L.first_conv_bn_act(dt, xb.data_ptr(), 8, wf.data_ptr(), sc1.data_ptr(), sh1.data_ptr(), act, slope, y1.data_ptr(), Co, z1.data_ptr(), ldz,
+                                B, H, W, st()), "first_conv_bn_act")
+    # the generic path
+    rows0 = L.conv2d_stats_rows_geom(dt, B, H, W, 8, Co, 3, 3, 1, 1, 1, 8)
+    part0 = torch.zeros(rows0, 2, Co, device="cuda")
+    y0 = torch.zeros(B, H, W, Co, dtype=TD[dt], device="cuda")
+    L.check(L.conv2d(dt, 0, xb.data_ptr(), 8, wf.data_ptr(), y0.data_ptr(), Co, None, None, 0, part0.data_ptr(), B, H, W, 8, H, W, Co, 3, 3, 1, 1, 1, st()))
+    sc0, sh0, mean0, is0 = finalize(part0, rows0)
+    z0 = torch.zeros(B, H, W, Co, dtype=TD[dt], device="cuda")
+    L.check(L.bn_act_fwd(dt, y0.data_ptr(), Co, sc0.data_ptr(), sh0.data_ptr(), None, 0, None, None, None, 0, z0.data_ptr(), Co, M, Co, act, slope, st()))
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(part).any())
+    # float64 reference on the rounded operands
+    ref = F.conv2d(rnd(dt, x).double(), rnd(dt, w).double(), None, 1, 1).permute(0, 2, 3, 1)          # [B, H, W, Co]
+    yf1 = y1.double().cpu()
+    tol = 2 ** -8 * np.maximum(np.abs(ref.numpy()), 2 ** -6)                                            # one bf16 rounding step of the result
+    assert bool((np.abs(yf1.numpy() - ref.numpy()) <= tol).all()), float(np.abs(yf1.numpy() - ref.numpy()).max())
+    mean_ref, var_ref = ref.reshape(-1, Co).mean(0), ref.reshape(-1, Co).var(0, unbiased=False)
+    np.testing.assert_allclose(mean1.cpu().numpy(), mean_ref.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(is1.cpu().numpy(), (1.0 / np.sqrt(var_ref.numpy() + 1e-5)), rtol=1e-4)
+    for a_, b_, name in ((sc1, sc0, "scale"), (sh1, sh0, "shift"), (mean1, mean0, "mean"), (is1, is0, "invstd")):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=name)
+    # y / z against the generic path: the accumulators differ in their last fp32 bits (K order), so a bf16 rounding may flip on a few elements
+    dy = (y1.float() - y0.float()).abs()
+    assert float(dy.max()) <= 2 ** -7 * max(1e-6, float(y0.float().abs().max())) and float((dy > 0).float().mean()) < 2e-2
+    zz = z1[..., :Co].float()
+    assert float(z1[..., Co:].float().abs().max()) == 0.0                                             # nothing written beside the 32 channels
+    pre = y1.float() * sc1 + sh1
+    zr = pre if act == 0 else torch.where(pre > 0, pre, pre * (slope if act == 1 else 0.0))
+    assert float((zz - zr).abs().max()) <= 2 ** -7 * max(1e-6, float(zr.abs().max()))                 # z is act(scale * y_as_stored + shift), rounded to bf16
+    dz = (zz - z0.float()).abs()
+    assert float(dz.max()) <= 2 ** -6 * max(1e-6, float(z0.float().abs().max())) and float((dz > 0).float().mean()) < 5e-2
+
+
 FUSE_CASES = [
     # B, Cin(conv input = channels of the BatchNorm), H, W, Cout, k, stride, pad
     (2, 64, 26, 20, 128, 3, 1, 1),      # shift kernel, 256-row tiles
