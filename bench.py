@@ -123,6 +123,14 @@ def call_work(name, args):
     one MAC per (dy pixel, tap, ci, co)).  BatchNorm / activation passes: every operand tensor once."""
     if name == "mdcv_conv2d":
         return conv_flops(args), 0.0
+    if name == "mdcv_conv2d_xstats":         # forward conv with the statistics added to exact accumulators: (dt, x, ldx, w, y, ldy, bias, xacc, reps, B, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, ...)
+        B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW = args[9:18]
+        return 2.0 * B * Hout * Wout * Nout * KH * KW * Cin, 0.0
+    if name in ("mdcv_pw_conv_fwd", "mdcv_pw_conv_fwd_xstats"):      # fused 1x1 forward block: (..., M, K, N)
+        return 2.0 * args[-3] * args[-2] * args[-1], 0.0
+    if name in ("mdcv_first_conv_stats", "mdcv_first_conv_bn_act"):  # the first conv's two streaming passes: 3x3, 8 -> 32 channels; (..., B, H, W)
+        px = float(args[-3]) * args[-2] * args[-1]
+        return 2.0 * px * 32 * 72, px * (16.0 if name.endswith("stats") else 16.0 + 128.0)
     if name == "mdcv_conv2d_affine_act":     # inference conv + BatchNorm(running stats) + activation: (dt, x, ldx, w, out, ldo, scale, shift, resid, ldr, act, slope, B, H, W, Cin, Ho, Wo, Cout, kh, kw, ...)
         B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW = args[12:21]
         return 2.0 * B * Hout * Wout * Nout * KH * KW * Cin, 0.0
@@ -190,6 +198,10 @@ def kernel_breakdown(model, plan, step_fn):
                     e["bytes"] += by * t / tmain
             if name == "mdcv_conv2d":
                 LAUNCH_DUMP.append((name, ms, [int(v) if isinstance(v, int) else 0 for v in args[11:23]] + [int(args[1])]))
+            elif name == "mdcv_conv2d_xstats":          # the forward convs of the training plans: same row format, mode 0
+                LAUNCH_DUMP.append(("mdcv_conv2d", ms, [int(v) if isinstance(v, int) else 0 for v in args[9:21]] + [0]))
+            elif name in ("mdcv_first_conv_stats", "mdcv_first_conv_bn_act"):   # (B, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, stride, pad, dil), mode 0
+                LAUNCH_DUMP.append(("mdcv_conv2d", ms, [int(args[-3]), int(args[-2]), int(args[-1]), 8, int(args[-2]), int(args[-1]), 32, 3, 3, 1, 1, 1, 0]))
             elif name == "mdcv_conv2d_dgrad_bnsums":      # data gradient with the producer's BatchNorm-backward sums in its store loop
                 LAUNCH_DUMP.append((name, ms, [int(v) for v in args[8:20]] + [1]))
             elif name == "conv2d_wgrad":
