@@ -36,6 +36,7 @@ def apply_build(codes):
     engine.Plan.wgrad_after_dgrad = False
     engine.Plan.wgrad_bnapply = True
     engine.Plan.first_conv_2pass = True
+    engine.Plan.pw_fwd_px = (50000, 1 << 30)
     from mdcv.yolo import models as _ym0
     _ym0._NetPlan.fork_on_dispatch = True
     _ym0._NetPlan.defer_slab_reduce = True
@@ -50,6 +51,8 @@ def apply_build(codes):
             engine.Plan.tune_wgrad = int(c[1:])
         if c and c[0] == "I":          # I0 / I1: the first conv's forward as conv + apply pass / as two streaming passes over its input (csrc/first_conv.hip)
             engine.Plan.first_conv_2pass = bool(int(c[1:]))
+        if c and c[0] == "M":          # M<n>: the fused 1x1 forward block (BatchNorm apply in the operand load) from n pixels per layer (default 50000: 52^2 and up)
+            engine.Plan.pw_fwd_px = (int(c[1:]), 1 << 30)
         if c and c[0] == "G":          # G0 / G1: the first layer's BatchNorm-apply pass as a launch / inside its weight gradient's operand load
             engine.Plan.wgrad_bnapply = bool(int(c[1:]))
         if c and c[0] == "W":          # W0 / W1: a 3x3 layer's weight gradient forked in front of / behind its data gradient
