@@ -10,6 +10,7 @@ struct WgradStreamArgs {
   int Wq, Sq, Mq;                       // W+dil, (H+dil)(W+dil), B*Sq: padded position stream with `dil` shared zero columns / rows
   int hpad, RS;                         // halo rows on each side (multiple of 32) and rows of the activation ring
   int pos_per_split, splits, xcd_chunk;
+  int tbl_steps;                        // steps covered by one window of the DMA-address table (TBL forms)
   int tiles, tiles_ci;                  // TILED instantiation: (Cout/128 or /64) x (Cin/64) channel tiles per split, blocks = splits * tiles
 };
 

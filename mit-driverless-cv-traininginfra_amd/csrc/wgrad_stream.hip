@@ -29,11 +29,6 @@
 namespace {
 
 constexpr unsigned OOB = 0x80000000u;
-#ifdef MDCV_WST_NOPIPE
-constexpr bool g_pipe_enabled = false;
-#else
-constexpr bool g_pipe_enabled = true;
-#endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -51,13 +46,22 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float inv, int& q, int
 // overlap.  The asm read is invisible to that pass; the kernel orders DMA and reads itself (counted vmcnt + barrier) and waits for
 // the reads with wait_frags() below, whose "+v" operands make every MFMA depend on the wait.
 template <int OFF> __device__ __forceinline__ s16x4_t lds_tr16(unsigned addr) {      // addr: LDS byte address; OFF: immediate offset
-#ifdef MDCV_WST_NOREADS                                      // timing ablation (scripts/wgrad_ab.py, MDCV_LIB): fragments without LDS reads
-  return s16x4_t{1, 1, 1, 1};
-#else
   s16x4_t v;
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
   return v;
-#endif
+}
+// plain 4-byte LDS read as inline asm (the DMA-address table of the TBL forms): same reason, and the caller waits with wait_tbl() below
+template <int OFF> __device__ __forceinline__ int lds_ld32(unsigned addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int NX, int NY> __device__ __forceinline__ void wait_tbl(int (&nx)[NX], int (&ny)[NY]) {     // all LDS reads of this wave have returned
+  static_assert(NX >= 1 && NX <= 2 && NY >= 1 && NY <= 2, "one or two DMA instructions per operand per wave per step");
+  if constexpr (NX == 1 && NY == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(ny[0]) :: "memory");
+  else if constexpr (NX == 1 && NY == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(ny[0]), "+v"(ny[1]) :: "memory");
+  else if constexpr (NX == 2 && NY == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(ny[0]) :: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(ny[0]), "+v"(ny[1]) :: "memory");
 }
 // wait until at most N of this wave's LDS reads are outstanding (they return in order); the MFMAs that use `f...` depend on it
 template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory"); }
@@ -80,7 +84,12 @@ template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[4], bf1
 // layers of YOLOv3 at 52x52 / 26x26 / 13x13.  Same ring, same fragments; the DMA columns and the slab rows / columns carry the tile offset.
 // 128 co x 64 ci x 9 taps per block fills 24 KiB per 64 positions = 393 FLOP per filled byte (generic 128 x 128 im2col tile: 64).
 // NW: waves per block (8, or 4 for the light form: 64 co x 64 ci per block, one wave per SIMD).
-template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8>
+// TBL: the DMA lanes take the pixel index of their stream position from a per-block TABLE in LDS (built once in the prologue: one entry per position of
+// the block's run, JUNK = B*H*W for padding / foreign rows, which the buffer's range check turns into zeros) instead of stepping (x, y, image) forward
+// and re-deriving the pixel row per DMA instruction.  Round 6: the light form's step was 72 MFMAs behind ~180 address / select instructions (ISA: eight
+// v_mad_u64_u32 among them), issued by the only wave of its SIMD; with the table a DMA instruction costs one ds_read_b32 (prefetched a step ahead), one
+// v_mad_u32_u24 and the m0 write.  Same lanes, same ring image: results are bit-identical to the stepping form.
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8, bool TBL = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3x3_stream_kernel(WgradStreamArgs a, unsigned dy_bytes, unsigned x_bytes) {
   constexpr int RBX = NCI * 32, RBY = NCO * 32;            // row bytes
   constexpr int LPRX = 2 * NCI, LPRY = 2 * NCO;            // 16-byte slots (= DMA lanes) per row
@@ -173,13 +182,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
     fast_divmod(rem, a.Wq, inv_wq, y, x);
   };
   const int nimg = a.Mq / a.Sq;
+  if constexpr (!TBL) {
 #pragma unroll
-  for (int j = 0; j < XI; ++j) seed(p_begin + a.hpad + (wave + NW * j) * RPIX + rrx, qx[j], qy[j], qi[j]);
+    for (int j = 0; j < XI; ++j) seed(p_begin + a.hpad + (wave + NW * j) * RPIX + rrx, qx[j], qy[j], qi[j]);
 #pragma unroll
-  for (int j = 0; j < DYI; ++j) {
-    const int p = p_begin + (wave + NW * j) * RPIY + rry;
-    seed(p, yx[j], yy[j], yi[j]);
-    yrem[j] = p_end - p;                                     // > 0 while the row belongs to this split
+    for (int j = 0; j < DYI; ++j) {
+      const int p = p_begin + (wave + NW * j) * RPIY + rry;
+      seed(p, yx[j], yy[j], yi[j]);
+      yrem[j] = p_end - p;                                   // > 0 while the row belongs to this split
+    }
   }
   auto advance = [&](int& x, int& y, int& img) {
     x += adv_r;
@@ -220,6 +231,63 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
       yrem[j] -= BP;
     }
   };
+
+  // ---- TBL forms: tbl[i] = pixel index of stream position p_lo + i (JUNK = B*H*W: byte offset == buffer size, so the range check zero-fills the row).
+  // ex / ey always hold the (complete) entries of the NEXT step to be issued; the entries of the one after are requested in front of a step's DMA issue
+  // and waited for behind it, before the step's first fragment read.
+  const unsigned tbl_base = ybase + (unsigned)((D + 1) * YSTAGE);
+  int ex[XI], ey[DYI];
+  unsigned tx_addr = 0, ty_addr = 0;
+  static_assert(!TBL || (XI <= 2 && DYI <= 2), "table reads are unrolled by hand");
+  int tbl_s0 = 0;                                             // first step of the table's current window (a.tbl_steps steps; long runs rebuild it)
+  auto fetch = [&](int t, int (&nx)[XI], int (&ny)[DYI]) {
+    const unsigned ax = tx_addr + (unsigned)((t - tbl_s0) * (BP * 4)), ay = ty_addr + (unsigned)((t - tbl_s0) * (BP * 4));
+    nx[0] = lds_ld32<0>(ax);
+    if constexpr (XI > 1) nx[1] = lds_ld32<NW * RPIX * 4>(ax);
+    ny[0] = lds_ld32<0>(ay);
+    if constexpr (DYI > 1) ny[1] = lds_ld32<NW * RPIY * 4>(ay);
+  };
+  auto issue_tbl = [&](int t, int rho_new) {                 // step t from ex / ey
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const int chunk = wave + NW * j;
+      const int rho = (rho_new + chunk * RPIX) & rmask;
+      const int vo = (int)(__umul24((unsigned)ex[j], lx2) + lane_x);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + rho * RBX), 16, vo, 0, 0, 0);
+      if (rho < MIR) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + (RS + rho) * RBX), 16, vo, 0, 0, 0);
+      }
+    }
+    unsigned char* sY = stages + (t % (D + 1)) * YSTAGE;
+#pragma unroll
+    for (int j = 0; j < DYI; ++j) {
+      const int chunk = wave + NW * j;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_void_t*)(sY + chunk * 1024), 16, (int)(__umul24((unsigned)ey[j], ldy2) + lane_y), 0, 0, 0);
+    }
+  };
+  // window of the table that starts at step s0: entry i <-> stream position p_lo + s0 * BP + i, i < tbl_steps * BP + 2 * hpad (the dY rows of a step
+  // sit hpad entries, its new activation rows 2 * hpad entries behind the step's first entry).  Called by all waves with no table read in flight.
+  auto build_tbl = [&](int s0) {
+    int* const tbl = reinterpret_cast<int*>(smem + tbl_base);
+    const int ntbl = a.tbl_steps * BP + 2 * a.hpad, junk = nimg * a.H * a.W, pw = p_lo + s0 * BP;
+    for (int i = tid; i < ntbl; i += NW * 64) {
+      const int p = pw + i;
+      bool ok = p >= 0 && p < a.Mq;
+      int img, rem, y, x;
+      fast_divmod(ok ? p : 0, a.Sq, inv_sq, img, rem);
+      fast_divmod(rem, a.Wq, inv_wq, y, x);
+      ok = ok && x < a.W && y < a.H;
+      tbl[i] = ok ? (img * a.H + y) * a.W + x : junk;
+    }
+    __syncthreads();
+    tbl_s0 = s0;
+  };
+  if constexpr (TBL) {
+    build_tbl(0);
+    tx_addr = tbl_base + 4u * (unsigned)(2 * a.hpad + wave * RPIX + rrx);
+    ty_addr = tbl_base + 4u * (unsigned)(a.hpad + wave * RPIY + rry);
+  }
 
   // fragment roles
   const int t16 = lane & 15, kq = lane >> 4;
@@ -286,11 +354,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
   for (int i = 0; i < A; ++i) fa[i] = bf16x8_t{};
 #pragma unroll
   for (int k = 0; k < 9; ++k) fb[k] = bf16x8_t{};
-#ifdef MDCV_WST_NOMFMA
-  constexpr bool kMfma = false;
-#else
-  constexpr bool kMfma = true;
-#endif
+  constexpr bool kMfma = true;                                 // (wgrad_stream_pipe.inc is generated with this switch)
   auto reads = [&](auto N) {                                   // sub-step N of the step whose addresses step_addrs() prepared
 #pragma unroll
     for (int i = 0; i < A; ++i) fa[i] = fragY(N, i);
@@ -310,13 +374,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
     MDCV_TAP(1) MDCV_TAP(2) MDCV_TAP(3) MDCV_TAP(4) MDCV_TAP(5) MDCV_TAP(6) MDCV_TAP(7) MDCV_TAP(8)
 #undef MDCV_TAP
   };
-#ifdef MDCV_WST_NOSKEW
-  const bool late = false;
-#else
   const bool late = NSUB == 1 && wave >= NW / 2;             // (two sub-steps per step: the skewed schedule spills)
-#endif
   // channel-tiled instantiation: the reads run a few fragments ahead of the multiplies (wgrad_stream_pipe.inc, scripts/gen_wgrad_pipeline.py)
-  constexpr bool kPipe = TILED && NSUB == 2 && PG == 1 && A == 4 && g_pipe_enabled;
+  constexpr bool kPipe = TILED && NSUB == 2 && PG == 1 && A == 4;
   bf16x8_t fa2[2][A];
   if constexpr (kPipe) {
 #pragma unroll
@@ -325,17 +385,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
       for (int i = 0; i < A; ++i) fa2[n][i] = bf16x8_t{};
   }
   auto step = [&](int t, int rho0, bool more, int t_new, int rho_new) {
-#ifdef MDCV_WST_NOCOMPUTE
-    if (more) issue(t_new, rho_new);
-    return;
-#endif
     // (the asm reads are invisible to the compiler's LDS-DMA hazard tracking, so the DMA may sit anywhere; it sits where no
     //  fragment is live, to keep the address arithmetic of the DMA out of the 256-register budget)
     if (late) mfmas();                                       // the previous slot's fragments (zeros the first time)
-#ifndef MDCV_WST_NODMA
-    if (more) issue(t_new, rho_new);
-#endif
-    step_addrs(t, rho0);
+    if constexpr (TBL) {
+      const bool next = more && t_new + 1 < nt;
+      int nx[XI], ny[DYI];
+      if (next && t_new + 1 - tbl_s0 == a.tbl_steps) build_tbl(t_new + 1);     // (block-uniform; every wave's table reads were waited for in its previous step)
+      if (next) fetch(t_new + 1, nx, ny);                    // entries of the step after the one issued now: they land under the DMA issue
+      if (more) issue_tbl(t_new, rho_new);
+      step_addrs(t, rho0);
+      if (next) {
+        wait_tbl(nx, ny);
+#pragma unroll
+        for (int j = 0; j < XI; ++j) ex[j] = nx[j];
+#pragma unroll
+        for (int j = 0; j < DYI; ++j) ey[j] = ny[j];
+      }
+    } else {
+      if (more) issue(t_new, rho_new);
+      step_addrs(t, rho0);
+    }
     if constexpr (kPipe) {
       using N0 = std::integral_constant<int, 0>;
       using N1 = std::integral_constant<int, 1>;
@@ -351,15 +421,33 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
   };
 
   // prologue: the 2*hpad rows below the first step's new rows, then D steps ahead
-  {
-    const int nch = 2 * a.hpad / RPIX;
-    for (int c = wave; c < nch; c += NW) issue_x(p_lo + c * RPIX, c * RPIX);
-  }
   int issued = 0;
   int rho_new = (2 * a.hpad) & rmask;                        // ring row of the next step's first new activation row
-  for (; issued < D && issued < nt; ++issued) {
-    issue(issued, rho_new);
-    rho_new = (rho_new + BP) & rmask;
+  if constexpr (TBL) {
+    const int nch = 2 * a.hpad / RPIX;
+    for (int c = wave; c < nch; c += NW) {
+      int e[1] = {lds_ld32<0>(tbl_base + 4u * (unsigned)(c * RPIX + rrx))}, e2[1] = {0};
+      wait_tbl(e, e2);
+      const int vo = (int)(__umul24((unsigned)e[0], lx2) + lane_x), rho = c * RPIX;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + rho * RBX), 16, vo, 0, 0, 0);
+      if (rho < MIR) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(ring + (RS + rho) * RBX), 16, vo, 0, 0, 0);
+      }
+    }
+    if (nt > 0) { fetch(0, ex, ey); wait_tbl(ex, ey); }
+    for (; issued < D && issued < nt; ++issued) {
+      issue_tbl(issued, rho_new);
+      rho_new = (rho_new + BP) & rmask;
+      if (issued + 1 < nt) { fetch(issued + 1, ex, ey); wait_tbl(ex, ey); }
+    }
+  } else {
+    const int nch = 2 * a.hpad / RPIX;
+    for (int c = wave; c < nch; c += NW) issue_x(p_lo + c * RPIX, c * RPIX);
+    for (; issued < D && issued < nt; ++issued) {
+      issue(issued, rho_new);
+      rho_new = (rho_new + BP) & rmask;
+    }
   }
   int rho0 = a.hpad;
   for (int t = 0; t < nt; ++t) {
@@ -367,12 +455,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
     // DMA issued behind the barrier refills the dY stage -- and, when the ring has less than one step of slack, activation rows -- those
     // reads come from.  ds_reads are served in issue order against other waves' ds_writes, not against an LDS-DMA write: the reads must have
     // RETURNED before any wave passes the barrier (same hazard as in conv_shift.hip; scripts/check_ring_barriers.py checks the built code).
-#ifndef MDCV_WST_NOBARRIER                                   // (timing ablation: the step loop without its waits and barrier)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (its own statement: on every path to the barrier, whichever vmcnt wait is taken)
     if (issued - 1 - t >= D - 1 && D > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-#endif
     const bool more = issued < nt;
     step(t, rho0, more, issued, rho_new);
     if (more) {
@@ -486,9 +572,7 @@ __global__ __launch_bounds__(512) void wgrad7x7_stream_kernel(WgradStreamArgs a,
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (two steps in flight measured the same: the step is read/VALU-bound)
     __builtin_amdgcn_s_barrier();
-#ifndef MDCV_STEM_NODMA
     if (t + 1 < nt) issue(t + 1, rho_new);
-#endif
     rho_new = (rho_new + BP) & rmask;
     // this wave's sub-step: positions p0 + 32*wave .. +31
     const unsigned ya = ybase + (unsigned)((t & 1) * YSTAGE + (wave * 32 + prow) * RB) + lcol;
@@ -511,9 +595,7 @@ __global__ __launch_bounds__(512) void wgrad7x7_stream_kernel(WgradStreamArgs a,
 #undef MDCV_RD
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fb[4]), "+v"(fb[5]), "+v"(fb[6]) :: "memory");
 #pragma unroll
-#ifndef MDCV_STEM_NOMFMA
       for (int kw = 0; kw < KT; ++kw) acc[kh * KT + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[kw], acc[kh * KT + kw], 0, 0, 0);
-#endif
     }
     rho0 = (rho0 + BP) & rmask;
   }
@@ -574,12 +656,16 @@ inline int stream_ring_rows(const StreamCfg& c, int W, int dil) {       // >= (D
   while (rs < need) rs *= 2;
   return rs;
 }
-inline int stream_lds(const StreamCfg& c, int W, int dil) {
+inline int stream_lds(const StreamCfg& c, int W, int dil, int tbl_bytes = 0) {
   const int rs = stream_ring_rows(c, W, dil);
-  const int ring = (c.d + 1) * c.bp * c.nco * 32 + (rs + c.bp / c.pg) * c.nci * 32;     // dY stages + ring + its mirror (one wave's sub-steps of a step)
+  const int ring = (c.d + 1) * c.bp * c.nco * 32 + (rs + c.bp / c.pg) * c.nci * 32 + tbl_bytes;     // dY stages + ring + its mirror (one wave's sub-steps of a step) + the DMA-address table
   const int stage_out = c.nco * 16 * (c.tgrp * c.nci * 16 + 4) * 4;
   return ring > stage_out ? ring : stage_out;
 }
+// TBL forms: one int per stream position of a block's run plus the halo on both sides
+// (runs longer than 4096 positions rebuild it window by window: tbl_steps steps of BP positions each)
+inline int stream_tbl_steps(int pos_per_split, int bp) { const int nt = pos_per_split / bp, cap = 4096 / bp; return nt < cap ? nt : cap; }
+inline int stream_tbl_bytes(int pos_per_split, int bp, int hpad) { return (stream_tbl_steps(pos_per_split, bp) * bp + 2 * hpad) * 4; }
 
 // configuration for a layer geometry: the prefetch depth shrinks until ring + stages fit the 160 KiB of a CU
 inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c, long long Mq = 0) {
@@ -588,14 +674,19 @@ inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c, lon
   return stream_lds(c, W, dil) <= 160 * 1024;
 }
 
-template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8>
-int launch_stream(const WgradStreamArgs& a, int lds, unsigned dyb, unsigned xb, hipStream_t st) {
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED, int NW, bool TBL>
+int launch_stream1(const WgradStreamArgs& a, int lds, unsigned dyb, unsigned xb, hipStream_t st) {
   static DynLds dyn_lds;
-  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW>), lds); e != hipSuccess)
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW, TBL>), lds); e != hipSuccess)
     return (int)e;
-  MDCV_LAUNCH((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, dyb, xb);
+  MDCV_LAUNCH((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW, TBL>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
+}
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8>
+int launch_stream(const WgradStreamArgs& a, int lds, bool tbl, unsigned dyb, unsigned xb, hipStream_t st) {
+  return tbl ? launch_stream1<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW, true>(a, lds, dyb, xb, st)
+             : launch_stream1<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW, false>(a, lds, dyb, xb, st);
 }
 
 }  // namespace
@@ -653,17 +744,21 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   a.tiles_ci = c.tiled ? Cin / 64 : 1;
   a.tiles = c.tiled ? (Cout / (16 * c.nco)) * a.tiles_ci : 1;
   a.xcd_chunk = (splits * a.tiles + 7) / 8;
-  const int lds = stream_lds(c, W, dil);
+  // the DMA-address table (TBL forms) where it fits beside the ring: 12-13 KiB for YOLOv3's layers (one window), at most 16 KiB + halo for longer runs
+  a.tbl_steps = stream_tbl_steps(a.pos_per_split, c.bp);
+  const int tblb = stream_tbl_bytes(a.pos_per_split, c.bp, a.hpad);
+  const bool tbl = TUNE().stream_table && stream_lds(c, W, dil, tblb) <= 160 * 1024;
+  const int lds = stream_lds(c, W, dil, tbl ? tblb : 0);
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
-  if (c.tiled && c.nw == 4) return c.d == 1 ? launch_stream<4, 4, 4, 1, 64, 1, 1, true, 4>(a, lds, dyb, xb, st) : launch_stream<4, 4, 4, 1, 64, 2, 1, true, 4>(a, lds, dyb, xb, st);
+  if (c.tiled && c.nw == 4) return c.d == 1 ? launch_stream<4, 4, 4, 1, 64, 1, 1, true, 4>(a, lds, tbl, dyb, xb, st) : launch_stream<4, 4, 4, 1, 64, 2, 1, true, 4>(a, lds, tbl, dyb, xb, st);
   if (c.tiled) {
-    if (c.d == 1) return launch_stream<4, 8, 4, 1, 64, 1, 1, true>(a, lds, dyb, xb, st);
-    return launch_stream<4, 8, 4, 1, 64, 2, 1, true>(a, lds, dyb, xb, st);
+    if (c.d == 1) return launch_stream<4, 8, 4, 1, 64, 1, 1, true>(a, lds, tbl, dyb, xb, st);
+    return launch_stream<4, 8, 4, 1, 64, 2, 1, true>(a, lds, tbl, dyb, xb, st);
   }
 #define STREAM_CASE(CI, CO, NCI, NCO, A, PG, BP, TGRP)                                            \
   if (Cin == CI && Cout == CO) {                                                                  \
-    if (c.d == 1) return launch_stream<NCI, NCO, A, PG, BP, 1, TGRP>(a, lds, dyb, xb, st);        \
-    return launch_stream<NCI, NCO, A, PG, BP, 2, TGRP>(a, lds, dyb, xb, st);                      \
+    if (c.d == 1) return launch_stream<NCI, NCO, A, PG, BP, 1, TGRP>(a, lds, tbl, dyb, xb, st);   \
+    return launch_stream<NCI, NCO, A, PG, BP, 2, TGRP>(a, lds, tbl, dyb, xb, st);                 \
   }
   STREAM_CASE(16, 16, 1, 1, 1, 8, 256, 9)
   STREAM_CASE(16, 32, 1, 2, 2, 8, 256, 9)

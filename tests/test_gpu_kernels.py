@@ -936,7 +936,7 @@ def test_wgrad_stream_kernel(case):
     xb, dyb = to_nhwc(x, dt), to_nhwc(dy, dt)
     ktot = 9 * Ci
     outs = {}
-    for variant in (0, 9):                      # 0: default dispatch (stream kernel) ; 9: generic kernel
+    for variant in (0, 34020, 9):               # 0: default dispatch (stream kernel, DMA addresses from the LDS table) ; 34020: its stepping-lane form ; 9: generic kernel
         L.conv2d_wgrad_set_variant(variant)
         try:
             splits = L.conv2d_wgrad_splits_geom(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, dil, dil, Co, Ci)
@@ -953,6 +953,7 @@ def test_wgrad_stream_kernel(case):
         assert np.isfinite(got).all(), v
         np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * scale, err_msg=f"variant {v} splits {splits}")
     np.testing.assert_allclose(outs[0][0], outs[9][0], rtol=1e-3, atol=1e-3 * scale)      # same bf16 products, fp32 sums in another order
+    assert outs[0][1] == outs[34020][1] and np.array_equal(outs[0][0], outs[34020][0])     # same lanes, same ring image: the table changes addresses' COST only
 
 
 @pytest.mark.parametrize("case", [(4, 128, 256, 13, 13, 1), (2, 64, 128, 26, 20, 1), (3, 256, 128, 9, 17, 2), (2, 128, 128, 52, 52, 1)], ids=str)
