@@ -126,8 +126,6 @@ def call_work(name, args):
     if name == "mdcv_conv2d_xstats":         # forward conv with the statistics added to exact accumulators: (dt, x, ldx, w, y, ldy, bias, xacc, reps, B, Hin, Win, Cin, Hout, Wout, Cout, kh, kw, ...)
         B, Hin, Win, Cin, Hout, Wout, Nout, KH, KW = args[9:18]
         return 2.0 * B * Hout * Wout * Nout * KH * KW * Cin, 0.0
-    if name in ("mdcv_pw_conv_fwd", "mdcv_pw_conv_fwd_xstats"):      # fused 1x1 forward block: (..., M, K, N)
-        return 2.0 * args[-3] * args[-2] * args[-1], 0.0
     if name in ("mdcv_first_conv_stats", "mdcv_first_conv_bn_act"):  # the first conv's two streaming passes: 3x3, 8 -> 32 channels; (..., B, H, W)
         px = float(args[-3]) * args[-2] * args[-1]
         return 2.0 * px * 32 * 72, px * (16.0 if name.endswith("stats") else 16.0 + 128.0)
@@ -138,7 +136,13 @@ def call_work(name, args):
         Bq, Hin, Win, Cin, Hout, Wout, Nout, KH, KW = args[8:17]
         return 2.0 * Bq * Hin * Win * Cin * KH * KW * Nout, 0.0
     if name == "mdcv_pw_bwd":                # 1x1 data gradient + weight-gradient slabs in one launch: (dt, dy, ldy, x, ldx, wd, dx, lddx, add, ldadd, ws, slabs, fy, ..., M, Cin, Cout)
-        return 2.0 * 2.0 * args[20] * args[21] * args[22], 0.0
+        M, Cin, Cout = args[20], args[21], args[22]
+        # algorithmic bytes: dy and x read, dx written, the residual gradient (addsrc) and the y of the fused BatchNorm sums read where present (bf16)
+        nby = 2.0 * M * (Cout + 2 * Cin + (Cin if args[8] is not None else 0) + (Cin if args[12] is not None else 0))
+        return 2.0 * 2.0 * M * Cin * Cout, nby
+    if name in ("mdcv_pw_conv_fwd", "mdcv_pw_conv_fwd_xstats"):      # fused 1x1 forward block: reads y (+ residual), writes z and the conv output
+        M, K, N = args[-3], args[-2], args[-1]
+        return 2.0 * M * K * N, 2.0 * M * (2 * K + N)
     if name == "conv2d_wgrad":               # info = (B, Hin, Win, Cin_pad, Hout, Wout, Cout_pad, k, stride, splits)
         B, Hin, Win, Cin, Hout, Wout, Cout, k = args[:8]
         return 2.0 * B * Hout * Wout * Cout * k * k * Cin, 0.0
@@ -268,7 +272,9 @@ def roofline_objects(krec, precision, traffic, in_step=None):
     for sym, e in krec.items():
         if e["launches"] == 0 or e["ms"] <= 0 or (e["flops"] == 0 and e["bytes"] == 0):
             continue
-        mf = e["flops"] > 0
+        # the roof a kernel is actually against: with both figures modelled, HBM when its algorithmic bytes at the achievable
+        # 6.3 TB/s take longer than its FLOPs at the dense peak (the one-launch 1x1 backward, the fused 1x1 forward block)
+        mf = e["flops"] > 0 and not (e["bytes"] > 0 and e["bytes"] / 6.3e12 > e["flops"] / (peak_f * 1e12))
         work, div = (e["flops"], 1e12) if mf else (e["bytes"], 1e9)
         peak = peak_f if mf else PEAK_HBM_GBS
         per_launch = work / e["launches"]
@@ -566,6 +572,97 @@ def write_detail(line, extra, detail):
         return None
 
 
+def reference_loop_yolo(model, device, xh, th, steps, warmup):
+    """img/s of the statements the reference's training loop executes per batch (CVC-YOLOv3/train.py:57-93), verbatim in what they ask of the
+    device: stock `torch.optim.Adam` over `model.parameters()` (train.py:180-187), the batch arriving in pinned host memory (DataLoader
+    pin_memory=True, train.py:131) and moved with `.to(device, non_blocking=True)` (:60-61), a blocking `.item()` on the label count (:63), one
+    `.sum().to('cpu').item()` per loss part (:75) and the eight `.item()` reads of the progress line (:85-89).  Reported beside the headline, never as it."""
+    optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-3, weight_decay=0.0)
+
+    def step():
+        imgs = xh.to(device, non_blocking=True)
+        targets = th.to(device, non_blocking=True)
+        targets.requires_grad_(False)
+        n_targets = ((targets[:, :, 1:5] > 0).sum(dim=2) > 1).sum().item() + 1e-12
+        optimizer.zero_grad()
+        losses = model(imgs, targets)
+        losses[0].sum().backward()
+        optimizer.step()
+        logged = [loss.sum().to("cpu").item() for loss in losses]
+        line = "%10.6f" % (losses[0].item() / n_targets)
+        total = losses[0].item()
+        for loss in losses[1:]:
+            line += "%5.2f" % (loss.item() / total * 100)
+        return logged, line
+    dt = timed_region(step, steps, warmup, device, 1)
+    return xh.shape[0] * steps / dt
+
+
+def reference_loop_rektnet(model, crit, device, xh, hmh, ph, steps, warmup):
+    """the RektNet twin (RektNet/train_eval.py:59-79): pageable host batch (its DataLoader sets no pin_memory, :256) moved with `.to(device)`,
+    stock Adam, three `.item()` reads per batch."""
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-1)
+
+    def step():
+        x_batch, y_hm_batch, y_points_batch = xh.to(device), hmh.to(device), ph.to(device)
+        optimizer.zero_grad()
+        output = model(x_batch)
+        loc_loss, geo_loss, loss = crit(output[0], output[1], y_hm_batch, y_points_batch)
+        loss.backward()
+        optimizer.step()
+        return loc_loss.item(), geo_loss.item(), loss.item()
+    dt = timed_region(step, steps, warmup, device, 1)
+    return xh.shape[0] * steps / dt
+
+
+def comm_preflight(backend, rank, world, device):
+    """The multi-GPU run's first act (scripts/dp_preflight.py has the long form): process-group init, a 4-byte all-reduce (the first collective
+    builds the rings), who is there, and ONE timed all-reduce(SUM) of the YOLOv3 flat gradient's size (248 MB as four buckets).  A failure prints
+    a one-line JSON DIAGNOSIS naming the step instead of leaving the driver with a return code; the numbers ride in `workloads.yolo.comm`."""
+    step = "init_process_group"
+    try:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        step = "first_allreduce"
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t)
+        torch.cuda.synchronize(device)
+        if int(t.item()) != world:
+            raise RuntimeError(f"4-byte all-reduce returned {t.item()}, expected {world}")
+        step = "roll_call"
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, torch.cuda.current_device(), os.environ.get("HIP_VISIBLE_DEVICES")))
+        step = "gradient_sized_allreduce"
+        n = 62 * (1 << 20)
+        buf = torch.full((n,), float(rank + 1), device=device)
+        per = n // 4
+        times = []
+        for _ in range(3):
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for b in range(4):
+                dist.all_reduce(buf[b * per:(b + 1) * per], op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize(device)
+            times.append(time.perf_counter() - t0)
+            buf.fill_(float(rank + 1))
+        ms = min(times[1:]) * 1e3
+        del buf
+        return {"ranks_seen": len({s0[0] for s0 in seen if s0 is not None}), "devices": sorted({s0[1] for s0 in seen if s0 is not None}),
+                "preflight_allreduce_248mb_ms": ms, "preflight_first_ms": times[0] * 1e3,
+                "preflight_busbw_gbs": 2 * (world - 1) / world * n * 4 / (ms * 1e-3) / 1e9}
+    except Exception as e:                                   # noqa: BLE001
+        import traceback
+        print(json.dumps({"error": "data-parallel preflight failed", "step": step, "rank": rank, "world": world, "backend": backend,
+                          "exception": repr(e), "trace": traceback.format_exc()[-1200:],
+                          "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                          "visible_devices": torch.cuda.device_count(), "hint": "python scripts/dp_preflight.py --gpus N --model gives the per-rank report"}),
+              flush=True)
+        raise SystemExit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -585,6 +682,8 @@ def main():
     ap.add_argument("--dump-launches", default="")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-fp32", action="store_true", help="skip the same-precision-as-the-reference (fp32 kernels) YOLOv3 rate")
+    ap.add_argument("--no-ref-loop", action="store_true", help="skip the legs that time the reference's unchanged training-loop statements")
+    ap.add_argument("--no-classes1", action="store_true", help="skip the classes=1 (cone-realistic, 18-channel heads) YOLOv3 rate")
     a = ap.parse_args()
     global CPU_THREADS
     if a.cpu_threads:
@@ -616,12 +715,10 @@ def main():
     dev_index = local % ndev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    preflight = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        preflight = comm_preflight(backend, rank, world, device)      # comm init + one timed gradient-sized all-reduce, BEFORE any model exists
     os.environ["MDCV_GRAPH"] = str(a.graph)
     from mdcv.yolo.models import Darknet
     from mdcv.rektnet.keypoint_net import KeypointNet
@@ -679,7 +776,11 @@ def main():
                 return out
             dth = timed_region(yolo_step_h2d, a.steps, a.warmup, device, world)
             pcie = B * world * a.steps / dth
-        extra["yolo"] = {"images_per_sec_with_h2d_copy": pcie, "images_per_sec": ips, "ms_per_step": 1e3 * dt / a.steps, "global_batch": B * world, "final_loss": loss,
+        unchanged = None
+        if world == 1 and not a.no_ref_loop:
+            # the loop the drop-in promises to leave unchanged, on the same model (its parameters are views of the flat buffers either way)
+            unchanged = reference_loop_yolo(net, device, x.cpu().pin_memory(), tg.cpu().pin_memory(), max(5, min(20, a.steps)), 3)
+        extra["yolo"] = {"images_per_sec_with_h2d_copy": pcie, "unchanged_loop_images_per_sec": unchanged, "images_per_sec": ips, "ms_per_step": 1e3 * dt / a.steps, "global_batch": B * world, "final_loss": loss,
                          "mfma_frac_step": ips * (YOLO_TRAIN_GFLOP_PER_IMG if a.yolo_classes == 80 else 195.87) / 1e3 / (PEAK_BF16_TFLOPS * world)}
         if world > 1:                 # replicas must hold identical parameters after the reduced-gradient updates
             chk = net.flat_parameters()[0].double().sum().reshape(1)
@@ -687,7 +788,7 @@ def main():
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             extra["yolo"]["replicas_in_sync"] = bool((hi - lo).abs().item() <= 1e-6 * max(1.0, abs(hi.item())))
-            extra["yolo"]["comm"] = dict(comm or {}, backend="rccl" if backend == "nccl" else backend, ranks=dist.get_world_size(),
+            extra["yolo"]["comm"] = dict(comm or {}, **(preflight or {}), backend="rccl" if backend == "nccl" else backend, ranks=dist.get_world_size(),
                                          gradient_bytes=int(net.flat_parameters()[1].numel() * 4), bucket_mb=32.0)
             # allreduce_busy_ms = time the comm stream spent inside all-reduce calls per step; exposed_comm_ms = how long after the last
             # compute kernel of backward the last bucket finished (rank 0, HIP events)
@@ -750,6 +851,27 @@ def main():
             opt = None
         del net, opt
         torch.cuda.empty_cache()
+        if world == 1 and a.yolo_classes == 80 and a.precision == "bf16" and not a.no_classes1:
+            # "also report classes=1" -- the cone-realistic variant (18-channel heads, models.py:51-54), same step, same batch
+            cfg1 = write_yolo_cfg(tempfile.mkdtemp(prefix="mdcv_bench_c1_"), classes=1)
+            cwd = os.getcwd()
+            os.chdir(os.path.dirname(cfg1))
+            try:
+                torch.manual_seed(0)
+                net1 = Darknet(cfg1, 2.0, 1.6, 25.0, 0.1, True, precision=a.precision).to(device).train()
+            finally:
+                os.chdir(cwd)
+            opt1 = FusedAdam(net1, lr=1e-3, pipeline=OPT_PIPELINE)
+
+            def yolo_step_c1():
+                opt1.zero_grad()
+                net1(x, tg)[0].sum().backward()
+                opt1.step()
+            n1 = max(5, min(20, a.steps))
+            dt1 = timed_region(yolo_step_c1, n1, 5, device, 1)
+            extra["yolo"]["classes1_images_per_sec"] = B * n1 / dt1
+            del net1, opt1
+            torch.cuda.empty_cache()
 
     if a.workload in ("both", "rektnet"):
         torch.manual_seed(0)
@@ -777,6 +899,10 @@ def main():
                             "final_loss": float(rekt_step()),
                             "mfma_frac_step": ips * REKT_TRAIN_GFLOP_PER_IMG / 1e3 / (PEAK_BF16_TFLOPS * world),
                             "hbm_frac_step": ips * REKT_TRAIN_MB_PER_IMG / 1e3 / (PEAK_HBM_GBS * world)}
+        if world == 1 and not a.no_ref_loop:
+            with contextlib.redirect_stdout(sys.stderr):
+                extra["rektnet"]["unchanged_loop_images_per_sec"] = reference_loop_rektnet(
+                    kp, crit, device, x.cpu(), torch.zeros(B, 7, 80, 80), tp.cpu(), max(5, min(20, a.steps)), 3)
         if not a.no_breakdown:
             plan = [p for p in kp._plans.values() if p.has_bwd][0]
             in_step = in_step_kernel_times(rekt_step)

@@ -209,6 +209,9 @@ int mdcv_build_targets(const float* targets, const float* anchors, int B, int T,
                        unsigned char* tcls, void* workspace, int* err_out, void* stream);
 
 /* ---- KeypointNet head (keypoint_net.py:46-56,68-70) and CrossRatioLoss (cross_ratio_loss.py:20-63) */
+/* the head's 1x1 conv (keypoint_net.py:40,68: `self.out`, Conv2d(128, 7, 1)) with fp32 logits out of bf16 features: x [M][ldx] bf16 NHWC (C % 32 == 0,
+ * C <= 1024), w = the fp32 weights [K][C] as the module holds them, bias [K] or NULL, out fp32 [M][8] (columns >= K are zeros), K <= 8 */
+int mdcv_head1x1_f32(const void* x_bf16, int ldx, const float* w, const float* bias, float* out, long long M, int C, int K, void* stream);
 int mdcv_softargmax_fwd(int dtype, const void* logits, int ldc, int B, int K, int H, int W, float* hm, float* pts, void* stream);
 int mdcv_softargmax_bwd(int dtype, const float* hm, const float* pts, const float* dpts, const float* dhm, float* sdot_ws, int B, int K,
                         int H, int W, void* dlogits, int ldd, void* stream);

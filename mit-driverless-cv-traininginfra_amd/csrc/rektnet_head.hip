@@ -51,6 +51,56 @@ __global__ __launch_bounds__(256) void softargmax_fwd_kernel(const T* __restrict
   }
 }
 
+// The head's 1x1 conv with an fp32 OUTPUT (round 6): logits[p][k] = bias[k] + sum_c x[p][c] * w[k][c], x = the last block's bf16 activations (NHWC),
+// w = the fp32 master weights [K][C] as they sit in the parameter buffer (no packing), out = fp32 [M][KP].  Why: the flat softmax over 6400
+// positions turns a logit's rounding step into a relative error of every heat-map weight -- with bf16 logits (8 mantissa bits at |logit| ~ 4..16:
+// steps of 0.03..0.06) the key points of the batch-256 test moved by up to 0.065 against the fp32 oracle where the reference's own arithmetic under
+// torch.autocast(bfloat16) shows 0.061; the features stay bf16, only the 8 numbers per pixel behind them are kept exact.  HBM-bound (256 B in,
+// 32 B out per pixel): four lanes share a pixel, each multiplies a quarter of the channels against the weights in LDS (broadcast reads), two
+// DPP-free butterfly steps add the quarters in a fixed order.
+template <int KP>
+__global__ __launch_bounds__(256) void head1x1_f32_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, long long M, int C, int K) {
+  extern __shared__ float sw[];                                // [KP][C], rows >= K are zeros
+  const int tid = threadIdx.x;
+  for (int i = tid; i < KP * C; i += 256) sw[i] = (i / C) < K ? w[i] : 0.f;
+  __syncthreads();
+  const long long p = (long long)blockIdx.x * 64 + (tid >> 2);
+  const int part = tid & 3, cq = C >> 2;                       // C % 32 == 0: whole 16-byte vectors per lane
+  float acc[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) acc[k] = 0.f;
+  if (p < M) {
+    const bf16_t* xp = x + p * ldx + part * cq;
+    const float* wp = sw + part * cq;
+    for (int c = 0; c < cq; c += 8) {
+      float f[8];
+      ET<bf16_t>::unpack(mdcv_ld_stream(xp + c), f);          // last reader of the features on the way forward
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wp + k * C + c), w1 = *reinterpret_cast<const float4*>(wp + k * C + c + 4);
+        float t = acc[k];
+        t = __builtin_fmaf(f[0], w0.x, t); t = __builtin_fmaf(f[1], w0.y, t); t = __builtin_fmaf(f[2], w0.z, t); t = __builtin_fmaf(f[3], w0.w, t);
+        t = __builtin_fmaf(f[4], w1.x, t); t = __builtin_fmaf(f[5], w1.y, t); t = __builtin_fmaf(f[6], w1.z, t); t = __builtin_fmaf(f[7], w1.w, t);
+        acc[k] = t;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    acc[k] += __shfl_xor(acc[k], 1, 64);
+    acc[k] += __shfl_xor(acc[k], 2, 64);
+  }
+  if (p < M && part == 0) {
+    float o[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) o[k] = k < K ? acc[k] + (bias ? bias[k] : 0.f) : 0.f;
+    float4* dst = reinterpret_cast<float4*>(out + p * KP);
+#pragma unroll
+    for (int k = 0; k < KP; k += 4) dst[k >> 2] = float4{o[k], o[k + 1], o[k + 2], o[k + 3]};
+  }
+}
+
 // s[b,k] = sum_j p_j * dhm_j   (softmax Jacobian term, only needed when the heat-map itself carries a gradient)
 __global__ __launch_bounds__(256) void softmax_dot_kernel(const float* __restrict__ hm, const float* __restrict__ dhm, int HW, float* __restrict__ s) {
   __shared__ float red[4];
@@ -211,6 +261,15 @@ int mdcv_softargmax_fwd(int dtype, const void* logits, int ldc, int B, int K, in
   if (dtype == MDCV_BF16) MDCV_LAUNCH(softargmax_fwd_kernel<bf16_t>, dim3((unsigned)(B * K)), dim3(256), lds, st, (const bf16_t*)logits, ldc, K, H, W, hm, pts);
   else if (dtype == MDCV_F32) MDCV_LAUNCH(softargmax_fwd_kernel<float>, dim3((unsigned)(B * K)), dim3(256), lds, st, (const float*)logits, ldc, K, H, W, hm, pts);
   else return MDCV_EARG;
+  MDCV_CHECK_LAUNCH();
+  return MDCV_OK;
+}
+
+int mdcv_head1x1_f32(const void* x_bf16, int ldx, const float* w, const float* bias, float* out, long long M, int C, int K, void* stream) {
+  if (!x_bf16 || !w || !out || M < 0 || K < 1 || K > 8 || C < 32 || (C & 31) || (ldx & 7) || ldx < C || C > 1024) return MDCV_EARG;
+  if (M == 0) return MDCV_OK;
+  MDCV_LAUNCH(head1x1_f32_kernel<8>, dim3((unsigned)((M + 63) / 64)), dim3(256), (unsigned)(8 * C * 4), (hipStream_t)stream, (const bf16_t*)x_bf16, ldx, w, bias,
+              out, M, C, K);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }

@@ -230,14 +230,69 @@ def auto_state():
     return _AUTO or None
 
 
+def auto_slice(batch, rank=None, world=None):
+    """(start, stop, weight) of rank r's share of a batch of `batch` samples: nn.DataParallel's scatter on dim 0 (torch.chunk: chunks of
+    ceil(batch / world) samples, the last one shorter, trailing replicas EMPTY when the batch is short -- the reference DataLoaders set no
+    drop_last, so this happens on the last batch of an epoch).  A rank whose chunk is empty still has to take part in the gradient exchange: it
+    gets sample 0 with weight 0.0 -- its forward runs, its outputs are multiplied by zero, its gradients are exact zeros -- which is what
+    DataParallel computes when it uses fewer replicas."""
+    st = auto_state()
+    if rank is None:
+        rank, world = st["rank"], st["world"]
+    per = -(-batch // world)
+    lo, hi = rank * per, min(batch, (rank + 1) * per)
+    if lo >= hi:
+        return 0, 1, 0.0
+    return lo, hi, 1.0
+
+
 def auto_shard(*tensors):
-    """Rank r's shard of every tensor whose batch (dim 0) divides by the world size; other tensors (and everything when the mode is off) pass
-    through.  -> (tuple of tensors, sharded?)"""
+    """Rank r's share (auto_slice) of every tensor along dim 0; everything passes through when the mode is off or the tensors disagree about
+    the batch size.  -> (tuple of tensors, weight): weight None = not sharded, 1.0 = a real shard, 0.0 = this rank's chunk was empty."""
     st = auto_state()
     if st is None:
-        return tensors, False
-    w, r = st["world"], st["rank"]
-    if not all(t is None or (t.dim() >= 1 and t.shape[0] >= w and t.shape[0] % w == 0) for t in tensors):
-        return tensors, False
-    return tuple(None if t is None else shard_batch(t, r, w) for t in tensors), True
+        return tensors, None
+    sizes = {t.shape[0] for t in tensors if t is not None and t.dim() >= 1}
+    if len(sizes) != 1 or any(t is not None and t.dim() < 1 for t in tensors):
+        return tensors, None
+    batch = sizes.pop()
+    if batch < 1:
+        return tensors, None
+    lo, hi, weight = auto_slice(batch)
+    global _WARNED_UNEVEN
+    if batch % st["world"] and not _WARNED_UNEVEN:
+        _WARNED_UNEVEN = True
+        import warnings
+        warnings.warn(f"mdcv: batch of {batch} over {st['world']} ranks: uneven shards (DataParallel's chunking; per-shard mean losses weigh the "
+                      "samples of a short shard more, as nn.DataParallel does)", RuntimeWarning, stacklevel=3)
+    return tuple(None if t is None else t[lo:hi] for t in tensors), weight
 
+
+_WARNED_UNEVEN = False
+
+
+def auto_attach(model, average=False):
+    """First training forward of `model` under the auto mode: the overlapped all-reduce is attached WHETHER OR NOT this batch divided evenly (a first
+    batch that did not used to leave N ranks training independently), and the replicas are made identical -- parameters and buffers broadcast from
+    rank 0 -- instead of trusting every process to have seeded alike (KeypointNet draws its initial weights at random)."""
+    if getattr(model, "_dp_reducer", None) is not None or auto_state() is None:
+        return
+    GradAllReducer.attach(model, average=average)
+    model._dp_auto = True                                     # backward() joins the comm stream itself: the script calls a stock optimizer.step()
+    with torch.no_grad():
+        dist.broadcast(model.flat_parameters()[0], 0)
+        for b in model.buffers():
+            if b.numel():
+                dist.broadcast(b, 0)
+
+
+def auto_is_writer():
+    """True where a checkpoint should be written: everywhere outside the auto mode, on rank 0 inside it."""
+    st = auto_state()
+    return st is None or st["rank"] == 0
+
+
+def auto_barrier():
+    st = auto_state()
+    if st is not None and dist.is_initialized():
+        dist.barrier()

@@ -82,12 +82,13 @@ class CrossRatioLoss(nn.Module):
         if target_points is not None and points.shape[0] != target_points.shape[0]:
             # torchrun on the unchanged train_eval.py (parallel.enable_auto_data_parallel): KeypointNet.forward kept rank r's shard of the batch; the
             # labels the script hands over (train_eval.py:72) are still the whole batch
-            from ..parallel import auto_state, shard_batch
-            st = auto_state()
-            if st is not None and target_points.shape[0] == st["world"] * points.shape[0]:
-                target_points = shard_batch(target_points, st["rank"], st["world"])
-                if target_hm is not None:
-                    target_hm = shard_batch(target_hm, st["rank"], st["world"])
+            from ..parallel import auto_state, auto_slice
+            if auto_state() is not None:
+                lo, hi, _ = auto_slice(target_points.shape[0])          # the same share KeypointNet.forward took (DataParallel's chunking)
+                if hi - lo == points.shape[0]:
+                    target_points = target_points[lo:hi]
+                    if target_hm is not None:
+                        target_hm = target_hm[lo:hi]
         if tuple(points.shape[1:]) != (7, 2) or tuple(target_points.shape) != tuple(points.shape):
             # the kernel's row stride is 14 floats and the geometric terms use key points 0..6 (cross_ratio_loss.py:36-57 hard-codes them too)
             raise ValueError(f"CrossRatioLoss (HIP) takes points / target_points of shape [B, 7, 2]; got {tuple(points.shape)} and "

@@ -58,6 +58,11 @@ class _KpPlan(_NetPlan):
 
 
 class KeypointNet(FlatParamsMixin, nn.Module):
+    # torchrun on the unchanged train_eval.py: CrossRatioLoss is a batch MEAN (cross_ratio_loss.py:21-29), so each rank's loss is the mean over its
+    # shard and the exchange AVERAGES the gradients -- the full-batch mean's gradient for the location term (the geometric term couples the samples
+    # of a shard only).  The reference has no multi-GPU path for this network; YOLOv3's SUM is DataParallel's `losses[0].sum()`.
+    _dp_average = True
+
     def __init__(self, num_kpt=7, image_size=(80, 80), onnx_mode=False, init_weight=True, precision=None):
         super().__init__()
         width = 16
@@ -115,7 +120,9 @@ class KeypointNet(FlatParamsMixin, nn.Module):
         if not self._flat_ok():
             self._flatten()
         if self.training and torch.is_grad_enabled() and not self.onnx_mode:
-            (x,) = self._auto_dp_shard(x)        # torchrun on the unchanged train_eval.py: rank r's shard (parallel.enable_auto_data_parallel)
+            (x,), dp_weight = self._auto_dp_shard(x)        # torchrun on the unchanged train_eval.py: rank r's shard (parallel.enable_auto_data_parallel)
+        else:
+            dp_weight = None
         B, _, H, W = x.shape
         if (H, W) != tuple(self.image_size):
             raise ValueError(f"KeypointNet was built for image_size={self.image_size}, got {(H, W)}")
@@ -135,6 +142,8 @@ class KeypointNet(FlatParamsMixin, nn.Module):
         else:
             plan.run_forward(x)
             hm, pts = plan.hm.clone(), plan.pts.clone()
+        if dp_weight == 0.0:                 # this rank's DataParallel chunk was empty: it joins the exchange with exact-zero gradients
+            hm, pts = hm * 0.0, pts * 0.0
         return hm, pts.view(-1, self.num_kpt, 2)
 
     def _build_plan(self, device, B, H, W, bn_train, logits_only, infer=False):
@@ -181,20 +190,30 @@ class KeypointNet(FlatParamsMixin, nn.Module):
         csh = ConvSpec(plan, self.out.weight, self.out.bias, 1, 0, 1, cin_pad=a.act.C)
         plan.emit_pack(csh, need_dgrad=True)
         lg = TNode(plan.new_act(B, H, W, K), name="logits")
-        plan.emit_conv_fwd(csh, a.act, lg.act)
+        # bf16 mode: the logits stay fp32 (csrc/rektnet_head.hip head1x1_f32_kernel has the reason); the bf16 buffer above only gives the backward its shape
+        f32_logits = plan.dtype == BF16 and a.act.C % 32 == 0 and a.act.C <= 1024 and K <= 8 and self.out.kernel_size == (1, 1)
+        if f32_logits:
+            plan.lg32 = torch.zeros(B * H * W, 8, dtype=torch.float32, device=device)
+            w_out, b_out = self.out.weight, self.out.bias
+            plan.call(plan.fwd, L.head1x1_f32, a.act.ptr, a.act.ldc, w_out.data_ptr(), b_out.data_ptr() if b_out is not None else None,
+                      plan.lg32.data_ptr(), B * H * W, a.act.C, K)
+            lg_dt, lg_ptr, lg_ldc = _lib.F32, plan.lg32.data_ptr(), 8
+        else:
+            plan.emit_conv_fwd(csh, a.act, lg.act)
+            lg_dt, lg_ptr, lg_ldc = dt, lg.act.ptr, lg.act.ldc
         if bn_train and nbt:
             plan.call(plan.fwd, _bump_counters, nbt)
         plan.finish_pack(0)
         if logits_only:
             plan.logits_nchw = torch.empty(B, K, H, W, dtype=torch.float32, device=device)
-            plan.call(plan.fwd, L.nhwc_to_nchw, dt, lg.act.ptr, lg.act.ldc, plan.logits_nchw.data_ptr(), B, K, H, W)
+            plan.call(plan.fwd, L.nhwc_to_nchw, lg_dt, lg_ptr, lg_ldc, plan.logits_nchw.data_ptr(), B, K, H, W)
             plan.has_bwd = False
             return plan
         plan.hm = torch.empty(B, K, H, W, dtype=torch.float32, device=device)
         plan.pts = torch.empty(B, K, 2, dtype=torch.float32, device=device)
         plan.dpts = torch.zeros(B, K, 2, dtype=torch.float32, device=device)
         plan.sdot = torch.zeros(B * K, dtype=torch.float32, device=device)
-        plan.call(plan.fwd, L.softargmax_fwd, dt, lg.act.ptr, lg.act.ldc, B, K, H, W, plan.hm.data_ptr(), plan.pts.data_ptr())
+        plan.call(plan.fwd, L.softargmax_fwd, lg_dt, lg_ptr, lg_ldc, B, K, H, W, plan.hm.data_ptr(), plan.pts.data_ptr())
         plan.has_bwd = not infer
         if infer:                          # inference plan: forward list only (the raw conv outputs a backward would need do not exist)
             return plan

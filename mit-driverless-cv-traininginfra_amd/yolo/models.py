@@ -306,9 +306,10 @@ class _NetPlan(Plan):
         st, ss = cur.cuda_stream, side.cuda_stream
         L = self.L
         fork, used = L.stream_fork, False                      # (one ring event, device-scope release; torch's wait_stream builds an Event per call)
-        roles = self.__dict__.get("_bwd_roles")
-        if roles is None or len(roles) != len(self.bwd):
-            roles = self._bwd_roles = self._classify_bwd()
+        rkey = (len(self.bwd), self.fork_on_dispatch, self.defer_slab_reduce)
+        if self.__dict__.get("_bwd_roles_key") != rkey:      # (A/B scripts flip the two switches after the first backward)
+            self._bwd_roles, self._bwd_roles_key = self._classify_bwd(), rkey
+        roles = self._bwd_roles
         ev = ctypes.c_void_p()
         armed = False
         pending = []                                           # deferred slab reduces (role 3): they ride behind the NEXT fork
@@ -347,6 +348,8 @@ class _NetPlan(Plan):
                     armed = True
                 rc = fn(*args, st)
             if rc:
+                if armed:                                      # the armed call failed before it launched: take the event back, or the next unrelated
+                    L.stream_fork_wait(ss, ev)                 # launch of this thread would carry it as its stop event (fork_wait clears a pending arm)
                 raise _lib.MdcvError(f"{getattr(fn, '__name__', fn)} returned {rc}")
         if pending:
             L.check(fork(st, ss, self.fork_device_scope), "stream_fork")
@@ -521,16 +524,18 @@ class FlatParamsMixin:
                 torch.cuda.current_stream().wait_event(ev)
                 plan._group_events[k] = None
 
+    _dp_average = False                                      # KeypointNet overrides: its loss is a batch MEAN (see rektnet/keypoint_net.py)
+
     def _auto_dp_shard(self, *tensors):
-        """Under torchrun with the drop-in modules (parallel.enable_auto_data_parallel): rank r's shard of a training batch -- nn.DataParallel's
-        scatter on dim 0, reference train.py:68 / :193-195 -- and, on first use, the overlapped gradient all-reduce attached to this model.
-        Off (the usual case): the tensors pass through."""
-        from ..parallel import auto_shard, GradAllReducer
-        out, sharded = auto_shard(*tensors)
-        if sharded and getattr(self, "_dp_reducer", None) is None:
-            GradAllReducer.attach(self)
-            self._dp_auto = True                             # backward() joins the comm stream itself: the script calls a stock optimizer.step()
-        return out
+        """Under torchrun with the drop-in modules (parallel.enable_auto_data_parallel): rank r's share of a training batch -- nn.DataParallel's
+        scatter on dim 0, reference train.py:68 / :193-195 -- and, on first use, the overlapped gradient all-reduce attached to this model and
+        the replicas synchronised from rank 0.  -> (tensors, weight): weight 0.0 marks a rank whose chunk was empty (its outputs are to be
+        multiplied by zero), None / 1.0 anything else.  Off (the usual case): the tensors pass through."""
+        from ..parallel import auto_shard, auto_attach
+        out, weight = auto_shard(*tensors)
+        if weight is not None:
+            auto_attach(self, average=self._dp_average)
+        return out, weight
 
     def _run_backward(self, plan, gout):
         self._last_train_plan = plan
@@ -628,7 +633,9 @@ class Darknet(FlatParamsMixin, nn.Module):
         if not self._flat_ok():
             self._flatten()
         if targets is not None and self.training and torch.is_grad_enabled():
-            x, targets = self._auto_dp_shard(x, targets)     # torchrun on the unchanged train.py: rank r's shard (parallel.enable_auto_data_parallel)
+            (x, targets), dp_weight = self._auto_dp_shard(x, targets)     # torchrun on the unchanged train.py: rank r's shard (parallel.enable_auto_data_parallel)
+        else:
+            dp_weight = None
         B, _, H, W = x.shape
         T = targets.shape[1] if targets is not None else 0
         key = (B, H, W, T, targets is not None, self.training, self.precision, x.device.index)
@@ -646,6 +653,8 @@ class Darknet(FlatParamsMixin, nn.Module):
         else:
             plan.run_forward(x, targets)
             out7 = plan.out7.clone()
+        if dp_weight == 0.0:
+            out7 = out7 * 0.0                # this rank's DataParallel chunk was empty: it joins the exchange with exact-zero gradients
         d = out7.detach()
         return (out7[0], d[1], d[2], d[3], d[4], d[5], d[6])
 
@@ -1049,7 +1058,25 @@ class Darknet(FlatParamsMixin, nn.Module):
                     pos += per * wide
 
     def save_weights(self, path, cutoff=-1):
+        """Byte-compatible darknet .weights (reference models.py:400-422).  Under torchrun (parallel.enable_auto_data_parallel) every rank reaches
+        this call of the unchanged script with identical parameters: rank 0 alone writes -- to a temporary name, renamed when complete --, and all
+        ranks leave together, so a rank that loads the file right afterwards reads whole bytes (until round 5 N ranks truncated and rewrote the
+        same path concurrently)."""
+        from ..parallel import auto_is_writer, auto_barrier
         self._param_sync()
+        if not auto_is_writer():
+            auto_barrier()
+            return
+        tmp_path = f"{path}.tmp.{os.getpid()}"
+        try:
+            self._write_weights(tmp_path, cutoff)
+            os.replace(tmp_path, path)
+        finally:
+            if os.path.exists(tmp_path):
+                os.remove(tmp_path)
+        auto_barrier()
+
+    def _write_weights(self, path, cutoff):
         with open(path, "wb") as fp:
             self.header_info[3] = self.seen
             np.asarray(self.header_info, dtype=np.int32).tofile(fp)

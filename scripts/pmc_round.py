@@ -19,13 +19,30 @@ from mdcv._fingerprint import kernel_fingerprint    # noqa: E402
 tmp, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 wl = sys.argv[4] if len(sys.argv) > 4 else "yolo"
 pre = tag if wl == "yolo" else f"{tag}_{wl}"               # r05_pmc_hbm_traffic.json (yolo: the name bench.py has always looked for) / r05_rektnet_pmc_...
-STEPS = 4                                            # --steps 2 --warmup 1 + the final loss step
+# STEADY-STATE steps only (round 6): the first step of a process also pays one-off initialisation copies / fills (parameter flattening, plan buffers:
+# ~2.5 GB that rounds 2-5 divided into "per step").  A step ends with the optimizer's `adam_kernel`; records up to and including the FIRST one are
+# dropped, and the window closes with the LAST one: STEPS = adam launches - 1.
+STEPS = None
+
+
+def steady(rows):
+    """rows of ONE process in dispatch order -> (rows of the steady-state window, steps in it)"""
+    rows = sorted(rows, key=lambda r: int(r["Dispatch_Id"]))
+    marks = [int(r["Dispatch_Id"]) for r in rows if "adam_kernel" in r["Kernel_Name"]]
+    marks = sorted(set(marks))
+    if len(marks) < 2:
+        raise SystemExit("pmc_round.py: fewer than two optimizer steps in the trace -- run bench.py with --steps >= 2")
+    lo, hi = marks[0], marks[-1]
+    return [r for r in rows if lo < int(r["Dispatch_Id"]) <= hi], len(marks) - 1
 
 
 def collect(sub):
+    global STEPS
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for f in glob.glob(os.path.join(tmp, sub, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
+        rows, n = steady(list(csv.DictReader(open(f))))
+        STEPS = n if STEPS is None else min(STEPS, n)
+        for r in rows:
             a = acc[short_symbol(r["Kernel_Name"])][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"])
             a[1] += 1
@@ -53,7 +70,7 @@ for k in set(fe) | set(wr):
                    "write_bytes_per_launch": 1024.0 * w[0] / max(w[1], 1)}
 tot = {k: (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches_per_step"] for k, v in kern.items()}
 json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes with --kernel-trace only, MDCV_WGRAD_STREAM=0, of `python bench.py --workload "
-                    + wl + " --steps 2 --warmup 1 --no-breakdown` (4 training steps, default batch, bf16); KB -> bytes; FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported",
+                    + wl + " --steps 4 --warmup 1 --no-breakdown --no-ref-loop --no-classes1`; STEADY-STATE steps only (the records up to the first adam_kernel -- one-off initialisation copies / fills -- are dropped; `steps` = optimizer steps in the window); KB -> bytes; FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported",
            "fingerprint": fp, "tag": tag, "workload": wl, "steps": STEPS, "total_bytes_per_step": sum(tot.values()),
            "bytes_per_step_by_kernel": dict(sorted(((k, round(v)) for k, v in tot.items()), key=lambda kv: -kv[1])),
            "kernels": dict(sorted(kern.items(), key=lambda kv: -tot[kv[0]]))},

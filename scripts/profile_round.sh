@@ -20,7 +20,7 @@ f=$(ls $T/stats/*/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$f" ] && cp "$f" $OUT/${TAG}_${WL}_bench_kernel_stats.csv
 
 if [ "$WL" = "yolo" ] || [ "$WL" = "rektnet" ]; then
-  CMD="python $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-fp32"
+  CMD="python $R/bench.py --workload $WL --steps 4 --warmup 1 --no-cpu-baseline --no-breakdown --no-fp32 --no-ref-loop --no-classes1"
   export MDCV_WGRAD_STREAM=0      # counters are per dispatch but device-wide: one kernel at a time
   timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $T/fetch -- $CMD > /dev/null 2> $T/fetch_err.log || echo "fetch pass failed"
   timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $T/write -- $CMD > /dev/null 2> $T/write_err.log || echo "write pass failed"
