@@ -62,6 +62,7 @@ class KeypointNet(FlatParamsMixin, nn.Module):
     # shard and the exchange AVERAGES the gradients -- the full-batch mean's gradient for the location term (the geometric term couples the samples
     # of a shard only).  The reference has no multi-GPU path for this network; YOLOv3's SUM is DataParallel's `losses[0].sum()`.
     _dp_average = True
+    f32_logits = True                  # bf16 mode: the head conv writes fp32 logits (csrc/rektnet_head.hip; tests / A-B flip the class attribute)
 
     def __init__(self, num_kpt=7, image_size=(80, 80), onnx_mode=False, init_weight=True, precision=None):
         super().__init__()
@@ -191,7 +192,7 @@ class KeypointNet(FlatParamsMixin, nn.Module):
         plan.emit_pack(csh, need_dgrad=True)
         lg = TNode(plan.new_act(B, H, W, K), name="logits")
         # bf16 mode: the logits stay fp32 (csrc/rektnet_head.hip head1x1_f32_kernel has the reason); the bf16 buffer above only gives the backward its shape
-        f32_logits = plan.dtype == BF16 and a.act.C % 32 == 0 and a.act.C <= 1024 and K <= 8 and self.out.kernel_size == (1, 1)
+        f32_logits = self.f32_logits and plan.dtype == BF16 and a.act.C % 32 == 0 and a.act.C <= 1024 and K <= 8 and self.out.kernel_size == (1, 1)
         if f32_logits:
             plan.lg32 = torch.zeros(B * H * W, 8, dtype=torch.float32, device=device)
             w_out, b_out = self.out.weight, self.out.bias

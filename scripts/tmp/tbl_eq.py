@@ -13,7 +13,7 @@ for (H, Ci, Co, xl) in SH:
     xw = torch.randn(M, xl, device="cuda", generator=g).to(torch.bfloat16)
     xp = xw.data_ptr() + (xl - Ci) * 2
     res = []
-    for code in (0, 34020, 0, 34020):
+    for code in (0, 34040, 0, 34040):
         dt = _lib.tuned(1, code)
         splits = L.conv2d_wgrad_splits_geom(dt, B, H, H, Ci, H, H, Co, 3, 3, 1, 1, 1, Co, xl)
         ws = torch.empty(splits * Co * 9 * Ci, device="cuda")

@@ -126,7 +126,7 @@ def test_both_networks_train_on_the_synthetic_streams(tmp_path):
     kp = KeypointNet(7, (80, 80), precision="bf16").cuda().train()
     opt = FusedAdam(kp, lr=1e-2)
     losses = []
-    for x, hm_t, pts_t, _, _ in SyntheticConeCrops(256, 80, batches=150, seed=5):
+    for x, hm_t, pts_t, _, _ in SyntheticConeCrops(256, 80, batches=300, seed=5):
         opt.zero_grad()
         hm, pts = kp(x)
         loss = crit(hm, pts, hm_t, pts_t)[2]
