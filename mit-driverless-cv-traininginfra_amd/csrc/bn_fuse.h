@@ -63,7 +63,7 @@ struct BnFuseAcc {
     ET<T>::unpack(yq, yv);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float pre = yv[e] * fs[e] + fb[e];
+      const float pre = __builtin_fmaf(yv[e], fs[e], fb[e]);   // (the sign at the activation boundary must be the apply pass's: common.h mdcv_bn_bwd_dy)
       const float g = (f.act != 0 && !(pre > 0.f)) ? dv[e] * f.slope : dv[e];
       sg[e] += g;
       sx[e] += g * (yv[e] - fm[e]);

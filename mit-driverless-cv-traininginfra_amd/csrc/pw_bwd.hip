@@ -253,7 +253,7 @@ __global__ __launch_bounds__(NT) void pw_bwd_kernel(PwbArgs a) {
           v[2] = __uint_as_float(d.y << 16); v[3] = __uint_as_float(d.y & 0xffff0000u);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float pre = yv[e] * fs[e] + fb[e];
+            const float pre = __builtin_fmaf(yv[e], fs[e], fb[e]);   // (the sign at the activation boundary must be the apply pass's: mdcv_bn_bwd_dy)
             const float g = (a.fuse.act != 0 && !(pre > 0.f)) ? v[e] * a.fuse.slope : v[e];
             sg[e] += g;
             sx[e] += g * (yv[e] - fm[e]);
@@ -311,14 +311,8 @@ int launch_pwb(const PwbArgs& a, hipStream_t st) {
   constexpr int LDS = KB * 4096 + S * (KB * 2048 + NX * T64) + BP * SPITCH + 1024;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   auto kern = pw_bwd_kernel<CO4, S, ADD, FUSE>;
-  static bool attr_done[64] = {};                          // per device: the attribute belongs to the function ON one device
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MDCV_EARG;
-  if (!attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
-    attr_done[dev] = true;
-  }
+  static DynLds dyn_lds;                                     // per device, race-free (common.h)
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(kern), LDS); e != hipSuccess) return (int)e;
   const unsigned grid = (unsigned)(8 * cdiv(a.nslabs, 8) * a.slices);
   MDCV_LAUNCH(kern, dim3(grid), dim3(NT), LDS, st, a);
   MDCV_CHECK_LAUNCH();

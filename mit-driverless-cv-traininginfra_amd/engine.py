@@ -178,9 +178,20 @@ class BnSpec:
         plan.keep.append(self)
 
 
+def _variant_env(name):
+    """ONE signed variant code per kernel family (csrc/tune.h); the comma lists the removed set_variant hooks took are refused with a clear message
+    instead of a ValueError from int() at import time."""
+    raw = (os.environ.get(name) or "0").strip()
+    try:
+        return int(raw)
+    except ValueError:
+        raise ValueError(f"{name}={raw!r}: one signed integer variant code per kernel family is carried by every call since round 5 "
+                         "(csrc/tune.h lists them); comma-separated lists are no longer accepted") from None
+
+
 class Plan:
-    tune_conv = int(os.environ.get("MDCV_CONV_VARIANT", "0") or 0)      # variant code of the conv family for this plan's calls (0: defaults)
-    tune_wgrad = int(os.environ.get("MDCV_WGRAD_VARIANT", "0") or 0)    # ... of the weight-gradient family
+    tune_conv = _variant_env("MDCV_CONV_VARIANT")       # variant code of the conv family for this plan's calls (0: defaults)
+    tune_wgrad = _variant_env("MDCV_WGRAD_VARIANT")     # ... of the weight-gradient family
 
     def __init__(self, device, precision, training, grad_sink=None):
         _lib.require_gpu()

@@ -2,7 +2,7 @@
 instead of beside the backward.  Results are garbage (the forward overwrites their operands); the schedule is real."""
 import os, sys, tempfile, time, statistics, ctypes
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 from mdcv import _lib

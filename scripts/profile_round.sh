@@ -14,7 +14,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 T=$OUT/tmp_$WL; rm -rf $T; mkdir -p $T
 
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats -- python $R/bench.py --workload $WL --no-cpu-baseline --no-fp32 \
+# (the headline loop only: the reference-loop and classes=1 legs of the default line run other step counts of the same kernels)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $T/stats -- python $R/bench.py --workload $WL --no-cpu-baseline --no-fp32 --no-ref-loop --no-classes1 \
     > $OUT/${TAG}_${WL}_bench_under_rocprof.json 2> $T/stats_err.log || echo "stats pass failed"
 f=$(ls $T/stats/*/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$f" ] && cp "$f" $OUT/${TAG}_${WL}_bench_kernel_stats.csv

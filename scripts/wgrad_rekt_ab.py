@@ -1,5 +1,5 @@
 import ctypes, os, sys, statistics, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mdcv import _lib
 L = _lib.lib()
