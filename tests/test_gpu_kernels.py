@@ -1641,3 +1641,31 @@ def test_batched_pack_equals_the_single_layer_pack():
             assert torch.equal(wd.view(torch.int16), wd0.view(torch.int16)), shp
         if bp is not None:
             assert torch.equal(bp[:shp[0]], b), shp
+
+
+@pytest.mark.parametrize("case", [(6400 * 3, 128, 128, 7), (1000, 32, 40, 8), (64 * 5 + 17, 256, 256, 7), (1, 64, 64, 1), (80 * 80 * 2, 128, 136, 7)], ids=str)
+def test_head1x1_f32_logits(case):
+    """mdcv_head1x1_f32 (round 6: KeypointNet's 1x1 head with fp32 logits out of bf16 features, keypoint_net.py:40,68): out[p][k] = bias[k] + sum_c x[p][c] w[k][c]
+    in fp32 over the bf16 features exactly as stored -- ragged pixel counts, features inside a wider NHWC buffer (ldx > C), K = 1 / 7 / 8, padding columns zero,
+    no bias, deterministic."""
+    L = _lib.lib()
+    M, C, ldx, K = case
+    g = torch.Generator().manual_seed(M + C + K)
+    xw = torch.randn(M, ldx, generator=g).to(torch.bfloat16)
+    w = torch.randn(K, C, generator=g) * 0.2
+    b = torch.randn(K, generator=g)
+    off = ldx - C                                            # the features sit at the END of each pixel row of the wider buffer
+    ref = xw[:, off:].float().double() @ w.double().t() + b.double()
+    xd, wd, bd = xw.cuda(), w.cuda(), b.cuda()
+    outs = []
+    for bias in (bd, None, bd):
+        out = torch.full((M, 8), float("nan"), dtype=torch.float32, device="cuda")
+        L.check(L.head1x1_f32(xd.data_ptr() + off * 2, ldx, wd.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), M, C, K, st()), "head1x1_f32")
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[2])
+    np.testing.assert_allclose(outs[0][:, :K].double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    np.testing.assert_allclose(outs[1][:, :K].double().numpy(), (ref - b.double()).numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    assert not bool(outs[0][:, K:].any()), "columns >= K must be exact zeros (the flat softmax reads a stride of 8)"
+    for bad in ((M, 48, 48, 7), (M, C, ldx, 9), (M, C, C - 8, 7)):     # C % 32 != 0, K > 8, ldx < C
+        assert L.head1x1_f32(xd.data_ptr(), bad[2], wd.data_ptr(), None, out.data_ptr(), bad[0], bad[1], bad[3], st()) != 0
