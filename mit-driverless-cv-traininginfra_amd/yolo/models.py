@@ -1074,7 +1074,7 @@ class Darknet(FlatParamsMixin, nn.Module):
         finally:
             if os.path.exists(tmp_path):
                 os.remove(tmp_path)
-        auto_barrier()
+            auto_barrier()                                   # (also when the write failed: the other ranks are waiting in theirs)
 
     def _write_weights(self, path, cutoff):
         with open(path, "wb") as fp:
