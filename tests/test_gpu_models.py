@@ -925,7 +925,7 @@ def test_pipelined_adam_is_bit_identical_mini_darknet():
         assert torch.equal(res[0][1][k], res[1][1][k]), k
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 5e-3)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 5e-3)])      # SURVEY 8d; measured (round 6): 1.2e-7 / 7.0e-4
 def test_full_yolov3_batch32_train_forward_backward_vs_oracle(precision, tol, tmp_path):
     """BASELINE config 3 at its real size (yolo_baseline 416x416, classes=80, batch 32) against the CPU oracle on the same seeded
     weights, inputs and targets: total loss within the SURVEY 8d tolerance, the six parts within 10 %, EVERY conv weight gradient aligned
@@ -967,6 +967,7 @@ def test_full_yolov3_batch32_train_forward_backward_vs_oracle(precision, tol, tm
     out[0].sum().backward()
     got = torch.stack([o.detach() for o in out]).cpu().numpy()
     exp = torch.stack([r.detach() for r in ref]).numpy()
+    print("total loss %.7f vs oracle %.7f: rel %.2e (tol %g)" % (got[0], exp[0], abs(got[0] - exp[0]) / abs(exp[0]), tol))
     assert abs(got[0] - exp[0]) <= tol * abs(exp[0]), (got, exp)
     np.testing.assert_allclose(got[1:], exp[1:], rtol=0.1 if precision == "bf16" else 1e-3)
     named = dict(net.named_parameters())
