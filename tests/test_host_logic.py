@@ -351,3 +351,21 @@ def test_ring_kernels_drain_their_lds_reads_before_every_barrier():
     seen, bad = check_ring_barriers.check(lib)
     assert seen >= 100, seen                              # the conv / shift / weight-gradient families are all LDS-DMA kernels
     assert not bad, bad[:10]
+
+
+def test_bench_comm_preflight_turns_a_failing_lease_into_a_diagnosis():
+    """`bench.py --gpus N` opens with comm_preflight: when the process group cannot come up -- here: the RCCL backend on a
+    box without a GPU, no rendezvous peer -- rank 0 prints ONE JSON object naming the failing step and the environment, and exits with 3 instead of
+    leaving the driver with a traceback and a return code."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import torch, bench; "
+            "bench.comm_preflight('nccl', 0, 2, torch.device('cpu'))" % root)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 3, (out.returncode, out.stdout[-500:], out.stderr[-1500:])
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["error"] == "data-parallel preflight failed" and d["step"] == "init_process_group" and d["world"] == 2 and d["backend"] == "nccl"
+    assert "exception" in d and "hint" in d and "HSA_ENABLE_IPC_MODE_LEGACY" in d
