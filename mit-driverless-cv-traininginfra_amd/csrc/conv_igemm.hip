@@ -2144,8 +2144,10 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
   }
   if (use_wgrad_stream(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc) &&
       mdcv_wgrad_stream_splits_ok(splits, B, Hout, Wout, Cin, Cout, dil)) {
-    const int rc = mdcv_wgrad_stream(dy, dy_ldc, x, x_ldc, ws, splits, B, Hout, Wout, Cin, Cout, dil, (hipStream_t)stream);
-    if (rc) return rc;
+    int wrote_dw = 0;
+    const int rc = mdcv_wgrad_stream(dy, dy_ldc, x, x_ldc, ws, splits, B, Hout, Wout, Cin, Cout, dil, (hipStream_t)stream, dw_oihw, Cin_real, Cout_real,
+                                     accumulate, &wrote_dw);
+    if (rc || wrote_dw) return rc;                           // (the slab-free form wrote the OIHW gradient itself)
     return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, 9, accumulate, (hipStream_t)stream);
   }
   // 3x3 / stride 1 / pad 1 with 128-multiple channel counts: the three kw taps of a kernel row share one activation tile

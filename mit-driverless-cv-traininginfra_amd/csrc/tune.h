@@ -61,6 +61,7 @@ struct MdcvTune {
   int stream_tiled = 1;   // channel-tiled instantiation for the wide layers (Cin % 64 == 0, Cout % 128 == 0); 0 = off (1800)
   int stream_light_maxpos = 600000;   // light form up to this many padded stream positions (30003: everywhere, 30005: never, 30002: default)
   int stream_table = 1;            // DMA addresses from a per-block LDS table of pixel indices (34021 on / 34020 off: the lanes step (x, y, image) forward) -- round 6
+  int stream_direct = 1;           // slab-free form where one split of 64 co x 32 ci tiles fills the chip (34051 on / 34050 off) -- round 6
   int stream_light_depth = 1;      // its DMA prefetch depth (steps in flight behind the one being multiplied; 34000 + d)
   int stream_light_blocks = 256;   // its block target (33000 + n)
   int stream_tiled_blocks = 128;   // block target of the 8-wave tiled form (30000 + n).  A block fills its CU, and the weight gradients run BESIDE
@@ -127,6 +128,7 @@ inline void mdcv_tune_apply_wgrad(MdcvTune& t, int v) {
     if (b >= 4001 && b <= 4002) { t.stream_light_depth = b - 4000; return; }
     if (b >= 4012 && b <= 4014) { t.wgrad_bna_stages = b - 4010; return; }
     if (b == 4020 || b == 4021) { t.stream_table = b - 4020; return; }
+    if (b == 4050 || b == 4051) { t.stream_direct = b - 4050; return; }
     if (b == 2) t.stream_light_maxpos = 600000;
     else if (b == 3) t.stream_light_maxpos = 1 << 30;
     else if (b == 5) t.stream_light_maxpos = 0;

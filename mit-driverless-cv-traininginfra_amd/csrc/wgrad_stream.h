@@ -11,6 +11,7 @@ struct WgradStreamArgs {
   int hpad, RS;                         // halo rows on each side (multiple of 32) and rows of the activation ring
   int pos_per_split, splits, xcd_chunk;
   int tbl_steps;                        // steps covered by one window of the DMA-address table (TBL forms)
+  float* dw; int Cin_real, Cout_real, accumulate;   // DIRECT form: the OIHW gradient itself (no slab), real channel counts, += instead of =
   int tiles, tiles_ci;                  // TILED instantiation: (Cout/128 or /64) x (Cin/64) channel tiles per split, blocks = splits * tiles
 };
 
@@ -18,8 +19,9 @@ bool mdcv_wgrad_stream_eligible(int dtype, int B, int H, int W, int Cin, int Cou
                                 long long dy_ldc, long long x_ldc);
 int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil);
 bool mdcv_wgrad_stream_splits_ok(int splits, int B, int H, int W, int Cin, int Cout, int dil);
+// wrote_dw: set to 1 when the launch wrote dw_oihw itself (the slab-free form; splits == 1, `ws` untouched) -- the caller then skips the slab reduce
 int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, int Cin, int Cout,
-                      int dil, hipStream_t st);
+                      int dil, hipStream_t st, float* dw_oihw, int Cin_real, int Cout_real, int accumulate, int* wrote_dw);
 // 7x7 / stride 1 / pad 3 stem, 16 (padded) -> 16 channels
 bool mdcv_wgrad_stem_eligible(int dtype, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int dil,
                               long long dy_ldc, long long x_ldc);

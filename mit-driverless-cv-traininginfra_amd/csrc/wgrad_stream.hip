@@ -57,11 +57,13 @@ template <int OFF> __device__ __forceinline__ int lds_ld32(unsigned addr) {
   return v;
 }
 template <int NX, int NY> __device__ __forceinline__ void wait_tbl(int (&nx)[NX], int (&ny)[NY]) {     // all LDS reads of this wave have returned
-  static_assert(NX >= 1 && NX <= 2 && NY >= 1 && NY <= 2, "one or two DMA instructions per operand per wave per step");
+  static_assert(NX >= 1 && NX <= 2 && NY >= 1 && NY <= 4 && NY != 3, "one or two (dY: up to four) DMA instructions per operand per wave per step");
   if constexpr (NX == 1 && NY == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(ny[0]) :: "memory");
   else if constexpr (NX == 1 && NY == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(ny[0]), "+v"(ny[1]) :: "memory");
   else if constexpr (NX == 2 && NY == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(ny[0]) :: "memory");
-  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(ny[0]), "+v"(ny[1]) :: "memory");
+  else if constexpr (NX == 2 && NY == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(ny[0]), "+v"(ny[1]) :: "memory");
+  else if constexpr (NX == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]) :: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(ny[0]), "+v"(ny[1]), "+v"(ny[2]), "+v"(ny[3]) :: "memory");
 }
 // wait until at most N of this wave's LDS reads are outstanding (they return in order); the MFMAs that use `f...` depend on it
 template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory"); }
@@ -89,7 +91,10 @@ template <int N> __device__ __forceinline__ void wait_lds(bf16x8_t (&fa)[4], bf1
 // and re-deriving the pixel row per DMA instruction.  Round 6: the light form's step was 72 MFMAs behind ~180 address / select instructions (ISA: eight
 // v_mad_u64_u32 among them), issued by the only wave of its SIMD; with the table a DMA instruction costs one ds_read_b32 (prefetched a step ahead), one
 // v_mad_u32_u24 and the m0 write.  Same lanes, same ring image: results are bit-identical to the stepping form.
-template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8, bool TBL = false>
+// DIRECT (round 6): the block owns its 16*NCO x 9 x 16*NCI slice of dW OUTRIGHT -- one split, no slab, no reduce launch: the epilogue adds the PG position
+// groups' partial sums in LDS (fixed order) in [co][ci][tap] order and writes whole OIHW rows of the gradient itself.  For layers with enough 64 co x 32 ci
+// tiles to fill the chip in one split: YOLOv3's 13^2 512->1024 layers (256 tiles).
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED = false, int NW = 8, bool TBL = false, bool DIRECT = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3x3_stream_kernel(WgradStreamArgs a, unsigned dy_bytes, unsigned x_bytes) {
   constexpr int RBX = NCI * 32, RBY = NCO * 32;            // row bytes
   constexpr int LPRX = 2 * NCI, LPRY = 2 * NCO;            // 16-byte slots (= DMA lanes) per row
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
   const unsigned tbl_base = ybase + (unsigned)((D + 1) * YSTAGE);
   int ex[XI], ey[DYI];
   unsigned tx_addr = 0, ty_addr = 0;
-  static_assert(!TBL || (XI <= 2 && DYI <= 2), "table reads are unrolled by hand");
+  static_assert(!TBL || (XI <= 2 && (DYI <= 2 || DYI == 4)), "table reads are unrolled by hand");
   int tbl_s0 = 0;                                             // first step of the table's current window (a.tbl_steps steps; long runs rebuild it)
   auto fetch = [&](int t, int (&nx)[XI], int (&ny)[DYI]) {
     const unsigned ax = tx_addr + (unsigned)((t - tbl_s0) * (BP * 4)), ay = ty_addr + (unsigned)((t - tbl_s0) * (BP * 4));
@@ -246,6 +251,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
     if constexpr (XI > 1) nx[1] = lds_ld32<NW * RPIX * 4>(ax);
     ny[0] = lds_ld32<0>(ay);
     if constexpr (DYI > 1) ny[1] = lds_ld32<NW * RPIY * 4>(ay);
+    if constexpr (DYI > 2) { ny[2] = lds_ld32<2 * NW * RPIY * 4>(ay); ny[3] = lds_ld32<3 * NW * RPIY * 4>(ay); }
   };
   auto issue_tbl = [&](int t, int rho_new) {                 // step t from ex / ey
 #pragma unroll
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
   };
   const bool late = NSUB == 1 && wave >= NW / 2;             // (two sub-steps per step: the skewed schedule spills)
   // channel-tiled instantiation: the reads run a few fragments ahead of the multiplies (wgrad_stream_pipe.inc, scripts/gen_wgrad_pipeline.py)
-  constexpr bool kPipe = TILED && NSUB == 2 && PG == 1 && A == 4;
+  constexpr bool kPipe = TILED && NSUB == 2 && (PG == 1 || PG == 2) && A == 4;
   bf16x8_t fa2[2][A];
   if constexpr (kPipe) {
 #pragma unroll
@@ -472,8 +478,49 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && NCO == 4) ? 2 : 1) void wgrad3
   __syncthreads();
 
   // epilogue: the PG partial sums meet in LDS (fixed order), TGRP taps at a time, then coalesced rows of the split's slab
-  constexpr int OR = TGRP * CIN + 4;                         // floats per staged row
   float* so = reinterpret_cast<float*>(smem);
+  if constexpr (DIRECT) {
+    static_assert(TILED && TGRP == 1, "the direct form is a tiled form");
+    constexpr int PR = CIN * 9 + 4;                          // floats per staged output-channel row: [ci][tap] + pad
+#pragma unroll
+    for (int pgi = 0; pgi < PG; ++pgi) {
+      if (pg == pgi) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+          for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int idx = ((cog * A + i) * 16 + kq * 4 + rr) * PR + (cit * 16 + t16) * 9 + tap;
+              const float v = acc[tap][i][rr];
+              so[idx] = pgi == 0 ? v : so[idx] + v;
+            }
+      }
+      __syncthreads();
+    }
+    // whole OIHW rows: output channel co of the tile -> CIN * 9 contiguous floats at dw[co][tile_ci * CIN][0][0]
+    float* __restrict__ dw = a.dw + ((size_t)tile_co * COUT * a.Cin_real + (size_t)tile_ci * CIN) * 9;
+    if (a.Cin_real == a.Cin && a.Cout_real == a.Cout) {
+      constexpr int V4 = CIN * 9 / 4;
+      for (int v = tid; v < COUT * V4; v += NW * 64) {
+        const int row = v / V4, c4 = (v - row * V4) * 4;
+        float4 val = *reinterpret_cast<const float4*>(so + row * PR + c4);
+        float4* dst = reinterpret_cast<float4*>(dw + (size_t)row * a.Cin_real * 9 + c4);
+        if (a.accumulate) { const float4 o = *dst; val.x += o.x; val.y += o.y; val.z += o.z; val.w += o.w; }
+        *dst = val;
+      }
+    } else {                                                 // padded channels are cropped: element by element
+      for (int v = tid; v < COUT * CIN * 9; v += NW * 64) {
+        const int row = v / (CIN * 9), c = v - row * (CIN * 9), ci = c / 9;
+        if (tile_co * COUT + row < a.Cout_real && tile_ci * CIN + ci < a.Cin_real) {
+          float* dst = dw + (size_t)row * a.Cin_real * 9 + c;
+          *dst = so[row * PR + c] + (a.accumulate ? *dst : 0.f);
+        }
+      }
+    }
+    return;
+  }
+  constexpr int OR = TGRP * CIN + 4;                         // floats per staged row
   float* __restrict__ ws = a.ws + ((size_t)slab_index * a.Cout + (size_t)tile_co * COUT) * a.Ktot + tile_ci * CIN;
 #pragma unroll
   for (int g0 = 0; g0 < 9 / TGRP; ++g0) {
@@ -625,7 +672,7 @@ __global__ __launch_bounds__(512) void wgrad7x7_stream_kernel(WgradStreamArgs a,
   }
 }
 
-struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; bool tiled = false; int nw = 8; };
+struct StreamCfg { int nci, nco, a, pg, bp, d, tgrp; bool tiled = false; int nw = 8; bool direct = false; };
 // Tuning hooks (mdcv_conv2d_wgrad_set_variant): ONE per decision that was measured on the training step.
 // Light form of the tiled instantiation: 64 co x 64 ci per block, FOUR waves (one per SIMD, 237 VGPRs), prefetch depth 1, 56 KiB of LDS -- about
 // half a CU, on 256 blocks.  The 8-wave form owns its CU outright (2 x 234 VGPRs per SIMD, 120 KiB) and runs on 128 blocks so that the main
@@ -645,6 +692,10 @@ inline bool stream_cfg(int Cin, int Cout, StreamCfg& c, long long Mq = 0) {     
   else if (TUNE().stream_tiled && Cin % 64 == 0 && Cout % 128 == 0 && Cin <= 4096 && Cout <= 4096) {
     c = {4, 8, 4, 1, 64, 2, 1}; c.tiled = true;
     if (Mq > 0 && Mq <= TUNE().stream_light_maxpos) { c.nco = 4; c.nw = 4; c.d = TUNE().stream_light_depth; }   // light form
+    // slab-free form: enough 64 co x 32 ci tiles to fill the chip with ONE split (13^2 512 -> 1024: 256), short position runs (the table window
+    // and the [64][32 * 9] staging fit beside the ring)
+    const int t32 = (Cout / 64) * (Cin / 32);
+    if (c.nw == 4 && TUNE().stream_direct && TUNE().stream_table && t32 >= 192 && t32 <= 512 && Mq <= 16384) { c = {2, 4, 4, 2, 128, 1, 1}; c.tiled = true; c.nw = 4; c.direct = true; }
   }
   else return false;
   return true;
@@ -659,7 +710,7 @@ inline int stream_ring_rows(const StreamCfg& c, int W, int dil) {       // >= (D
 inline int stream_lds(const StreamCfg& c, int W, int dil, int tbl_bytes = 0) {
   const int rs = stream_ring_rows(c, W, dil);
   const int ring = (c.d + 1) * c.bp * c.nco * 32 + (rs + c.bp / c.pg) * c.nci * 32 + tbl_bytes;     // dY stages + ring + its mirror (one wave's sub-steps of a step) + the DMA-address table
-  const int stage_out = c.nco * 16 * (c.tgrp * c.nci * 16 + 4) * 4;
+  const int stage_out = c.direct ? c.nco * 16 * (c.nci * 16 * 9 + 4) * 4 : c.nco * 16 * (c.tgrp * c.nci * 16 + 4) * 4;
   return ring > stage_out ? ring : stage_out;
 }
 // TBL forms: one int per stream position of a block's run plus the halo on both sides
@@ -674,12 +725,12 @@ inline bool stream_cfg_geom(int Cin, int Cout, int W, int dil, StreamCfg& c, lon
   return stream_lds(c, W, dil) <= 160 * 1024;
 }
 
-template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED, int NW, bool TBL>
+template <int NCI, int NCO, int A, int PG, int BP, int D, int TGRP, bool TILED, int NW, bool TBL, bool DIRECT = false>
 int launch_stream1(const WgradStreamArgs& a, int lds, unsigned dyb, unsigned xb, hipStream_t st) {
   static DynLds dyn_lds;
-  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW, TBL>), lds); e != hipSuccess)
+  if (hipError_t e = mdcv_dyn_lds(dyn_lds, reinterpret_cast<const void*>(wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW, TBL, DIRECT>), lds); e != hipSuccess)
     return (int)e;
-  MDCV_LAUNCH((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW, TBL>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, dyb, xb);
+  MDCV_LAUNCH((wgrad3x3_stream_kernel<NCI, NCO, A, PG, BP, D, TGRP, TILED, NW, TBL, DIRECT>), dim3((unsigned)(a.xcd_chunk * 8)), dim3(NW * 64), lds, st, a, dyb, xb);
   MDCV_CHECK_LAUNCH();
   return MDCV_OK;
 }
@@ -710,6 +761,7 @@ int mdcv_wgrad_stream_splits(int B, int H, int W, int Cin, int Cout, int dil) {
   StreamCfg c;
   const int Mq = B * (H + dil) * (W + dil);
   if (!stream_cfg(Cin, Cout, c, Mq)) return 1;
+  if (c.direct) return 1;                                    // the slab-free form: every block owns its slice of dW outright
   int s = TUNE().stream_blocks > 0 ? TUNE().stream_blocks : (c.a <= 2 ? 512 : 256);
   if (c.tiled) s = ((TUNE().stream_blocks > 0 ? TUNE().stream_blocks : (c.nco == 4 ? TUNE().stream_light_blocks : TUNE().stream_tiled_blocks)) + (Cout / (16 * c.nco)) * (Cin / 64) - 1) / ((Cout / (16 * c.nco)) * (Cin / 64));   // blocks = splits x channel tiles
   const int max_s = (Mq + c.bp * 4 - 1) / (c.bp * 4);
@@ -723,12 +775,14 @@ bool mdcv_wgrad_stream_splits_ok(int splits, int B, int H, int W, int Cin, int C
   StreamCfg c;
   const int Mq = B * (H + dil) * (W + dil);
   if (splits < 1 || !stream_cfg(Cin, Cout, c, Mq)) return false;
+  if (c.direct) return splits == 1;
   const int pps = ((Mq + splits - 1) / splits + c.bp - 1) / c.bp * c.bp;
   return (Mq + pps - 1) / pps == splits;
 }
 
 int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, int Cin, int Cout,
-                      int dil, hipStream_t st) {
+                      int dil, hipStream_t st, float* dw_oihw, int Cin_real, int Cout_real, int accumulate, int* wrote_dw) {
+  if (wrote_dw) *wrote_dw = 0;
   StreamCfg c;
   if (!stream_cfg_geom(Cin, Cout, W, dil, c, (long long)B * (H + dil) * (W + dil))) return MDCV_EARG;
   if (c.bp / (W + dil) + 1 >= H + dil) return MDCV_EARG;
@@ -741,15 +795,21 @@ int mdcv_wgrad_stream(const void* dy, int dy_ldc, const void* x, int x_ldc, floa
   a.pos_per_split = ((a.Mq + splits - 1) / splits + c.bp - 1) / c.bp * c.bp;
   if ((a.Mq + a.pos_per_split - 1) / a.pos_per_split != splits) return MDCV_EARG;
   a.splits = splits;
-  a.tiles_ci = c.tiled ? Cin / 64 : 1;
+  a.tiles_ci = c.tiled ? Cin / (16 * c.nci) : 1;
   a.tiles = c.tiled ? (Cout / (16 * c.nco)) * a.tiles_ci : 1;
   a.xcd_chunk = (splits * a.tiles + 7) / 8;
+  a.dw = dw_oihw; a.Cin_real = Cin_real; a.Cout_real = Cout_real; a.accumulate = accumulate;
   // the DMA-address table (TBL forms) where it fits beside the ring: 12-13 KiB for YOLOv3's layers (one window), at most 16 KiB + halo for longer runs
   a.tbl_steps = stream_tbl_steps(a.pos_per_split, c.bp);
   const int tblb = stream_tbl_bytes(a.pos_per_split, c.bp, a.hpad);
   const bool tbl = TUNE().stream_table && stream_lds(c, W, dil, tblb) <= 160 * 1024;
   const int lds = stream_lds(c, W, dil, tbl ? tblb : 0);
   const unsigned dyb = (unsigned)((long long)B * H * W * dy_ldc * 2), xb = (unsigned)((long long)B * H * W * x_ldc * 2);
+  if (c.direct) {                                            // slab-free: the kernel writes the OIHW gradient itself
+    if (!tbl || !dw_oihw || !wrote_dw || splits != 1) return MDCV_EARG;
+    *wrote_dw = 1;
+    return launch_stream1<2, 4, 4, 2, 128, 1, 1, true, 4, true, true>(a, lds, dyb, xb, st);
+  }
   if (c.tiled && c.nw == 4) return c.d == 1 ? launch_stream<4, 4, 4, 1, 64, 1, 1, true, 4>(a, lds, tbl, dyb, xb, st) : launch_stream<4, 4, 4, 1, 64, 2, 1, true, 4>(a, lds, tbl, dyb, xb, st);
   if (c.tiled) {
     if (c.d == 1) return launch_stream<4, 8, 4, 1, 64, 1, 1, true>(a, lds, tbl, dyb, xb, st);

@@ -936,7 +936,8 @@ def test_wgrad_stream_kernel(case):
     xb, dyb = to_nhwc(x, dt), to_nhwc(dy, dt)
     ktot = 9 * Ci
     outs = {}
-    for variant in (0, 34020, 9):               # 0: default dispatch (stream kernel, DMA addresses from the LDS table) ; 34020: its stepping-lane form ; 9: generic kernel
+    for variant in (0, 34050, 34020, 9):        # 0: default dispatch (stream kernel, DMA addresses from the LDS table; slab-free where one split fills the chip) ;
+                                                # 34050: the slab form everywhere ; 34020: its stepping-lane form ; 9: generic kernel
         L.conv2d_wgrad_set_variant(variant)
         try:
             splits = L.conv2d_wgrad_splits_geom(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, dil, dil, Co, Ci)
@@ -953,7 +954,8 @@ def test_wgrad_stream_kernel(case):
         assert np.isfinite(got).all(), v
         np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * scale, err_msg=f"variant {v} splits {splits}")
     np.testing.assert_allclose(outs[0][0], outs[9][0], rtol=1e-3, atol=1e-3 * scale)      # same bf16 products, fp32 sums in another order
-    assert outs[0][1] == outs[34020][1] and np.array_equal(outs[0][0], outs[34020][0])     # same lanes, same ring image: the table changes addresses' COST only
+    assert outs[34050][1] == outs[34020][1] and np.array_equal(outs[34050][0], outs[34020][0])     # same lanes, same ring image: the table changes addresses' COST only
+    np.testing.assert_allclose(outs[0][0], outs[34050][0], rtol=1e-3, atol=1e-3 * scale)   # slab-free form (where taken: splits == 1): same products, another summation order
 
 
 @pytest.mark.parametrize("case", [(4, 128, 256, 13, 13, 1), (2, 64, 128, 26, 20, 1), (3, 256, 128, 9, 17, 2), (2, 128, 128, 52, 52, 1)], ids=str)
@@ -1669,3 +1671,35 @@ def test_head1x1_f32_logits(case):
     assert not bool(outs[0][:, K:].any()), "columns >= K must be exact zeros (the flat softmax reads a stride of 8)"
     for bad in ((M, 48, 48, 7), (M, C, ldx, 9), (M, C, C - 8, 7)):     # C % 32 != 0, K > 8, ldx < C
         assert L.head1x1_f32(xd.data_ptr(), bad[2], wd.data_ptr(), None, out.data_ptr(), bad[0], bad[1], bad[3], st()) != 0
+
+
+@pytest.mark.parametrize("case", [(4, 512, 1024, 13, 13, 512, 1024), (2, 512, 1024, 13, 11, 500, 1020)], ids=str)
+def test_wgrad_slab_free_form(case):
+    """Round 6: where ONE split of 64 co x 32 ci tiles fills the chip (YOLOv3's 13^2 512 -> 1024 layers: 256 tiles) the LDS-ring weight gradient owns its
+    slice of dW outright -- splits == 1, the slab buffer is never touched, no reduce launch: the kernel writes OIHW rows itself.  == torch; accumulate adds;
+    padded channels are cropped; deterministic."""
+    L = _lib.lib()
+    dt = BF16
+    B, Ci, Co, H, W, ci_real, co_real = case
+    g = torch.Generator().manual_seed(Ci + H + ci_real)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(rnd(dt, x), w, None, stride=1, padding=1).backward(rnd(dt, dy))
+    ref = w.grad.numpy()[:co_real, :ci_real]
+    xb, dyb = to_nhwc(x, dt), to_nhwc(dy, dt)
+    splits = L.conv2d_wgrad_splits_geom(dt, B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, Co, Ci)
+    assert splits == 1
+    ws = torch.full((Co * 9 * Ci,), float("nan"), dtype=torch.float32, device="cuda")   # one slab's worth: it must stay untouched
+    res = []
+    for acc, init in ((0, 3.0), (0, -1.0), (1, 2.5)):
+        dw = torch.full((co_real, ci_real, 3, 3), init, dtype=torch.float32, device="cuda")
+        L.check(L.conv2d_wgrad(dt, dyb.data_ptr(), Co, xb.data_ptr(), Ci, ws.data_ptr(), splits, dw.data_ptr(), acc, B, H, W, Ci, ci_real,
+                               H, W, Co, co_real, 3, 3, 1, 1, 1, st()), "wgrad")
+        torch.cuda.synchronize()
+        res.append(dw.cpu().numpy())
+    assert bool(torch.isnan(ws).all())
+    scale = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(res[0], ref, rtol=2e-2, atol=2e-2 * scale)
+    assert np.array_equal(res[0], res[1])
+    np.testing.assert_allclose(res[2], res[0] + 2.5, rtol=1e-6, atol=1e-5)
