@@ -510,6 +510,7 @@ class Plan:
     # fixed-point words with fire-and-forget integer atomics (exact, order-independent: bit-reproducible), the BatchNorm-apply pass reads the
     # totals in its prologue.  No partial rows, no finalize launch, no hand-off inside a launch.
     stats_xacc = True                  # (tests / scripts/ab_step.py flip the class attribute; no environment knob)
+    stats_xacc_pw = True               # ... also for layers whose apply pass lives in the 1x1 block behind them (round 6: publisher-only finalize)
     stats_xacc_words = 1 << 20         # 64-bit words of the accumulator arena (zeroed by one memset at the head of the forward list)
     stats_xacc_chain = 1024            # most additions one word may see per launch (416^2 x 32, 43 264 rows on 32 replicas: +8 us on a 160 us launch -> keeps its rows)
 
@@ -526,7 +527,15 @@ class Plan:
             if len(idx) != 1:
                 continue
             i = idx[0]
-            if i + 2 > len(self.fwd) - 1 or self.fwd[i + 1] is not fin or self.fwd[i + 2] is not act:
+            if i + 2 > len(self.fwd) - 1 or self.fwd[i + 1] is not fin:
+                continue
+            nxt = self.fwd[i + 2]
+            # round 6: the apply pass of this layer may live in the operand load of the 1x1 block behind it (emit_pw_fwd popped the apply entry):
+            # conv -> finalize -> pw block.  The finalize over the conv's partial rows (676 .. 2704 rows, 8 us) then becomes the PUBLISHER workgroup
+            # of the accumulator form alone -- mdcv_bn_act_fwd_xstats over an empty strip (M = 0) -- and the conv writes no rows.
+            pw_next = (self.stats_xacc_pw and nxt is not act and nxt[0] in (L.pw_conv_fwd, L.pw_conv_fwd_xstats) and len(nxt[1]) > 4
+                       and nxt[1][3] == bs.scale.data_ptr() and nxt[1][1] == y.ptr)
+            if nxt is not act and not pw_next:
                 continue
             if y.C > 1024:
                 continue
@@ -546,6 +555,13 @@ class Plan:
                 self.fwd[i] = (L.conv2d_xstats, (a[0],) + a[2:8] + (acc.data_ptr(), reps) + a[11:])
             else:
                 used -= need
+                continue
+            if pw_next:                                      # finalize entry -> publisher-only launch; the block behind it reads scale / shift as before
+                self.fwd[i + 1] = (L.bn_act_fwd_xstats, (dt, y.ptr, y.ldc, acc.data_ptr(), reps, float(y.M), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                         bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                                                         bs.scale.data_ptr(), bs.shift.data_ptr(), bs.mean.data_ptr(), bs.invstd.data_ptr(),
+                                                         None, 0, y.ptr, y.ldc, 0, y.C, act_code, slope))
+                done += 1
                 continue
             self.fwd[i + 2] = (L.bn_act_fwd_xstats, (dt, y.ptr, y.ldc, acc.data_ptr(), reps, float(y.M), bn.weight.data_ptr(), bn.bias.data_ptr(),
                                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),

@@ -31,6 +31,7 @@ def apply(codes):
 def apply_build(codes):
     engine.Plan.pw_fuse, engine.Plan.fuse_skip, engine.Plan.fuse_max_rows = BUILD_DEFAULTS["pw_fuse"], BUILD_DEFAULTS["fuse_skip"], BUILD_DEFAULTS["fuse_max_rows"]
     engine.Plan.stats_xacc = BUILD_DEFAULTS["sx"]
+    engine.Plan.stats_xacc_pw = True
     engine.Plan.pw_bwd1 = BUILD_DEFAULTS["pb"]
     engine.Plan.tune_conv = engine.Plan.tune_wgrad = 0
     engine.Plan.wgrad_after_dgrad = False
@@ -59,6 +60,8 @@ def apply_build(codes):
             engine.Plan.wgrad_after_dgrad = bool(int(c[1:]))
         if c and c[0] == "B":          # B0 / B1: 1x1 layers' backward as data gradient + weight gradient + reduce / in one launch (csrc/pw_bwd.hip)
             engine.Plan.pw_bwd1 = bool(int(c[1:]))
+        if c and c[0] == "Q":          # Q0 / Q1: layers in front of a fused 1x1 forward block keep their finalize launch / take the publisher-only accumulator form
+            engine.Plan.stats_xacc_pw = bool(int(c[1:]))
         if c and c[0] == "Y":          # Y0 / Y1: forward statistics as partial rows + finalize launch / through exact accumulators (csrc/exact_acc.h)
             engine.Plan.stats_xacc = bool(int(c[1:]))
         if c and c[0] == "P":
