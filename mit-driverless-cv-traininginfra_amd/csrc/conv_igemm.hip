@@ -2115,6 +2115,13 @@ static bool use_wgrad_stream(int dtype, int B, int Hin, int Win, int Cin, int Ho
   return mdcv_wgrad_stream_eligible(dtype, B, Hout, Wout, Cin, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc);
 }
 
+// 3x3 / stride-2 down-sampling layers: the input's four parity planes as one LDS ring (wgrad_stream_s2.hip).  Variants 9 and 10 disable it.
+static bool use_wgrad_s2(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride, int pad,
+                         int dil, long long dy_ldc, long long x_ldc) {
+  if (TUNE().wgrad_variant == 9 || TUNE().wgrad_variant == 10) return false;
+  return mdcv_wgrad_s2_eligible(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc);
+}
+
 // geometry-aware variant: the kernel mdcv_conv2d_wgrad will pick for this layer decides the split (use this one to size `ws`)
 int mdcv_conv2d_wgrad_splits_geom(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride,
                                   int pad, int dil, int dy_ldc, int x_ldc) {
@@ -2126,6 +2133,8 @@ int mdcv_conv2d_wgrad_splits_geom(int dtype, int B, int Hin, int Win, int Cin, i
     return mdcv_wgrad_stream_splits(B, Hout, Wout, Cin, Cout, dil);
   if (use_wgrad_shift(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc))
     return mdcv_wgrad_shift_splits(B, Hout, Wout, Cin, Cout);
+  if (use_wgrad_s2(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc))
+    return mdcv_wgrad_s2_splits(B, Hout, Wout, Cin, Cout);
   return mdcv_conv2d_wgrad_splits(dtype, B * Hout * Wout, Cout, KH * KW * Cin);
 }
 
@@ -2155,6 +2164,12 @@ int mdcv_conv2d_wgrad(int dtype, const void* dy, int dy_ldc, const void* x, int 
                        mdcv_wgrad_shift_splits_ok(splits, B, Hout, Wout);
   if (shift_w) {
     const int rc = mdcv_wgrad_shift(dy, dy_ldc, x, x_ldc, ws, splits, B, Hout, Wout, Cin, Cout, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, 9, accumulate, (hipStream_t)stream);
+  }
+  if (use_wgrad_s2(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, dil, dy_ldc, x_ldc) &&
+      mdcv_wgrad_s2_splits_ok(splits, B, Hout, Wout)) {
+    const int rc = mdcv_wgrad_s2(dy, dy_ldc, x, x_ldc, ws, splits, B, Hout, Wout, Cin, Cout, (hipStream_t)stream);
     if (rc) return rc;
     return launch_wgrad_reduce(ws, dw_oihw, splits, Cout, Cout_real, Cin, Cin_real, 9, accumulate, (hipStream_t)stream);
   }

@@ -62,6 +62,10 @@ struct MdcvTune {
   int stream_light_maxpos = 600000;   // light form up to this many padded stream positions (30003: everywhere, 30005: never, 30002: default)
   int stream_table = 1;            // DMA addresses from a per-block LDS table of pixel indices (34021 on / 34020 off: the lanes step (x, y, image) forward) -- round 6
   int stream_direct = 1;           // slab-free form where one split of 64 co x 32 ci tiles fills the chip (34051 on / 34050 off) -- round 6
+  int stream_s2 = 1;               // stride-2 layers on the parity-plane ring kernel (wgrad_stream_s2.hip; 34061 on / 34060 off) -- round 6
+  int stream_s2_depth = 2;         // its DMA prefetch depth (34071 .. 34073): alone 99-117 / 79-88 / 78-85 us at depth 1 / 2 / 3, the step 13.49 / 13.48 / 13.48 ms
+  int stream_s2_lds = 160 * 1024;  // LDS bound of its block (34100 + KiB; the depth shrinks until it fits).  Same-box A/B of the YOLOv3 step, bound 92 / 100 / 128 / 160 KiB:
+      // 13.17 / 13.22 / 13.13 / 13.10 ms against 13.13 with the generic kernel -- room for a main-queue workgroup beside the block buys nothing here
   int stream_light_depth = 1;      // its DMA prefetch depth (steps in flight behind the one being multiplied; 34000 + d)
   int stream_light_blocks = 256;   // its block target (33000 + n)
   int stream_tiled_blocks = 128;   // block target of the 8-wave tiled form (30000 + n).  A block fills its CU, and the weight gradients run BESIDE
@@ -129,6 +133,9 @@ inline void mdcv_tune_apply_wgrad(MdcvTune& t, int v) {
     if (b >= 4012 && b <= 4014) { t.wgrad_bna_stages = b - 4010; return; }
     if (b == 4020 || b == 4021) { t.stream_table = b - 4020; return; }
     if (b == 4050 || b == 4051) { t.stream_direct = b - 4050; return; }
+    if (b == 4060 || b == 4061) { t.stream_s2 = b - 4060; return; }
+    if (b >= 4071 && b <= 4073) { t.stream_s2_depth = b - 4070; return; }
+    if (b >= 4100 && b <= 4260) { t.stream_s2_lds = (b - 4100) * 1024; return; }
     if (b == 2) t.stream_light_maxpos = 600000;
     else if (b == 3) t.stream_light_maxpos = 1 << 30;
     else if (b == 5) t.stream_light_maxpos = 0;

@@ -28,3 +28,10 @@ bool mdcv_wgrad_stem_eligible(int dtype, int B, int H, int W, int Cin, int Cout,
 int mdcv_wgrad_stem_splits(int B, int H, int W);
 bool mdcv_wgrad_stem_splits_ok(int splits, int B, int H, int W);
 int mdcv_wgrad_stem(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int H, int W, hipStream_t st);
+// 3x3 / stride 2 / pad 1 with an even input (Hin = 2 Hout, Win = 2 Wout): the four parity planes of the input as one ring (wgrad_stream_s2.hip)
+bool mdcv_wgrad_s2_eligible(int dtype, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int KH, int KW, int stride, int pad, int dil,
+                            long long dy_ldc, long long x_ldc);
+int mdcv_wgrad_s2_splits(int B, int Hout, int Wout, int Cin, int Cout);
+bool mdcv_wgrad_s2_splits_ok(int splits, int B, int Hout, int Wout);
+int mdcv_wgrad_s2(const void* dy, int dy_ldc, const void* x, int x_ldc, float* ws, int splits, int B, int Hout, int Wout, int Cin, int Cout,
+                  hipStream_t st);

@@ -958,6 +958,53 @@ def test_wgrad_stream_kernel(case):
     np.testing.assert_allclose(outs[0][0], outs[34050][0], rtol=1e-3, atol=1e-3 * scale)   # slab-free form (where taken: splits == 1): same products, another summation order
 
 
+WGRAD_S2_CASES = [  # B, Cin, Cout, Hout, Wout  (input 2 Hout x 2 Wout); last entry: x / dy are channel slices of wider buffers
+    (2, 32, 64, 13, 13, 0), (3, 64, 128, 9, 14, 0), (2, 128, 256, 26, 26, 0), (1, 32, 64, 52, 52, 0), (4, 96, 192, 5, 4, 0), (2, 64, 64, 40, 7, 0),
+    (5, 32, 128, 13, 11, 8), (32, 512, 1024, 13, 13, 0)]
+
+
+@pytest.mark.parametrize("case", WGRAD_S2_CASES, ids=[str(c) for c in WGRAD_S2_CASES])
+def test_wgrad_stride2_parity_plane_kernel(case):
+    """3x3 / stride-2 / pad-1 weight gradient (Darknet-53's down-sampling layers, reference models.py create_modules) on the parity-plane LDS ring
+    (csrc/wgrad_stream_s2.hip) == torch reference == generic kernel; image and row boundaries, several splits and table windows, many channel
+    tiles, operands that are channel slices of wider NHWC buffers; bit-identical from run to run."""
+    L = VariantLib()
+    dt = BF16
+    B, Ci, Co, Ho, Wo, extra = case
+    H, W = 2 * Ho, 2 * Wo
+    g = torch.Generator().manual_seed(Ci + Co + Ho + 3 * Wo)
+    xw = torch.randn(B, Ci + 3 * extra, H, W, generator=g)
+    dyw = torch.randn(B, Co + 2 * extra, Ho, Wo, generator=g)
+    x, dy = xw[:, extra:extra + Ci], dyw[:, 2 * extra:2 * extra + Co]
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(rnd(dt, x), w, None, stride=2, padding=1).backward(rnd(dt, dy))
+    ref = w.grad.numpy()
+    xb, dyb = to_nhwc(xw, dt), to_nhwc(dyw, dt)
+    xl, dyl = xb.shape[-1], dyb.shape[-1]
+    xp, dyp = xb.data_ptr() + extra * 2, dyb.data_ptr() + 2 * extra * 2
+    outs = {}
+    for variant in (0, 0, 34060):               # default dispatch twice (the parity-plane kernel), 34060: the generic kernel
+        L.conv2d_wgrad_set_variant(variant)
+        try:
+            splits = L.conv2d_wgrad_splits_geom(dt, B, H, W, Ci, Ho, Wo, Co, 3, 3, 2, 1, 1, dyl, xl)
+            ws = torch.full((splits * Co * 9 * Ci,), float("nan"), dtype=torch.float32, device="cuda")
+            dw = torch.full((Co, Ci, 3, 3), 7.0, dtype=torch.float32, device="cuda")
+            L.check(L.conv2d_wgrad(dt, dyp, dyl, xp, xl, ws.data_ptr(), splits, dw.data_ptr(), 0, B, H, W, Ci, Ci,
+                                   Ho, Wo, Co, Co, 3, 3, 2, 1, 1, st()), "wgrad")
+            torch.cuda.synchronize()
+            outs.setdefault(variant, []).append((dw.cpu().numpy(), splits))
+        finally:
+            L.conv2d_wgrad_set_variant(0)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for v, runs in outs.items():
+        for got, splits in runs:
+            assert np.isfinite(got).all(), v
+            np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * scale, err_msg=f"variant {v} splits {splits}")
+    assert np.array_equal(outs[0][0][0], outs[0][1][0])                                       # fixed-order sums
+    np.testing.assert_allclose(outs[0][0][0], outs[34060][0][0], rtol=1e-3, atol=1e-3 * scale)   # same bf16 products, fp32 sums in another order
+
+
+
 @pytest.mark.parametrize("case", [(4, 128, 256, 13, 13, 1), (2, 64, 128, 26, 20, 1), (3, 256, 128, 9, 17, 2), (2, 128, 128, 52, 52, 1)], ids=str)
 def test_wgrad_tiled_light_and_heavy_forms(case):
     """The channel-tiled LDS-ring weight gradient has two forms: 128 co x 64 ci per block on 8 waves (it owns its CU) and the light one,
