@@ -63,6 +63,7 @@ struct MdcvTune {
   int stream_table = 1;            // DMA addresses from a per-block LDS table of pixel indices (34021 on / 34020 off: the lanes step (x, y, image) forward) -- round 6
   int stream_direct = 1;           // slab-free form where one split of 64 co x 32 ci tiles fills the chip (34051 on / 34050 off) -- round 6
   int stream_s2 = 1;               // stride-2 layers on the parity-plane ring kernel (wgrad_stream_s2.hip; 34061 on / 34060 off) -- round 6
+  int stream_s2_blocks = 256;      // its block target (35000 + n): 128 / 192 / 256 / 384 / 512 -> 13.04 / 12.99 / 12.99 / 13.00 / 13.03 ms (YOLOv3 step, same box)
   int stream_s2_depth = 2;         // its DMA prefetch depth (34071 .. 34073): alone 99-117 / 79-88 / 78-85 us at depth 1 / 2 / 3, the step 13.49 / 13.48 / 13.48 ms
   int stream_s2_lds = 160 * 1024;  // LDS bound of its block (34100 + KiB; the depth shrinks until it fits).  Same-box A/B of the YOLOv3 step, bound 92 / 100 / 128 / 160 KiB:
       // 13.17 / 13.22 / 13.13 / 13.10 ms against 13.13 with the generic kernel -- room for a main-queue workgroup beside the block buys nothing here
@@ -127,6 +128,7 @@ inline void mdcv_tune_apply_conv(MdcvTune& t, int v) {
 inline void mdcv_tune_apply_wgrad(MdcvTune& t, int v) {
   if (v == 0) return;
   if (v >= 20000 && v < 30000) { t.wgrad_slots = v - 20000; return; }
+  if (v >= 35000 && v < 36000) { t.stream_s2_blocks = v - 35000; return; }
   if (v >= 30000 && v < 40000) {
     const int b = v - 30000;
     if (b >= 4001 && b <= 4002) { t.stream_light_depth = b - 4000; return; }

@@ -320,7 +320,7 @@ bool mdcv_wgrad_s2_eligible(int dtype, int B, int Hin, int Win, int Cin, int Hou
 
 int mdcv_wgrad_s2_splits(int B, int Hout, int Wout, int Cin, int Cout) {
   const int Mq = B * (Hout + 1) * (Wout + 1), tiles = (Cout / 64) * (Cin / 32);
-  int s = (TUNE().stream_light_blocks + tiles - 1) / tiles;
+  int s = (TUNE().stream_s2_blocks + tiles - 1) / tiles;
   const int max_s = (Mq + S2_BP * 4 - 1) / (S2_BP * 4);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
