@@ -35,6 +35,25 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert L.yolo_head_workspace_bytes(2, 3, 13, 13) > 0
 
 
+def test_stride2_weight_gradients_dispatch_to_the_parity_plane_kernel():
+    """Host side of mdcv_conv2d_wgrad's dispatch (no GPU): Darknet-53's five down-sampling layers (reference yolo_baseline.cfg, the `stride=2`
+    [convolutional] blocks at batch 32) size their slab workspace by the parity-plane ring kernel's split rule (csrc/wgrad_stream_s2.hip: 256
+    blocks of 64 co x 32 ci tiles), variant 34060 by the generic kernel's; odd inputs and channel counts the ring kernel does not tile stay generic."""
+    from mdcv import _lib
+    L = _lib.lib()
+    for Ho, Ci, Co, want in ((13, 512, 1024, 1), (26, 256, 512, 4), (52, 128, 256, 16), (104, 64, 128, 64), (208, 32, 64, 254)):
+        H = 2 * Ho
+        tiles = (Co // 64) * (Ci // 32)
+        assert L.conv2d_wgrad_splits_geom(1, 32, H, H, Ci, Ho, Ho, Co, 3, 3, 2, 1, 1, Co, Ci) == want
+        assert 192 <= want * tiles <= 256
+    generic = L.conv2d_wgrad_splits_geom(_lib.tuned(1, 34060), 32, 104, 104, 128, 52, 52, 256, 3, 3, 2, 1, 1, 256, 128)
+    assert generic != 16
+    assert L.conv2d_wgrad_splits_geom(1, 32, 105, 105, 128, 53, 53, 256, 3, 3, 2, 1, 1, 256, 128) == \
+        L.conv2d_wgrad_splits_geom(_lib.tuned(1, 34060), 32, 105, 105, 128, 53, 53, 256, 3, 3, 2, 1, 1, 256, 128)          # odd input
+    assert L.conv2d_wgrad_splits_geom(1, 32, 104, 104, 48, 52, 52, 256, 3, 3, 2, 1, 1, 256, 48) == \
+        L.conv2d_wgrad_splits_geom(_lib.tuned(1, 34060), 32, 104, 104, 48, 52, 52, 256, 3, 3, 2, 1, 1, 256, 48)            # Cin % 32 != 0
+
+
 def test_product_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
