@@ -101,6 +101,68 @@ __global__ __launch_bounds__(256) void head1x1_f32_kernel(const bf16_t* __restri
   }
 }
 
+// The same product for C = 128 (KeypointNet's head, keypoint_net.py:40) with the WEIGHTS IN REGISTERS: eight lanes share a pixel, each holds its 16 channels
+// of all 8 rows (128 VGPRs) for the life of the workgroup and walks a run of pixels.  The LDS form above issues sixteen 16-byte weight reads per 8 channels
+// per lane -- 85 us of LDS time for the 80^2 x 256-image tensor, 190 us in the step against 90 us of bytes (420 MB of features in, 52 MB of logits out).
+template <int KP, int KR>                                  // KR: rows computed (K <= KR <= KP); the others are zeros
+__global__ __launch_bounds__(256) void head1x1_f32_c128_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ out, long long M, int K, int ppb) {
+  constexpr int C = 128, CPL = 16;
+  const int tid = threadIdx.x, part = tid & 7, slot = tid >> 3;
+  float wr[KR][CPL];
+#pragma unroll
+  for (int k = 0; k < KR; ++k)
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) wr[k][j] = k < K ? w[k * C + part * CPL + j] : 0.f;
+  float bv[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) bv[k] = (bias && k < K) ? bias[k] : 0.f;
+  // Grid-stride over 32-pixel groups, PF groups requested ahead: one group in flight per wave (8 waves of 160 VGPRs per CU = 16 KiB) is the
+  // latency-bound rate -- 1.5 us per group, 3.0 TB/s; four groups ahead = 64 KiB per CU.
+  constexpr int PF = 4;
+  const long long gs = (long long)gridDim.x * 32;
+  const long long pf = (long long)blockIdx.x * 32 + slot;
+  uint4 nb[PF][2];
+#pragma unroll
+  for (int d = 0; d < PF; ++d) {
+    nb[d][0] = nb[d][1] = uint4{0, 0, 0, 0};
+    const long long pp = pf + d * gs;
+    if (pp < M) { const bf16_t* xp = x + pp * ldx + part * CPL; nb[d][0] = mdcv_ld_stream(xp); nb[d][1] = mdcv_ld_stream(xp + 8); }   // (last reader of the features on the way forward)
+  }
+  for (long long pb = pf; pb < M; pb += PF * gs) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+      const long long p = pb + d * gs;
+      if (p < M) {
+        float f[CPL];
+        const uint4 q0 = nb[d][0], q1 = nb[d][1];
+        const long long pn = p + PF * gs;
+        if (pn < M) { const bf16_t* xn = x + pn * ldx + part * CPL; nb[d][0] = mdcv_ld_stream(xn); nb[d][1] = mdcv_ld_stream(xn + 8); }
+        ET<bf16_t>::unpack(q0, f);
+        ET<bf16_t>::unpack(q1, f + 8);
+        float acc[KP];
+#pragma unroll
+        for (int k = KR; k < KP; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) t = __builtin_fmaf(f[j], wr[k][j], t);
+          t += __shfl_xor(t, 1, 64);
+          t += __shfl_xor(t, 2, 64);
+          t += __shfl_xor(t, 4, 64);
+          acc[k] = t + bv[k];
+        }
+        if (part == 0) {
+          float4* dst = reinterpret_cast<float4*>(out + p * KP);
+#pragma unroll
+          for (int k = 0; k < KP; k += 4) dst[k >> 2] = float4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+        }
+      }
+    }
+  }
+}
+
 // s[b,k] = sum_j p_j * dhm_j   (softmax Jacobian term, only needed when the heat-map itself carries a gradient)
 __global__ __launch_bounds__(256) void softmax_dot_kernel(const float* __restrict__ hm, const float* __restrict__ dhm, int HW, float* __restrict__ s) {
   __shared__ float red[4];
@@ -268,6 +330,13 @@ int mdcv_softargmax_fwd(int dtype, const void* logits, int ldc, int B, int K, in
 int mdcv_head1x1_f32(const void* x_bf16, int ldx, const float* w, const float* bias, float* out, long long M, int C, int K, void* stream) {
   if (!x_bf16 || !w || !out || M < 0 || K < 1 || K > 8 || C < 32 || (C & 31) || (ldx & 7) || ldx < C || C > 1024) return MDCV_EARG;
   if (M == 0) return MDCV_OK;
+  if (C == 128) {                                            // weights in registers, 2048 pixels per workgroup (>= 4 workgroups per CU on KeypointNet's tensors)
+    const int ppb = M >= 2048LL * 1024 ? 2048 : (M >= 256LL * 1024 ? 1024 : 256);
+    if (K <= 7) MDCV_LAUNCH((head1x1_f32_c128_kernel<8, 7>), dim3((unsigned)((M + ppb - 1) / ppb)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, ldx, w, bias, out, M, K, ppb);
+    else MDCV_LAUNCH((head1x1_f32_c128_kernel<8, 8>), dim3((unsigned)((M + ppb - 1) / ppb)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, ldx, w, bias, out, M, K, ppb);
+    MDCV_CHECK_LAUNCH();
+    return MDCV_OK;
+  }
   MDCV_LAUNCH(head1x1_f32_kernel<8>, dim3((unsigned)((M + 63) / 64)), dim3(256), (unsigned)(8 * C * 4), (hipStream_t)stream, (const bf16_t*)x_bf16, ldx, w, bias,
               out, M, C, K);
   MDCV_CHECK_LAUNCH();
