@@ -763,7 +763,8 @@ def main():
         loss = float(yolo_step()[0])
         result = {"ms_per_step": 1e3 * dt / a.steps, "value": ips}
         pcie = None
-        if a.host_input:       # what train.py's loop does with a DataLoader batch: pinned host tensors, .to(device, non_blocking=True)
+        if a.host_input or (world == 1 and not a.no_ref_loop):   # what train.py's loop does with a DataLoader batch: pinned host tensors, .to(device, non_blocking=True)
+            # (part of the default N = 1 line since round 6: VERDICT r5 found the field null in the driver's line; --host-input forces it for N > 1)
             xh, th = x.cpu().pin_memory(), tg.cpu().pin_memory()
 
             def yolo_step_h2d():
